@@ -1,0 +1,217 @@
+"""Oracle: Keras-semantics forward pass of the small CNNs.  Test infrastructure only.
+
+** parity unpinned ** -- the real forward lives in TensorFlow/Keras
+(segmenter.py:131 `keras.models.load_model`, :163 `self.nn.predict`) over
+un-vendored HDF5 assets (remote_utils.py:4-15); neither exists in this
+container.  This file restates the published Keras layer semantics:
+channels-last NHWC activations, HWIO conv kernels, 'valid'/'same' padding with
+the TF rule (extra pad goes bottom/right), BatchNormalization inference form
+gamma*(x-mean)/sqrt(var+eps)+beta, Flatten in (H,W,C) order, Dropout=identity,
+softmax over the last axis.  Two independent implementations are kept so they
+can check each other: `forward` (torch-CPU functional, fast enough to be the
+CPU baseline) and `forward_naive` (pure numpy loops, tiny cases only).
+
+A model is a list of plain dicts (same vocabulary as
+inaspeechsegmenter_amd/keras_model.py produces, but this file does not import it):
+  conv2d   : W (kh,kw,cin,cout) f32, b (cout,)|None, strides, padding, activation
+  dense    : W (in,out) f32, b (out,)|None, activation
+  batchnorm: gamma, beta, mean, var, eps
+  activation: fn ; maxpool/avgpool: pool, strides, padding ; flatten ; dropout
+  globalavgpool / globalmaxpool
+"""
+import numpy as np
+
+
+def same_pads(size, k, s):
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return total // 2, total - total // 2
+
+
+def _act_np(x, fn):
+    if fn in (None, 'linear'):
+        return x
+    if fn == 'relu':
+        return np.maximum(x, 0)
+    if fn == 'sigmoid':
+        return 1.0 / (1.0 + np.exp(-x))
+    if fn == 'tanh':
+        return np.tanh(x)
+    if fn == 'softmax':
+        e = np.exp(x - x.max(axis=-1, keepdims=True))
+        return e / e.sum(axis=-1, keepdims=True)
+    raise ValueError(fn)
+
+
+def forward(layers, x, batch_size=1024, threads=None):
+    """x: (N,H,W,C) float32 -> (N,classes) float32, torch-CPU."""
+    import torch
+    import torch.nn.functional as F
+    if threads:
+        torch.set_num_threads(threads)
+
+    def act(t, fn):
+        if fn in (None, 'linear'):
+            return t
+        if fn == 'relu':
+            return torch.relu(t)
+        if fn == 'sigmoid':
+            return torch.sigmoid(t)
+        if fn == 'tanh':
+            return torch.tanh(t)
+        if fn == 'softmax':
+            return torch.softmax(t, dim=-1)
+        raise ValueError(fn)
+
+    outs = []
+    with torch.no_grad():
+        for s in range(0, len(x), batch_size):
+            t = torch.from_numpy(np.ascontiguousarray(x[s:s + batch_size], dtype=np.float32))
+            t = t.permute(0, 3, 1, 2)                      # NCHW internally
+            flat = False
+            for L in layers:
+                ty = L['type']
+                if ty == 'conv2d':
+                    w = torch.from_numpy(np.ascontiguousarray(L['W'].transpose(3, 2, 0, 1)))
+                    b = None if L.get('b') is None else torch.from_numpy(L['b'])
+                    kh, kw = L['W'].shape[:2]
+                    sh, sw = L.get('strides', (1, 1))
+                    if L.get('padding', 'valid') == 'same':
+                        pt, pb = same_pads(t.shape[2], kh, sh)
+                        pl, pr = same_pads(t.shape[3], kw, sw)
+                        t = F.pad(t, (pl, pr, pt, pb))
+                    t = act_nchw(F.conv2d(t, w, b, stride=(sh, sw)), L.get('activation'), act)
+                elif ty == 'batchnorm':
+                    sc = L['gamma'] / np.sqrt(L['var'] + np.float32(L['eps']))
+                    sh_ = L['beta'] - L['mean'] * sc
+                    sc_t = torch.from_numpy(sc.astype(np.float32))
+                    sh_t = torch.from_numpy(sh_.astype(np.float32))
+                    if flat:
+                        t = t * sc_t + sh_t
+                    else:
+                        t = t * sc_t[None, :, None, None] + sh_t[None, :, None, None]
+                elif ty == 'activation':
+                    t = act(t, L['fn']) if flat else act_nchw(t, L['fn'], act)
+                elif ty in ('maxpool', 'avgpool'):
+                    ph, pw = L['pool']
+                    sh, sw = L.get('strides') or L['pool']
+                    if L.get('padding', 'valid') == 'same':
+                        pt, pb = same_pads(t.shape[2], ph, sh)
+                        pl, pr = same_pads(t.shape[3], pw, sw)
+                        fill = float('-inf') if ty == 'maxpool' else 0.0
+                        assert ty == 'maxpool' or (pt + pb + pl + pr) == 0, "avgpool same-pad unsupported"
+                        t = F.pad(t, (pl, pr, pt, pb), value=fill)
+                    t = F.max_pool2d(t, (ph, pw), (sh, sw)) if ty == 'maxpool' else F.avg_pool2d(t, (ph, pw), (sh, sw))
+                elif ty == 'globalavgpool':
+                    t = t.mean(dim=(2, 3)); flat = True
+                elif ty == 'globalmaxpool':
+                    t = t.amax(dim=(2, 3)); flat = True
+                elif ty == 'flatten':
+                    t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1); flat = True
+                elif ty == 'dense':
+                    assert flat, "dense on un-flattened input"
+                    t = t @ torch.from_numpy(L['W'])
+                    if L.get('b') is not None:
+                        t = t + torch.from_numpy(L['b'])
+                    t = act(t, L.get('activation'))
+                elif ty == 'dropout':
+                    pass
+                else:
+                    raise ValueError(ty)
+            outs.append(t.numpy())
+    return np.concatenate(outs) if outs else np.zeros((0, 0), np.float32)
+
+
+def act_nchw(t, fn, act):
+    if fn == 'softmax':
+        return act(t.permute(0, 2, 3, 1), fn).permute(0, 3, 1, 2)
+    return act(t, fn)
+
+
+def forward_naive(layers, x):
+    """Pure-numpy NHWC loops, float32, for tiny shapes: independent check of `forward`."""
+    t = np.asarray(x, dtype=np.float32)
+    for L in layers:
+        ty = L['type']
+        if ty == 'conv2d':
+            W = L['W']; kh, kw, cin, cout = W.shape
+            sh, sw = L.get('strides', (1, 1))
+            if L.get('padding', 'valid') == 'same':
+                pt, pb = same_pads(t.shape[1], kh, sh); pl, pr = same_pads(t.shape[2], kw, sw)
+                t = np.pad(t, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+            n, H, Wd, _ = t.shape
+            ho, wo = (H - kh) // sh + 1, (Wd - kw) // sw + 1
+            o = np.zeros((n, ho, wo, cout), np.float32)
+            for y in range(ho):
+                for xx in range(wo):
+                    patch = t[:, y * sh:y * sh + kh, xx * sw:xx * sw + kw, :].reshape(n, -1)
+                    o[:, y, xx, :] = patch @ W.reshape(-1, cout)
+            if L.get('b') is not None:
+                o = o + L['b']
+            t = _act_np(o, L.get('activation')).astype(np.float32)
+        elif ty == 'batchnorm':
+            sc = L['gamma'] / np.sqrt(L['var'] + np.float32(L['eps']))
+            t = (t * sc + (L['beta'] - L['mean'] * sc)).astype(np.float32)
+        elif ty == 'activation':
+            t = _act_np(t, L['fn']).astype(np.float32)
+        elif ty in ('maxpool', 'avgpool'):
+            ph, pw = L['pool']; sh, sw = L.get('strides') or L['pool']
+            if L.get('padding', 'valid') == 'same':
+                pt, pb = same_pads(t.shape[1], ph, sh); pl, pr = same_pads(t.shape[2], pw, sw)
+                t = np.pad(t, ((0, 0), (pt, pb), (pl, pr), (0, 0)), constant_values=-np.inf)
+            n, H, Wd, c = t.shape
+            ho, wo = (H - ph) // sh + 1, (Wd - pw) // sw + 1
+            o = np.zeros((n, ho, wo, c), np.float32)
+            for y in range(ho):
+                for xx in range(wo):
+                    win = t[:, y * sh:y * sh + ph, xx * sw:xx * sw + pw, :]
+                    o[:, y, xx, :] = win.max(axis=(1, 2)) if ty == 'maxpool' else win.mean(axis=(1, 2))
+            t = o
+        elif ty == 'globalavgpool':
+            t = t.mean(axis=(1, 2))
+        elif ty == 'globalmaxpool':
+            t = t.max(axis=(1, 2))
+        elif ty == 'flatten':
+            t = t.reshape(t.shape[0], -1)
+        elif ty == 'dense':
+            t = t @ L['W']
+            if L.get('b') is not None:
+                t = t + L['b']
+            t = _act_np(t, L.get('activation')).astype(np.float32)
+        elif ty == 'dropout':
+            pass
+        else:
+            raise ValueError(ty)
+    return t
+
+
+def flops_per_sample(layers, in_shape):
+    """2*MAC count of conv + dense layers for one (H,W,C) input (SURVEY 8d F_net)."""
+    h, w, c = in_shape
+    fl = 0
+    flat = None
+    for L in layers:
+        ty = L['type']
+        if ty == 'conv2d':
+            kh, kw, cin, cout = L['W'].shape
+            sh, sw = L.get('strides', (1, 1))
+            if L.get('padding', 'valid') == 'same':
+                h, w = -(-h // sh), -(-w // sw)
+            else:
+                h, w = (h - kh) // sh + 1, (w - kw) // sw + 1
+            fl += 2 * kh * kw * cin * cout * h * w
+            c = cout
+        elif ty in ('maxpool', 'avgpool'):
+            ph, pw = L['pool']; sh, sw = L.get('strides') or L['pool']
+            if L.get('padding', 'valid') == 'same':
+                h, w = -(-h // sh), -(-w // sw)
+            else:
+                h, w = (h - ph) // sh + 1, (w - pw) // sw + 1
+        elif ty == 'flatten':
+            flat = h * w * c
+        elif ty in ('globalavgpool', 'globalmaxpool'):
+            flat = c
+        elif ty == 'dense':
+            fl += 2 * L['W'].shape[0] * L['W'].shape[1]
+            flat = L['W'].shape[1]
+    return fl

@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""Generate the committed golden fixtures by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference).  The reference
+modules that are importable without TensorFlow (sidekit_mfcc, features_vbx,
+pyannote_viterbi, viterbi_utils, resnet -- SURVEY.md 8c) are loaded with
+importlib straight from /root/reference and executed on the inputs below; the
+oracle restatement (oracle/) is bit-checked against them while the vectors are
+written, so a committed fixture is by construction "reference output".
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*
+
+Media inputs (musanmix.wav, silence2sec.wav, lamartine.wav) and the reference's
+own golden CSV/TextGrid files are copied verbatim: they are the reference test
+suite's fixtures (run_test.py:107-148), not source code.
+"""
+import importlib.util
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+
+def ref_module(name):
+    spec = importlib.util.spec_from_file_location('ref_' + name, f'{REF}/inaSpeechSegmenter/{name}.py')
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def read_wav(path):
+    import scipy.io.wavfile as wf
+    sr, x = wf.read(path)
+    assert sr == 16000
+    if x.dtype == np.int16:
+        return x, (x / 32768.0).astype(np.float32)       # libsndfile float conversion
+    return x, x.astype(np.float32)
+
+
+def synth_signal(seed, n):
+    """Deterministic test signal: silence / noise / harmonic / chord pieces."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    x = np.zeros(n)
+    q = n // 4
+    x[q:2 * q] = rng.normal(0, 0.03, q)
+    x[2 * q:3 * q] = sum(0.1 / k * np.sin(2 * np.pi * 110 * k * t[2 * q:3 * q]) for k in range(1, 20)) \
+        * (0.6 + 0.4 * np.sin(2 * np.pi * 4 * t[2 * q:3 * q]))
+    x[3 * q:] = 0.05 * (np.sin(2 * np.pi * 440 * t[3 * q:]) + np.sin(2 * np.pi * 554.37 * t[3 * q:])) \
+        + rng.normal(0, 0.001, n - 3 * q)
+    pcm = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+    return pcm
+
+
+def main():
+    from oracle import sidekit as osk, viterbi as ovit, segment as oseg, vbx as ovbx
+
+    sk = ref_module('sidekit_mfcc')
+    vit = ref_module('pyannote_viterbi')
+    vu = ref_module('viterbi_utils')
+    fv = ref_module('features_vbx')
+
+    # ---- media + reference golden files ------------------------------------------------
+    for f in ['musanmix.wav', 'silence2sec.wav', 'lamartine.wav', 'musanmix-smn-gender.csv',
+              'musanmix-sm-gender.csv', 'silence2sec-smn-gender.csv', '0021-smn-gender.csv',
+              'musanmix-smn-gender.TextGrid']:
+        shutil.copyfile(f'{REF}/media/{f}', f'{HERE}/{f}')
+
+    # ---- mel bank ----------------------------------------------------------------------
+    bank_ref, _ = sk.trfbank(16000, 512, 100, 8000, 0, 24)
+    bank_or, _ = osk.mel_bank()
+    assert np.array_equal(bank_ref, bank_or)
+    np.save(f'{HERE}/sidekit_melbank.npy', bank_ref)
+
+    # ---- sidekit features: musanmix, silence, synthetic -----------------------------------
+    out = {}
+    for tag, sig in [('musanmix', read_wav(f'{REF}/media/musanmix.wav')[1]),
+                     ('silence', read_wav(f'{REF}/media/silence2sec.wav')[1]),
+                     ('synth', (synth_signal(1234, 48000) / 32768.0).astype(np.float32)),
+                     ('short', (synth_signal(77, 16000)[7000:7000 + 10000] / 32768.0).astype(np.float32))]:
+        with np.errstate(divide='ignore'):
+            _, loge, _, mspec = sk.mfcc(sig, get_mspec=True)
+        loge_o, mspec_o = osk.mfcc_mspec(sig)
+        assert np.array_equal(loge, loge_o, equal_nan=True) and np.array_equal(mspec, mspec_o, equal_nan=True), tag
+        out[tag + '_loge'] = loge
+        out[tag + '_mspec'] = mspec
+        print(tag, mspec.shape)
+    np.savez_compressed(f'{HERE}/sidekit_feats.npz', **out)
+
+    # ---- viterbi known-answer cases --------------------------------------------------------
+    rng = np.random.default_rng(42)
+    cases = {}
+    for i, (T, K, arg) in enumerate([(1, 2, 80), (2, 3, 80), (57, 2, 150), (400, 3, 80), (1500, 2, 80), (333, 3, 1)]):
+        p = rng.dirichlet(np.ones(K) * 0.6, size=T).astype(np.float32)
+        p[rng.random(T) < 0.05] = 0.5                       # forced ties (segmenter.py:175)
+        em = np.log(p)
+        tr = vu.diag_trans_exp(arg, K)
+        st = vit.viterbi_decoding(em, tr)
+        assert np.array_equal(st, ovit.viterbi_decoding(em, tr))
+        assert np.array_equal(tr, ovit.diag_trans_exp(arg, K))
+        cases[f'em{i}'] = em; cases[f'tr{i}'] = tr; cases[f'st{i}'] = st
+    # the energy detector's 2-state machine on real log-energies
+    loge = out['musanmix_loge']
+    thr = np.mean(loge[np.isfinite(loge)]) + np.log(0.03)
+    em = vu.pred2logemission(loge > thr); tr = vu.log_trans_exp(150, cost0=-5)
+    st = vit.viterbi_decoding(em, tr)
+    assert np.array_equal(em, ovit.pred2logemission(loge > thr)) and np.array_equal(tr, ovit.log_trans_exp(150, cost0=-5))
+    assert np.array_equal(st, oseg.energy_activity(loge, 0.03))
+    cases['energy_states_musanmix'] = st.astype(np.int8)
+    np.savez_compressed(f'{HERE}/viterbi_cases.npz', **cases)
+
+    # ---- VBx features: lamartine + reference test.h5 ----------------------------------------
+    dump = f'{HERE}/_h5dump.npz'
+    subprocess.run(['/opt/conda/bin/python3.9', '-c',
+                    "import h5py, numpy as np\n"
+                    f"f = h5py.File('{REF}/media/test.h5','r')\n"
+                    f"np.savez('{dump}', mel=f['lamartinemelbands'][:], onnx=f['lamartineonnx'][:])"], check=True)
+    h5 = np.load(dump); os.remove(dump)
+    raw, lam = read_wav(f'{REF}/media/lamartine.wav')
+    sig = np.round(lam.astype(np.float64) * 32768) / 32768          # ffmpeg pcm_s16le hop
+    # reference get_features, vbx_segmenter.py:72-89, composed from the reference's own functions
+    window = fv.povey_window(400)
+    bank = fv.mel_fbank_mx(400, 16000, NUMCHANS=64, LOFREQ=20.0, HIFREQ=7600, htk_bug=False)
+    np.random.seed(3)
+    s2 = fv.add_dither((sig * 2 ** 15).astype(int))
+    seg = np.r_[s2[240 // 2 - 1::-1], s2, s2[-1:-400 // 2 - 1:-1]]
+    fea = fv.fbank_htk(seg, window, 240, bank, USEPOWER=True, ZMEANSOURCE=True)
+    fea = fv.cmvn_floating_kaldi(fea, 150, 149, norm_vars=False).astype(np.float32)
+    assert np.array_equal(fea[:144], h5['mel']), np.abs(fea[:144] - h5['mel']).max()
+    fea_o = ovbx.get_features(sig)
+    assert np.array_equal(fea, fea_o), np.abs(fea - fea_o).max()
+    assert np.array_equal(bank, ovbx.mel_bank()) and np.array_equal(window, ovbx.povey_window())
+    np.savez_compressed(f'{HERE}/vbx_feats.npz', test_h5_melbands=h5['mel'], test_h5_onnx=h5['onnx'],
+                        lamartine_fea=fea, lamartine_pcm16=np.round(lam.astype(np.float64) * 32768).astype(np.int16))
+    print('vbx', fea.shape)
+
+    # ---- ResNet-101 topology: reference resnet.py vs the functional restatement --------------
+    import torch
+    rn = ref_module('resnet')
+    model = rn.ResNet101(feat_dim=64, embed_dim=256).eval()
+    params = ovbx.resnet101_random_params(seed=0)
+    sd = model.state_dict()
+    for k, v in params.items():
+        assert tuple(sd[k].shape) == v.shape, k
+    assert set(k for k in sd if 'num_batches' not in k) == set(params)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=False)
+    x = np.random.default_rng(5).normal(0, 1, (2, 64, 144)).astype(np.float32)
+    with torch.no_grad():
+        ref = model(torch.from_numpy(x.copy())).numpy()
+    mine = ovbx.resnet101_forward(params, x)
+    err = np.abs(ref - mine).max()
+    print('resnet oracle vs reference max abs', err, 'scale', np.abs(ref).max())
+    assert err < 1e-4 * max(1.0, np.abs(ref).max())
+    np.savez_compressed(f'{HERE}/resnet_golden.npz', x=x, emb=ref, seed=np.array(0))
+    print('done')
+
+
+if __name__ == '__main__':
+    main()
