@@ -1,0 +1,243 @@
+"""ctypes binding of libiss_hip.so (include/iss.h).  No fallback: if the shared library is
+missing, or a device call is made without a usable gfx950 GPU, this raises.
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc, --offload-arch=gfx950).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libiss_hip.so')
+
+PROG_COLS = 32
+OP_CONV, OP_POOL, OP_SOFTMAX, OP_STATPOOL = 1, 2, 3, 4
+(C_OP, C_IN, C_OUT, C_RES, C_H, C_W, C_CIN, C_HO, C_WO, C_COUT, C_KH, C_KW, C_SH, C_SW, C_PT, C_PL,
+ C_ACT, C_WOFF, C_BOFF, C_PSOFF, C_PTOFF, C_INMODE, C_POOLKIND, C_ORDER) = range(24)
+BUF_INPUT = -2
+MAX_NETS = 8
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library; raises NativeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is no CPU fallback for the feature/CNN path.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    pf, pd, pi32, pi64, pu8, pi16 = (C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_uint8), C.POINTER(C.c_int16))
+    sig = {
+        'iss_create': (C.c_int, [C.c_int, C.POINTER(vp)]),
+        'iss_destroy': (None, [vp]),
+        'iss_last_error': (C.c_char_p, [vp]),
+        'iss_version': (C.c_char_p, []),
+        'iss_set_workspace_limit': (C.c_int, [vp, u64]),
+        'iss_synchronize': (C.c_int, [vp]),
+        'iss_sidekit_tables': (C.c_int, [vp, pd, pf]),
+        'iss_signal_pcm16': (C.c_int, [vp, pi16, i64]),
+        'iss_signal_f32': (C.c_int, [vp, pf, i64]),
+        'iss_signal_pcm16_device': (C.c_int, [vp, vp, i64]),
+        'iss_sidekit': (C.c_int, [vp, pi32]),
+        'iss_get_loge': (C.c_int, [vp, pf]),
+        'iss_get_mspec': (C.c_int, [vp, pf]),
+        'iss_set_mspec': (C.c_int, [vp, pf, i32]),
+        'iss_cnn_load': (C.c_int, [vp, C.c_int, pi32, i32, pf, i64, i32, pi64, i32, i32, i32, i32]),
+        'iss_cnn_probs': (C.c_int, [vp, C.c_int, pi32, i32, pf, pu8]),
+        'iss_cnn_forward': (C.c_int, [vp, C.c_int, pf, i32, pf]),
+        'iss_cnn_flops': (C.c_int, [vp, C.c_int, pd]),
+        'iss_vbx_tables': (C.c_int, [vp, pd, pd]),
+        'iss_vbx_features': (C.c_int, [vp, pi32, pd, i64, pf, pi32]),
+        'iss_prof_enable': (C.c_int, [vp, C.c_int]),
+        'iss_prof_get': (C.c_int, [vp, C.c_int, pd, pi64, pd]),
+        'iss_prof_reset': (C.c_int, [vp]),
+        'iss_viterbi_f64': (C.c_int, [pd, i64, i32, pd, pi32]),
+        'iss_viterbi_f32': (C.c_int, [pf, i64, i32, pd, pi32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    L._iss_symbols = tuple(sig)
+    _lib = L
+    return L
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def viterbi(emission, transition):
+    """Host Viterbi (iss_viterbi_f32/f64): emission (T,K) float32|float64 log-scores,
+    transition (K,K) float64.  Returns int32 state ids (T,)."""
+    L = lib()
+    em = np.ascontiguousarray(emission)
+    if em.dtype not in (np.float32, np.float64):
+        em = em.astype(np.float64)
+    tr = np.ascontiguousarray(transition, dtype=np.float64)
+    T, K = em.shape
+    out = np.empty(T, dtype=np.int32)
+    if em.dtype == np.float32:
+        rc = L.iss_viterbi_f32(_ptr(em, C.c_float), T, K, _ptr(tr, C.c_double), _ptr(out, C.c_int32))
+    else:
+        rc = L.iss_viterbi_f64(_ptr(em, C.c_double), T, K, _ptr(tr, C.c_double), _ptr(out, C.c_int32))
+    if rc != 0:
+        raise NativeError(f"iss_viterbi failed ({rc}): T={T} K={K}")
+    return out
+
+
+class Context:
+    """One device context (stream + resident signal/features + loaded networks)."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.iss_create(int(device), C.byref(h))
+        if rc != 0:
+            raise NativeError(f"iss_create(device={device}) failed ({rc}): "
+                              f"{self._L.iss_last_error(None).decode()}")
+        self._h = h
+        self.device = device
+        self.T = 0
+        self._net_out = {}
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.iss_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise NativeError(f"{what} failed ({rc}): {self._L.iss_last_error(self._h).decode()}")
+
+    # ---- SIDEKIT front end
+    def sidekit_tables(self, window, melbank):
+        w = np.ascontiguousarray(window, dtype=np.float64)
+        b = np.ascontiguousarray(melbank, dtype=np.float32)
+        assert w.shape == (400,) and b.shape == (24, 257)
+        self._ck(self._L.iss_sidekit_tables(self._h, _ptr(w, C.c_double), _ptr(b, C.c_float)), 'iss_sidekit_tables')
+
+    def set_signal(self, sig):
+        """sig: 1-D int16 (PCM) or float32 array, 16 kHz mono."""
+        sig = np.ascontiguousarray(sig)
+        if sig.dtype == np.int16:
+            self._ck(self._L.iss_signal_pcm16(self._h, _ptr(sig, C.c_int16), sig.size), 'iss_signal_pcm16')
+        elif sig.dtype == np.float32:
+            self._ck(self._L.iss_signal_f32(self._h, _ptr(sig, C.c_float), sig.size), 'iss_signal_f32')
+        else:
+            raise TypeError(f"signal dtype {sig.dtype}: need int16 or float32")
+        self._keep = sig            # the async H2D copy reads it until the next sync
+
+    def set_signal_device(self, dev_ptr, n):
+        self._ck(self._L.iss_signal_pcm16_device(self._h, C.c_void_p(int(dev_ptr)), int(n)), 'iss_signal_pcm16_device')
+
+    def sidekit(self):
+        t = C.c_int32()
+        self._ck(self._L.iss_sidekit(self._h, C.byref(t)), 'iss_sidekit')
+        self.T = t.value
+        return self.T
+
+    def get_loge(self):
+        out = np.empty(self.T, dtype=np.float32)
+        self._ck(self._L.iss_get_loge(self._h, _ptr(out, C.c_float)), 'iss_get_loge')
+        return out
+
+    def get_mspec(self):
+        out = np.empty((self.T, 24), dtype=np.float32)
+        self._ck(self._L.iss_get_mspec(self._h, _ptr(out, C.c_float)), 'iss_get_mspec')
+        return out
+
+    def set_mspec(self, mspec):
+        m = np.ascontiguousarray(mspec, dtype=np.float32)
+        assert m.ndim == 2 and m.shape[1] == 24
+        self._ck(self._L.iss_set_mspec(self._h, _ptr(m, C.c_float), m.shape[0]), 'iss_set_mspec')
+        self.T = m.shape[0]
+
+    # ---- CNN engine
+    def cnn_load(self, net_id, compiled):
+        """compiled: keras_model.CompiledNet."""
+        prog = np.ascontiguousarray(compiled.prog, dtype=np.int32)
+        blob = np.ascontiguousarray(compiled.blob, dtype=np.float32)
+        be = np.ascontiguousarray(compiled.buf_elems, dtype=np.int64)
+        h, w, c = compiled.in_shape
+        self._ck(self._L.iss_cnn_load(self._h, net_id, _ptr(prog, C.c_int32), prog.shape[0], _ptr(blob, C.c_float),
+                                      blob.size, be.size, _ptr(be, C.c_int64), h, w, c, compiled.out_dim),
+                 'iss_cnn_load')
+        self._net_out[net_id] = compiled.out_dim
+
+    def cnn_probs(self, net_id, win_row):
+        wr = np.ascontiguousarray(win_row, dtype=np.int32)
+        n = wr.size
+        probs = np.empty((n, self._net_out[net_id]), dtype=np.float32)
+        fin = np.empty(n, dtype=np.uint8)
+        self._ck(self._L.iss_cnn_probs(self._h, net_id, _ptr(wr, C.c_int32), n, _ptr(probs, C.c_float),
+                                       _ptr(fin, C.c_uint8)), 'iss_cnn_probs')
+        return probs, fin.astype(bool)
+
+    def cnn_forward(self, net_id, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        out = np.empty((n, self._net_out[net_id]), dtype=np.float32)
+        self._ck(self._L.iss_cnn_forward(self._h, net_id, _ptr(x, C.c_float), n, _ptr(out, C.c_float)), 'iss_cnn_forward')
+        return out
+
+    def cnn_flops(self, net_id):
+        f = C.c_double()
+        self._ck(self._L.iss_cnn_flops(self._h, net_id, C.byref(f)), 'iss_cnn_flops')
+        return f.value
+
+    def set_workspace_limit(self, nbytes):
+        self._ck(self._L.iss_set_workspace_limit(self._h, int(nbytes)), 'iss_set_workspace_limit')
+
+    def synchronize(self):
+        self._ck(self._L.iss_synchronize(self._h), 'iss_synchronize')
+
+    # ---- VBx front end
+    def vbx_tables(self, window, melbank):
+        w = np.ascontiguousarray(window, dtype=np.float64)
+        b = np.ascontiguousarray(melbank, dtype=np.float64)
+        assert w.shape == (400,) and b.shape == (257, 64)
+        self._ck(self._L.iss_vbx_tables(self._h, _ptr(w, C.c_double), _ptr(b, C.c_double)), 'iss_vbx_tables')
+
+    def vbx_features(self, sig_i32, dither_u):
+        s = np.ascontiguousarray(sig_i32, dtype=np.int32)
+        u = np.ascontiguousarray(dither_u, dtype=np.float64)
+        assert s.shape == u.shape and s.ndim == 1
+        T = (s.size + 320 - 400) // 160 + 1
+        out = np.empty((T, 64), dtype=np.float32)
+        t = C.c_int32()
+        self._ck(self._L.iss_vbx_features(self._h, _ptr(s, C.c_int32), _ptr(u, C.c_double), s.size,
+                                          _ptr(out, C.c_float), C.byref(t)), 'iss_vbx_features')
+        assert t.value == T
+        return out
+
+    # ---- profiling
+    def prof_enable(self, on=True):
+        self._ck(self._L.iss_prof_enable(self._h, 1 if on else 0), 'iss_prof_enable')
+
+    def prof_reset(self):
+        self._ck(self._L.iss_prof_reset(self._h), 'iss_prof_reset')
+
+    def prof_get(self, kind):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        self._ck(self._L.iss_prof_get(self._h, kind, C.byref(ms), C.byref(n), C.byref(fl)), 'iss_prof_get')
+        return ms.value, n.value, fl.value

@@ -1,0 +1,99 @@
+// Internal state of libiss_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <string>
+#include <vector>
+#include "../../include/iss.h"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct ConvOp;   // cnn.hip
+
+struct IssNet {
+    bool loaded = false;
+    std::vector<int32_t> prog;            // nrows * ISS_PROG_COLS
+    int nrows = 0;
+    float* d_blob = nullptr;              // parameters (conv weights re-laid [Cout][Kpad])
+    int64_t blob_floats = 0;
+    std::vector<int64_t> w_dev_off;       // per row: offset of the padded weight matrix in d_blob
+    std::vector<int32_t> kpad;            // per row: K padded to the GEMM k-tile
+    int32_t* d_ktab = nullptr;            // per-conv im2col tables
+    std::vector<int64_t> ktab_off;        // per row
+    int nbuf = 0;
+    std::vector<int64_t> buf_elems;
+    int in_h = 0, in_w = 0, in_c = 0, out_dim = 0;
+    double flops_per_sample = 0;
+};
+
+struct iss_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // sidekit tables
+    bool sk_tables = false;
+    double* d_window = nullptr;           // 400
+    float* d_melw = nullptr;              // packed non-zero weights per filter
+    int32_t* d_mellim = nullptr;          // 24 x {first_bin, n_bins, weight_offset}
+    double* d_tw = nullptr;               // W256 (256 complex) then W512 (256 complex)
+
+    // resident signal
+    DevBuf sig;                           // owned copy
+    const void* sig_ptr = nullptr;        // points into sig.p or to caller's device memory
+    int sig_kind = 0;                     // 0 none, 1 pcm16, 2 f32
+    int64_t sig_n = 0;
+
+    // resident features
+    DevBuf mspec, loge;
+    int32_t T = 0;
+    bool have_feats = false;
+
+    // CNN engine
+    IssNet nets[ISS_MAX_NETS];
+    uint64_t ws_limit = 6ull << 30;
+    std::vector<DevBuf> act;              // activation buffers (grown on demand)
+    DevBuf d_winrow, d_stats, d_finite, d_out, d_in;
+
+    // vbx
+    bool vbx_tables = false;
+    double* d_vbx_window = nullptr;
+    double* d_vbx_melw = nullptr;
+    int32_t* d_vbx_mellim = nullptr;
+    DevBuf vbx_sig, vbx_dither, vbx_fb, vbx_out;
+    int32_t vbx_T = 0;
+
+    // profiling
+    bool prof = false;
+    double prof_ms[3] = {0, 0, 0};
+    int64_t prof_launch[3] = {0, 0, 0};
+    double prof_flops[3] = {0, 0, 0};
+    struct Pending { hipEvent_t a, b; int kind; double flops; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+int iss_fail(iss_ctx* c, int code, const char* fmt, ...);
+int iss_reserve(iss_ctx* c, DevBuf& b, size_t bytes);
+
+#define ISS_HIP(c, call)                                                                  \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return iss_fail((c), ISS_EHIP, "%s failed: %s (%s:%d)", #call,                \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                  \
+    } while (0)
+
+// profiling brackets: record events around a kernel class when enabled
+void iss_prof_begin(iss_ctx* c, int kind, double flops);
+void iss_prof_end(iss_ctx* c);
+void iss_prof_collect(iss_ctx* c);
+
+// implemented in the .hip files
+int iss_launch_sidekit(iss_ctx* c);
+int iss_cnn_free(iss_ctx* c, int net_id);

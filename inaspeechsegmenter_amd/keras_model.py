@@ -1,0 +1,489 @@
+"""Keras-model front end of the CNN engine: HDF5 / model_config -> layer list -> op program.
+
+The reference loads its three CNNs with `keras.models.load_model(path, compile=False)`
+(segmenter.py:129-131) from release assets named in remote_utils.py:7-15; the topology is
+NOT in the reference tree, so nothing here hard-codes one: `layers_from_keras_config`
+interprets the `model_config` JSON stored in the HDF5 file and `compile_layers` lowers the
+resulting layer list onto the op program of include/iss.h (ISS_OP_*), fusing
+bias / BatchNormalization / activation into the conv epilogue.
+
+Keras conventions honoured (Keras documentation; not visible in the reference):
+channels-last activations, HWIO conv kernels, (in,out) dense kernels, TF 'same' padding
+(extra pad bottom/right), BatchNormalization inference form with `epsilon`, Flatten in
+(H,W,C) order, Dropout = identity.
+
+File formats accepted by `load_model_file`:
+  *.hdf5 / *.h5   Keras HDF5 (needs h5py at run time)
+  *.npz           flat export written by scripts/convert_keras_hdf5.py (numpy only):
+                  key 'model_config' (JSON string) + one array per '<layer>/<weight>'.
+"""
+import json
+import os
+
+import numpy as np
+
+from . import _native as N
+
+_ACT_CODE = {None: 0, 'linear': 0, 'relu': 1, 'sigmoid': 2, 'tanh': 3}
+
+
+class CompiledNet:
+    def __init__(self, prog, blob, buf_elems, in_shape, out_dim, flops, patch_input):
+        self.prog = prog
+        self.blob = blob
+        self.buf_elems = buf_elems
+        self.in_shape = in_shape
+        self.out_dim = out_dim
+        self.flops_per_sample = flops
+        self.patch_input = patch_input
+
+
+# ------------------------------------------------------------------------------ Keras parsing
+def _pair(v):
+    return (int(v), int(v)) if np.isscalar(v) else (int(v[0]), int(v[1]))
+
+
+def layers_from_keras_config(model_config, weights):
+    """model_config: dict (parsed JSON of the HDF5 'model_config' attribute).
+    weights: dict layer_name -> dict short_weight_name -> ndarray
+             (short name = 'kernel','bias','gamma','beta','moving_mean','moving_variance').
+    Returns (layers, input_shape(H,W,C))."""
+    cls = model_config.get('class_name')
+    cfg = model_config['config']
+    klayers = cfg['layers'] if isinstance(cfg, dict) else cfg
+    if cls not in ('Sequential', 'Model', 'Functional'):
+        raise NotImplementedError(f"Keras model class {cls!r}")
+    if cls != 'Sequential':
+        # accept functional models that are a plain chain
+        for i, kl in enumerate(klayers[1:], 1):
+            inb = kl.get('inbound_nodes', [])
+            names = json.dumps(inb)
+            if names.count(klayers[i - 1]['config']['name']) < 1:
+                raise NotImplementedError("only linear-chain functional models are supported")
+    layers, in_shape = [], None
+    for kl in klayers:
+        cn, c = kl['class_name'], kl['config']
+        name = c.get('name')
+        if in_shape is None and c.get('batch_input_shape') is not None:
+            in_shape = tuple(int(v) for v in c['batch_input_shape'][1:])
+        if in_shape is None and c.get('batch_shape') is not None:
+            in_shape = tuple(int(v) for v in c['batch_shape'][1:])
+        w = weights.get(name, {})
+        if cn == 'InputLayer':
+            continue
+        if cn in ('Conv2D', 'Convolution2D'):
+            if c.get('data_format', 'channels_last') != 'channels_last':
+                raise NotImplementedError('channels_first Conv2D')
+            if _pair(c.get('dilation_rate', 1)) != (1, 1):
+                raise NotImplementedError('dilated Conv2D')
+            layers.append(dict(type='conv2d', name=name, W=np.asarray(w['kernel'], np.float32),
+                               b=np.asarray(w['bias'], np.float32) if c.get('use_bias', True) else None,
+                               strides=_pair(c.get('strides', 1)), padding=c.get('padding', 'valid'),
+                               activation=c.get('activation', 'linear')))
+        elif cn == 'Dense':
+            layers.append(dict(type='dense', name=name, W=np.asarray(w['kernel'], np.float32),
+                               b=np.asarray(w['bias'], np.float32) if c.get('use_bias', True) else None,
+                               activation=c.get('activation', 'linear')))
+        elif cn == 'BatchNormalization':
+            axis = c.get('axis', -1)
+            axis = axis[0] if isinstance(axis, (list, tuple)) else axis
+            if axis not in (-1, 3, 1):
+                raise NotImplementedError(f'BatchNormalization axis {axis}')
+            n = len(w['moving_mean'])
+            layers.append(dict(type='batchnorm', name=name,
+                               gamma=np.asarray(w['gamma'], np.float32) if c.get('scale', True) else np.ones(n, np.float32),
+                               beta=np.asarray(w['beta'], np.float32) if c.get('center', True) else np.zeros(n, np.float32),
+                               mean=np.asarray(w['moving_mean'], np.float32),
+                               var=np.asarray(w['moving_variance'], np.float32), eps=float(c.get('epsilon', 1e-3))))
+        elif cn == 'Activation':
+            layers.append(dict(type='activation', name=name, fn=c['activation']))
+        elif cn == 'ReLU':
+            layers.append(dict(type='activation', name=name, fn='relu'))
+        elif cn == 'Softmax':
+            layers.append(dict(type='activation', name=name, fn='softmax'))
+        elif cn in ('MaxPooling2D', 'AveragePooling2D'):
+            pool = _pair(c.get('pool_size', 2))
+            st = c.get('strides')
+            layers.append(dict(type='maxpool' if cn.startswith('Max') else 'avgpool', name=name, pool=pool,
+                               strides=_pair(st) if st is not None else pool, padding=c.get('padding', 'valid')))
+        elif cn == 'GlobalAveragePooling2D':
+            layers.append(dict(type='globalavgpool', name=name))
+        elif cn == 'GlobalMaxPooling2D':
+            layers.append(dict(type='globalmaxpool', name=name))
+        elif cn == 'Flatten':
+            layers.append(dict(type='flatten', name=name))
+        elif cn in ('Dropout', 'SpatialDropout2D', 'GaussianNoise', 'GaussianDropout', 'AlphaDropout'):
+            layers.append(dict(type='dropout', name=name))
+        else:
+            raise NotImplementedError(f"Keras layer {cn!r} ({name}) is not supported by the op program")
+    if in_shape is None:
+        raise ValueError("model_config carries no batch_input_shape")
+    if len(in_shape) != 3:
+        raise NotImplementedError(f"input shape {in_shape}: need (H, W, C)")
+    return layers, in_shape
+
+
+def _short(wname):
+    s = wname.split('/')[-1]
+    return s.split(':')[0]
+
+
+def load_model_file(path):
+    """-> (layers, input_shape).  See module docstring for formats."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == '.npz':
+        z = np.load(path, allow_pickle=False)
+        cfg = json.loads(str(z['model_config']))
+        weights = {}
+        for k in z.files:
+            if k == 'model_config':
+                continue
+            lname, wname = k.rsplit('/', 1) if '/' in k else (k, k)
+            weights.setdefault(lname.split('/')[0], {})[_short(wname)] = z[k]
+        return layers_from_keras_config(cfg, weights)
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError(
+            f"{path}: reading Keras HDF5 needs h5py, which is not installed in this interpreter. "
+            "Convert once with scripts/convert_keras_hdf5.py (any python with h5py) and place the "
+            ".npz next to the .hdf5.") from e
+    with h5py.File(path, 'r') as f:
+        mc = f.attrs['model_config']
+        if isinstance(mc, bytes):
+            mc = mc.decode('utf-8')
+        cfg = json.loads(mc)
+        g = f['model_weights'] if 'model_weights' in f else f
+        weights = {}
+        for lname in g:
+            names = g[lname].attrs.get('weight_names', [])
+            for wn in names:
+                wn = wn.decode('utf-8') if isinstance(wn, bytes) else wn
+                weights.setdefault(lname, {})[_short(wn)] = np.asarray(g[lname][wn])
+    return layers_from_keras_config(cfg, weights)
+
+
+# ------------------------------------------------------------------------------ lowering
+def _same_pads(size, k, s):
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2
+
+
+class _Builder:
+    def __init__(self):
+        self.rows = []
+        self.blob = []
+        self.nblob = 0
+        self.buf_elems = {}
+        self.flops = 0
+
+    def add_blob(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32).ravel()
+        off = self.nblob
+        pad = (-a.size) % 4
+        self.blob.append(a)
+        if pad:
+            self.blob.append(np.zeros(pad, np.float32))
+        self.nblob += a.size + pad
+        return off
+
+    def use_buf(self, b, elems):
+        self.buf_elems[b] = max(self.buf_elems.get(b, 0), int(elems))
+
+    def conv(self, src, dst, shape_in, Wm, kh, kw, sh, sw, pt, pl, ho, wo, bias=None, act=0, ps=None, pt_=None,
+             res=-1, inmode=0):
+        """Wm: (Cout, kh*kw*Cin) in (ky,kx,cin) order."""
+        h, w, cin = shape_in
+        cout, K = Wm.shape
+        assert K == kh * kw * cin
+        kpad = -(-K // 16) * 16
+        Wp = np.zeros((cout, kpad), np.float32)
+        Wp[:, :K] = Wm
+        r = [0] * N.PROG_COLS
+        r[N.C_OP] = N.OP_CONV
+        r[N.C_IN], r[N.C_OUT], r[N.C_RES] = src, dst, res
+        r[N.C_H], r[N.C_W], r[N.C_CIN] = h, w, cin
+        r[N.C_HO], r[N.C_WO], r[N.C_COUT] = ho, wo, cout
+        r[N.C_KH], r[N.C_KW], r[N.C_SH], r[N.C_SW], r[N.C_PT], r[N.C_PL] = kh, kw, sh, sw, pt, pl
+        r[N.C_ACT] = act
+        r[N.C_WOFF] = self.add_blob(Wp)
+        r[N.C_BOFF] = self.add_blob(bias) if bias is not None else -1
+        r[N.C_PSOFF] = self.add_blob(ps) if ps is not None else -1
+        r[N.C_PTOFF] = self.add_blob(pt_) if pt_ is not None else -1
+        r[N.C_INMODE] = inmode
+        self.rows.append(r)
+        self.use_buf(dst, ho * wo * cout)
+        self.flops += 2 * K * cout * ho * wo
+        return (ho, wo, cout)
+
+    def pool(self, src, dst, shape_in, kh, kw, sh, sw, pt, pl, ho, wo, kind):
+        h, w, c = shape_in
+        r = [0] * N.PROG_COLS
+        r[N.C_OP] = N.OP_POOL
+        r[N.C_IN], r[N.C_OUT], r[N.C_RES] = src, dst, -1
+        r[N.C_H], r[N.C_W], r[N.C_CIN] = h, w, c
+        r[N.C_HO], r[N.C_WO], r[N.C_COUT] = ho, wo, c
+        r[N.C_KH], r[N.C_KW], r[N.C_SH], r[N.C_SW], r[N.C_PT], r[N.C_PL] = kh, kw, sh, sw, pt, pl
+        r[N.C_POOLKIND] = kind
+        for col in (N.C_WOFF, N.C_BOFF, N.C_PSOFF, N.C_PTOFF):
+            r[col] = -1
+        self.rows.append(r)
+        self.use_buf(dst, ho * wo * c)
+        return (ho, wo, c)
+
+    def softmax(self, src, dst, shape_in):
+        h, w, c = shape_in
+        r = [0] * N.PROG_COLS
+        r[N.C_OP] = N.OP_SOFTMAX
+        r[N.C_IN], r[N.C_OUT], r[N.C_RES] = src, dst, -1
+        r[N.C_H], r[N.C_W], r[N.C_CIN] = h, w, c
+        r[N.C_HO], r[N.C_WO], r[N.C_COUT] = h, w, c
+        for col in (N.C_WOFF, N.C_BOFF, N.C_PSOFF, N.C_PTOFF):
+            r[col] = -1
+        self.rows.append(r)
+        self.use_buf(dst, h * w * c)
+        return shape_in
+
+    def statpool(self, src, dst, shape_in):
+        h, w, c = shape_in
+        r = [0] * N.PROG_COLS
+        r[N.C_OP] = N.OP_STATPOOL
+        r[N.C_IN], r[N.C_OUT], r[N.C_RES] = src, dst, -1
+        r[N.C_H], r[N.C_W], r[N.C_CIN] = h, w, c
+        r[N.C_HO], r[N.C_WO], r[N.C_COUT] = 1, 1, 2 * c * h
+        for col in (N.C_WOFF, N.C_BOFF, N.C_PSOFF, N.C_PTOFF):
+            r[col] = -1
+        self.rows.append(r)
+        self.use_buf(dst, 2 * c * h)
+        return (1, 1, 2 * c * h)
+
+    def finish(self, in_shape, out_dim, patch_input):
+        nbuf = max(self.buf_elems) + 1
+        be = np.array([self.buf_elems.get(i, 1) for i in range(nbuf)], dtype=np.int64)
+        blob = np.concatenate(self.blob) if self.blob else np.zeros(4, np.float32)
+        return CompiledNet(np.array(self.rows, dtype=np.int32).reshape(-1, N.PROG_COLS), blob, be,
+                           tuple(int(v) for v in in_shape), int(out_dim), float(self.flops), patch_input)
+
+
+def _bn_affine(L):
+    sc = (L['gamma'].astype(np.float64) / np.sqrt(L['var'].astype(np.float64) + L['eps']))
+    sh = L['beta'].astype(np.float64) - L['mean'].astype(np.float64) * sc
+    return sc, sh
+
+
+def compile_layers(layers, in_shape, patch_input=True):
+    """Lower a sequential layer list onto the op program.  Fusions: conv/dense + bias,
+    + BatchNorm directly after (folded into W, b), + relu/sigmoid/tanh, + BatchNorm after the
+    activation (epilogue scale/shift).  Anything left over becomes an identity 1x1 conv."""
+    B = _Builder()
+    shape = tuple(int(v) for v in in_shape)
+    cur = N.BUF_INPUT
+    first = True
+    i, n = 0, len(layers)
+
+    def nxt_buf():
+        return 0 if cur in (N.BUF_INPUT, 1) else 1
+
+    def peek(j):
+        while j < n and layers[j]['type'] == 'dropout':
+            j += 1
+        return j
+
+    while i < n:
+        L = layers[i]
+        ty = L['type']
+        if ty == 'dropout':
+            i += 1
+            continue
+        if ty == 'flatten':
+            shape = (1, 1, shape[0] * shape[1] * shape[2])
+            i += 1
+            continue
+        if ty in ('conv2d', 'dense', 'batchnorm', 'activation') and not (ty == 'activation' and L['fn'] == 'softmax'):
+            h, w, cin = shape
+            if ty == 'conv2d':
+                W = L['W']
+                kh, kw, wc, cout = W.shape
+                assert wc == cin, (L.get('name'), wc, cin)
+                sh, sw = L.get('strides', (1, 1))
+                if L.get('padding', 'valid') == 'same':
+                    ho, pt = _same_pads(h, kh, sh)
+                    wo, pl = _same_pads(w, kw, sw)
+                else:
+                    ho, wo, pt, pl = (h - kh) // sh + 1, (w - kw) // sw + 1, 0, 0
+                Wm = W.transpose(3, 0, 1, 2).reshape(cout, -1).astype(np.float64)
+                bias = None if L.get('b') is None else L['b'].astype(np.float64)
+                act_name = L.get('activation', 'linear')
+                j = i + 1
+            elif ty == 'dense':
+                assert h == 1 and w == 1, "Dense on un-flattened input is not supported"
+                W = L['W']
+                assert W.shape[0] == cin, (L.get('name'), W.shape, cin)
+                cout = W.shape[1]
+                kh = kw = sh = sw = 1
+                ho = wo = 1
+                pt = pl = 0
+                Wm = W.T.astype(np.float64)
+                bias = None if L.get('b') is None else L['b'].astype(np.float64)
+                act_name = L.get('activation', 'linear')
+                j = i + 1
+            else:                                   # stand-alone BN / activation: identity 1x1 conv carrier
+                cout = cin
+                kh = kw = sh = sw = 1
+                ho, wo, pt, pl = h, w, 0, 0
+                Wm = np.eye(cin, dtype=np.float64)
+                bias = None
+                act_name = 'linear'
+                j = i
+            softmax_after = False
+            if act_name == 'softmax':
+                act_name, softmax_after = 'linear', True
+            # BN straight after the linear part -> fold
+            j = peek(j)
+            if act_name in (None, 'linear') and not softmax_after and j < n and layers[j]['type'] == 'batchnorm':
+                sc, sft = _bn_affine(layers[j])
+                Wm = Wm * sc[:, None]
+                bias = (bias if bias is not None else 0.0) * sc + sft
+                j = peek(j + 1)
+            # activation
+            if act_name in (None, 'linear') and not softmax_after and j < n and layers[j]['type'] == 'activation' \
+                    and layers[j]['fn'] in ('relu', 'sigmoid', 'tanh'):
+                act_name = layers[j]['fn']
+                j = peek(j + 1)
+            if act_name not in _ACT_CODE:
+                raise NotImplementedError(f"activation {act_name!r}")
+            # BN after the activation -> epilogue affine
+            ps = pt_ = None
+            if not softmax_after and j < n and layers[j]['type'] == 'batchnorm':
+                sc, sft = _bn_affine(layers[j])
+                ps, pt_ = sc.astype(np.float32), sft.astype(np.float32)
+                j = peek(j + 1)
+            if j == i:                               # nothing consumed (cannot happen) -> avoid a loop
+                raise RuntimeError("lowering made no progress")
+            dst = nxt_buf()
+            inmode = 1 if (first and patch_input) else 0
+            if inmode == 1 and not (cin == 1 and h == 68 and w <= 24):
+                raise ValueError(f"patch input must be (68, <=24, 1); got {shape}")
+            shape = B.conv(cur, dst, (h, w, cin), Wm.astype(np.float32), kh, kw, sh, sw, pt, pl, ho, wo,
+                           bias=None if bias is None else np.asarray(bias, np.float32),
+                           act=_ACT_CODE[act_name], ps=ps, pt_=pt_, inmode=inmode)
+            cur, first = dst, False
+            if softmax_after:
+                dst = nxt_buf()
+                shape = B.softmax(cur, dst, shape)
+                cur = dst
+            i = j
+            continue
+        if first and patch_input:                   # network does not start with a conv: identity carrier
+            dst = nxt_buf()
+            shape = B.conv(cur, dst, shape, np.eye(1, dtype=np.float32), 1, 1, 1, 1, 0, 0, shape[0], shape[1], inmode=1)
+            cur, first = dst, False
+        if ty == 'activation' and L['fn'] == 'softmax':
+            dst = nxt_buf()
+            shape = B.softmax(cur, dst, shape)
+            cur = dst
+        elif ty in ('maxpool', 'avgpool'):
+            h, w, c = shape
+            ph, pw = L['pool']
+            sh, sw = L.get('strides') or L['pool']
+            if L.get('padding', 'valid') == 'same':
+                if ty == 'avgpool':
+                    raise NotImplementedError("AveragePooling2D(padding='same')")
+                ho, pt = _same_pads(h, ph, sh)
+                wo, pl = _same_pads(w, pw, sw)
+            else:
+                ho, wo, pt, pl = (h - ph) // sh + 1, (w - pw) // sw + 1, 0, 0
+            dst = nxt_buf()
+            shape = B.pool(cur, dst, shape, ph, pw, sh, sw, pt, pl, ho, wo, 0 if ty == 'maxpool' else 1)
+            cur = dst
+        elif ty in ('globalavgpool', 'globalmaxpool'):
+            h, w, c = shape
+            dst = nxt_buf()
+            shape = B.pool(cur, dst, shape, h, w, h, w, 0, 0, 1, 1, 1 if ty == 'globalavgpool' else 0)
+            cur = dst
+        else:
+            raise NotImplementedError(ty)
+        first = False
+        i += 1
+    if cur == N.BUF_INPUT:
+        raise ValueError("empty network")
+    out_dim = shape[0] * shape[1] * shape[2]
+    return B.finish(in_shape, out_dim, patch_input)
+
+
+# ------------------------------------------------------------------------------ ResNet-101
+def compile_resnet101(params, feat_dim=64, frames=144, eps=1e-5):
+    """params: dict keyed like resnet.py's state_dict (conv OIHW, BN weight/bias/running_*).
+    Lowers resnet.py:78-130 (Bottleneck [3,4,23,3], m_channels 32) for a fixed number of
+    frames; BatchNorm (eval mode) is folded into the preceding conv."""
+    B = _Builder()
+
+    def fold(conv, bn):
+        W = np.asarray(params[conv + '.weight'], np.float64)                      # OIHW
+        sc = np.asarray(params[bn + '.weight'], np.float64) / np.sqrt(np.asarray(params[bn + '.running_var'], np.float64) + eps)
+        sft = np.asarray(params[bn + '.bias'], np.float64) - np.asarray(params[bn + '.running_mean'], np.float64) * sc
+        Wm = (W * sc[:, None, None, None]).transpose(0, 2, 3, 1).reshape(W.shape[0], -1)
+        return Wm.astype(np.float32), sft.astype(np.float32), W.shape[2], W.shape[3]
+
+    def conv(src, dst, shape, cname, bname, stride, pad, act, res=-1):
+        Wm, b, kh, kw = fold(cname, bname)
+        h, w, _ = shape
+        ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+        return B.conv(src, dst, shape, Wm, kh, kw, stride, stride, pad, pad, ho, wo, bias=b, act=act, res=res)
+
+    shape = (feat_dim, frames, 1)                     # NHWC view of torch's (B,1,F,T)
+    A, Bb, Cc, D = 0, 1, 2, 3
+    shape = conv(N.BUF_INPUT, A, shape, 'conv1', 'bn1', 1, 1, 1)
+    cur = A
+    spare = D
+    for li, (planes, nblocks, stride) in enumerate(zip((32, 64, 128, 256), (3, 4, 23, 3), (1, 2, 2, 2)), 1):
+        for bi in range(nblocks):
+            s = stride if bi == 0 else 1
+            p = f'layer{li}.{bi}'
+            s1 = conv(cur, Bb, shape, p + '.conv1', p + '.bn1', 1, 0, 1)
+            s2 = conv(Bb, Cc, s1, p + '.conv2', p + '.bn2', s, 1, 1)
+            if (p + '.shortcut.0.weight') in params:
+                conv(cur, spare, shape, p + '.shortcut.0', p + '.shortcut.1', s, 0, 0)
+                shape = conv(Cc, spare, s2, p + '.conv3', p + '.bn3', 1, 0, 1, res=spare)   # in-place add + relu
+                cur, spare = spare, cur
+            else:
+                shape = conv(Cc, cur, s2, p + '.conv3', p + '.bn3', 1, 0, 1, res=cur)
+    shape = B.statpool(cur, Bb, shape)
+    Wm = np.asarray(params['embedding.weight'], np.float32)
+    B.conv(Bb, Cc, shape, Wm, 1, 1, 1, 1, 0, 0, 1, 1, bias=np.asarray(params['embedding.bias'], np.float32))
+    return B.finish((feat_dim, frames, 1), Wm.shape[0], False)
+
+
+# ------------------------------------------------------------------------------ synthetic nets
+def synthetic_ina_like(nmel, nclasses, seed=0):
+    """A seeded stand-in for the un-vendored Keras CNNs: same I/O contract
+    ((68,nmel,1) -> nclasses softmax, segmenter.py:146-163,184-204) and the ~1.25 M
+    parameter budget the reference quotes (Dockerfile:18), topology chosen here:
+    4 x [conv-BN-relu] with two max-pools, two dense layers, softmax."""
+    rng = np.random.default_rng(seed)
+
+    def conv(kh, kw, cin, cout):
+        return dict(type='conv2d', W=(rng.normal(0, np.sqrt(2.0 / (kh * kw * cin)), (kh, kw, cin, cout))).astype(np.float32),
+                    b=rng.normal(0, 0.05, cout).astype(np.float32), strides=(1, 1), padding='valid', activation='linear')
+
+    def bn(c):
+        return dict(type='batchnorm', gamma=rng.uniform(0.8, 1.2, c).astype(np.float32),
+                    beta=rng.normal(0, 0.1, c).astype(np.float32), mean=rng.normal(0, 0.1, c).astype(np.float32),
+                    var=rng.uniform(0.5, 1.5, c).astype(np.float32), eps=1e-3)
+
+    def dense(i, o, act):
+        return dict(type='dense', W=rng.normal(0, np.sqrt(2.0 / i), (i, o)).astype(np.float32),
+                    b=rng.normal(0, 0.05, o).astype(np.float32), activation=act)
+
+    relu = dict(type='activation', fn='relu')
+    h, w = 68, nmel
+    L = [conv(4, 5, 1, 64), bn(64), relu]; h, w = h - 3, w - 4
+    L += [conv(5, 3, 64, 64), bn(64), relu]; h, w = h - 4, w - 2
+    L += [dict(type='maxpool', pool=(2, 2), strides=(2, 2), padding='valid')]; h, w = h // 2, w // 2
+    L += [conv(3, 3, 64, 128), bn(128), relu]; h, w = h - 2, w - 2
+    L += [conv(3, 3, 128, 128), bn(128), relu]; h, w = h - 2, w - 2
+    L += [dict(type='maxpool', pool=(2, 1), strides=(2, 1), padding='valid')]; h = h // 2
+    L += [dict(type='flatten'), dense(h * w * 128, 192, 'linear'), bn(192), relu, dict(type='dropout'),
+          dense(192, 128, 'relu'), dense(128, nclasses, 'softmax')]
+    return L, (68, nmel, 1)

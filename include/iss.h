@@ -1,0 +1,166 @@
+/* iss.h -- C ABI of the MI355X-native inaSpeechSegmenter hot path (libiss_hip.so).
+ *
+ * The reference (ina-foss/inaSpeechSegmenter) has NO native/FFI boundary: its hot
+ * path is numpy + TensorFlow/Keras + onnxruntime called from Python.  The entry
+ * points below are what a ctypes binding inside the reference's own modules would
+ * call instead; each one cites the reference interface it replaces (paths are
+ * relative to the reference repo root, inaSpeechSegmenter/<file>:<line>).
+ * INTEGRATION.md shows the reference-side ctypes stub.
+ *
+ * Conventions
+ *   - plain C types only; no torch / numpy types cross this boundary.
+ *   - every function returns 0 on success, a negative ISS_E* code on failure;
+ *     iss_last_error(ctx) (ctx may be NULL for creation errors) gives the text.
+ *   - the caller owns every host buffer; the library owns all device memory,
+ *     streams and events and frees them in iss_destroy().
+ *   - one context per (device, host thread); a context is not thread-safe.
+ *   - there is NO CPU fallback: device entry points fail with ISS_ENODEV when no
+ *     gfx950 device is usable.  The host-only helpers (iss_viterbi_*) need no GPU.
+ */
+#ifndef ISS_H
+#define ISS_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISS_OK        0
+#define ISS_EINVAL   -1   /* bad argument / bad program                         */
+#define ISS_ENODEV   -2   /* no usable HIP device                               */
+#define ISS_EHIP     -3   /* a HIP runtime call failed (text in last_error)     */
+#define ISS_ESTATE   -4   /* call order violated (e.g. features before signal)  */
+#define ISS_ENOMEM   -5
+
+typedef struct iss_ctx iss_ctx;
+
+/* ------------------------------------------------------------------ context */
+int         iss_create(int device_id, iss_ctx** out);
+void        iss_destroy(iss_ctx* ctx);
+const char* iss_last_error(const iss_ctx* ctx);
+const char* iss_version(void);
+/* Cap (bytes) on the activation workspace of the CNN engine; decides how many
+ * 20 ms slots are pushed through the layer stack per pass.  Default 6 GiB.     */
+int         iss_set_workspace_limit(iss_ctx* ctx, uint64_t bytes);
+int         iss_synchronize(iss_ctx* ctx);
+
+/* ---------------------------------------------------- SIDEKIT log-mel front end
+ * replaces sidekit_mfcc.py:278-352 `mfcc(sig, get_mspec=True)` as called from
+ * segmenter.py:58 (framing 400/160, per-frame pre-emphasis, log-energy, Hann,
+ * rfft-512 in float64, 24-band mel, log).                                      */
+
+/* Constant tables (built by the host mirror with the reference's formulas):
+ * window  = numpy.hanning(400) float64         (sidekit_mfcc.py:223)
+ * melbank = trfbank(16000,512,100,8000,0,24)[0], (24,257) float32 row-major
+ *           (sidekit_mfcc.py:118-197,332).                                     */
+int iss_sidekit_tables(iss_ctx* ctx, const double* window400, const float* melbank_24x257);
+
+/* Hand a decoded 16 kHz mono signal to the device (host -> HBM copy).
+ * pcm16: what `ffmpeg -acodec pcm_s16le` produces (io.py:61-68); converted on the
+ * device as x/32768 exactly like libsndfile's float read (io.py:77).
+ * f32  : what soundfile hands back for float WAVs (io.py:52).                  */
+int iss_signal_pcm16(iss_ctx* ctx, const int16_t* pcm, int64_t n);
+int iss_signal_f32(iss_ctx* ctx, const float* sig, int64_t n);
+/* Same, but the samples are ALREADY in device memory (hipMalloc'ed pointer, e.g. a
+ * torch tensor's data_ptr); no copy, the buffer must outlive the feature call.   */
+int iss_signal_pcm16_device(iss_ctx* ctx, const void* dev_pcm, int64_t n);
+
+/* Run the front end on the resident signal.  Results stay in HBM (mspec (T,24),
+ * loge (T,)); *T_out = int((n-400)/160)+1 (sidekit_mfcc.py:254), 0 if n < 400. */
+int iss_sidekit(iss_ctx* ctx, int32_t* T_out);
+int iss_get_loge(iss_ctx* ctx, float* loge_out /* T */);
+int iss_get_mspec(iss_ctx* ctx, float* mspec_out /* T*24 */);
+/* Replace the resident mel spectrogram (segment_feats(mspec, ...) entry,
+ * segmenter.py:250, and the <68-frame padding of segmenter.py:61-65).          */
+int iss_set_mspec(iss_ctx* ctx, const float* mspec, int32_t T);
+
+/* ------------------------------------------------------------ small-CNN engine
+ * replaces segmenter.py:76-88 `_get_patches` + :156-163 gather + `nn.predict`.
+ *
+ * A network is a flat op program (ISS_OP_* rows of ISS_PROG_COLS int32) plus one
+ * float32 parameter blob; inaspeechsegmenter_amd/keras_model.py compiles a Keras
+ * `model_config` into it.  net_id in [0, ISS_MAX_NETS).                        */
+#define ISS_MAX_NETS   8
+#define ISS_PROG_COLS  32
+
+enum {
+    ISS_OP_CONV     = 1,  /* conv2d / dense as implicit GEMM (MFMA f32) + fused epilogue */
+    ISS_OP_POOL     = 2,  /* max / average pooling, NHWC                                 */
+    ISS_OP_SOFTMAX  = 3,  /* softmax over the channel axis                               */
+    ISS_OP_STATPOOL = 4,  /* mean || std over the time axis (resnet.py:123-127)          */
+};
+/* column meaning of a program row (unused columns = 0, absent offsets = -1) */
+enum {
+    ISS_C_OP = 0, ISS_C_IN, ISS_C_OUT, ISS_C_RES,      /* buffer ids; RES = residual add   */
+    ISS_C_H, ISS_C_W, ISS_C_CIN, ISS_C_HO, ISS_C_WO, ISS_C_COUT,
+    ISS_C_KH, ISS_C_KW, ISS_C_SH, ISS_C_SW, ISS_C_PT, ISS_C_PL,
+    ISS_C_ACT,                                          /* 0 none 1 relu 2 sigmoid 3 tanh   */
+    ISS_C_WOFF, ISS_C_BOFF,                             /* blob offsets: W [Cout][kh*kw*Cin], bias */
+    ISS_C_PSOFF, ISS_C_PTOFF,                           /* post-activation scale / shift   */
+    ISS_C_INMODE,                                       /* 0 NHWC buffer, 1 z-normed mspec patch */
+    ISS_C_POOLKIND,                                     /* POOL: 0 max 1 avg               */
+    ISS_C_ORDER,                                        /* STATPOOL out order: 0 = (c,h) torch flatten */
+};
+#define ISS_BUF_INPUT  (-2)   /* IN: the network input (patch source or iss_cnn_forward input) */
+
+/* nbuf activation buffers with buf_elems[i] floats per sample; the last op's OUT
+ * buffer holds the (out_dim,) result per sample.                                */
+int iss_cnn_load(iss_ctx* ctx, int net_id, const int32_t* prog, int32_t nrows,
+                 const float* blob, int64_t blob_floats,
+                 int32_t nbuf, const int64_t* buf_elems,
+                 int32_t in_h, int32_t in_w, int32_t in_c, int32_t out_dim);
+
+/* Class probabilities of n 20 ms slots.  win_row[i] = first mspec row of the 68-frame
+ * window feeding slot i (the host applies the 17-left/16(+1)-right edge replication of
+ * segmenter.py:83-84 when it builds this list); nmel columns are used (21 or 24,
+ * segmenter.py:146-147).  Per window: z-normalisation with population std
+ * (segmenter.py:82) and finite_out[i] = all(isfinite(normalised patch)) (:86); windows
+ * that are not finite get probs 0.5 (segmenter.py:175).                         */
+int iss_cnn_probs(iss_ctx* ctx, int net_id, const int32_t* win_row, int32_t n,
+                  float* probs_out /* n*out_dim */, uint8_t* finite_out /* n */);
+
+/* Generic batched forward on caller-supplied host input (n, in_h, in_w, in_c) f32 NHWC:
+ * replaces vbx_segmenter.py:262-266 `OnnxBackendExtractor.get_embedding` (ResNet-101
+ * of resnet.py:78-135, one launch sequence for many windows instead of batch 1).  */
+int iss_cnn_forward(iss_ctx* ctx, int net_id, const float* x, int32_t n, float* out /* n*out_dim */);
+
+/* FLOPs (2*MAC of conv/dense ops) per sample of a loaded network.               */
+int iss_cnn_flops(iss_ctx* ctx, int net_id, double* flops_per_sample);
+
+/* ------------------------------------------------ VBx 64-band fbank front end
+ * replaces vbx_segmenter.py:72-89 `get_features` (features_vbx.py:62-149).
+ * window = povey_window(400) f64; melbank = mel_fbank_mx(...) (257,64) f64 row-major.
+ * sig_i32 = (signal * 2**15).astype(int) (vbx_segmenter.py:85); dither_u = the
+ * np.random.seed(3) uniform stream of n doubles (features_vbx.py:127-128), generated
+ * on the host because it is an MT19937 stream.  out = (T,64) f32, T = n/160 style
+ * count *T_out = (n + 320 - 400)/160 + 1.                                        */
+int iss_vbx_tables(iss_ctx* ctx, const double* window400, const double* melbank_257x64);
+int iss_vbx_features(iss_ctx* ctx, const int32_t* sig_i32, const double* dither_u, int64_t n,
+                     float* fea_out /* T*64, may be NULL to keep on device */, int32_t* T_out);
+
+/* ------------------------------------------------------------ profiling hooks */
+/* Accumulated device time (ms, hipEvent-timed on the context's stream) and launch
+ * count of the dominant kernel classes since the last reset.  kind: 0 = conv/dense
+ * implicit-GEMM kernels, 1 = sidekit front end, 2 = everything else.             */
+int iss_prof_enable(iss_ctx* ctx, int on);
+int iss_prof_get(iss_ctx* ctx, int kind, double* ms, int64_t* launches, double* flops);
+int iss_prof_reset(iss_ctx* ctx);
+
+/* ------------------------------------------------------------------ host only
+ * Viterbi smoothing, replaces pyannote_viterbi.py:118-224 `viterbi_decoding` on the
+ * unconstrained path the segmenter uses (segmenter.py:72-73,176): float64 scores,
+ * uniform initial log(1/K), argmax takes the FIRST maximum, back-tracking :217-220.
+ * emission (T,K) row-major; f32 variant promotes each value to double exactly like
+ * numpy does when `np.log(r)` (float32) is added to float64 (segmenter.py:176).
+ * transition (K,K) row-major, T[i][j] = i -> j.  K <= 16.                        */
+int iss_viterbi_f64(const double* emission, int64_t T, int32_t K, const double* transition,
+                    int32_t* states_out);
+int iss_viterbi_f32(const float* emission, int64_t T, int32_t K, const double* transition,
+                    int32_t* states_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISS_H */

@@ -1,0 +1,153 @@
+"""GPU parity: CNN engine (patch gather + z-norm + implicit-GEMM conv/dense on f32 MFMA + pooling
++ softmax) vs the Keras-semantics oracle, on seeded synthetic weights.  Tolerance 1e-3 on
+probabilities is the north-star bound; observed errors are ~1e-6."""
+import os
+
+import numpy as np
+import pytest
+
+from inaspeechsegmenter_amd import keras_model as KM, segmenter as S
+from oracle import keras_cnn as ocnn, segment as oseg
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+PROB_TOL = 1e-3
+
+
+def _rand_conv(rng, kh, kw, cin, cout, strides=(1, 1), padding='valid', act='linear', bias=True):
+    return dict(type='conv2d', W=rng.normal(0, np.sqrt(2.0 / (kh * kw * cin)), (kh, kw, cin, cout)).astype(np.float32),
+                b=rng.normal(0, 0.1, cout).astype(np.float32) if bias else None, strides=strides, padding=padding,
+                activation=act)
+
+
+def _rand_bn(rng, c):
+    return dict(type='batchnorm', gamma=rng.uniform(0.5, 1.5, c).astype(np.float32), beta=rng.normal(0, 0.2, c).astype(np.float32),
+                mean=rng.normal(0, 0.2, c).astype(np.float32), var=rng.uniform(0.5, 1.5, c).astype(np.float32), eps=1e-3)
+
+
+def _rand_dense(rng, i, o, act='linear'):
+    return dict(type='dense', W=rng.normal(0, np.sqrt(1.0 / i), (i, o)).astype(np.float32),
+                b=rng.normal(0, 0.1, o).astype(np.float32), activation=act)
+
+
+def _mspec(rng, T):
+    return (rng.normal(-3, 2, (T, 24))).astype(np.float32)
+
+
+def _oracle_probs(layers, mspec, nmel, rows):
+    patches = np.stack([mspec[r:r + 68, :nmel] for r in rows])
+    flat = patches.reshape(len(rows), -1)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        z = (flat - flat.mean(axis=1, keepdims=True)) / flat.std(axis=1, keepdims=True)
+    fin = np.all(np.isfinite(z), axis=1)
+    z = np.where(fin[:, None], z, 0).reshape(len(rows), 68, nmel, 1).astype(np.float32)
+    p = ocnn.forward(layers, z)
+    p[~fin] = 0.5
+    return p, fin
+
+
+TOPOLOGIES = {
+    'conv_valid_relu_dense': lambda r, h: [_rand_conv(r, 4, 5, 1, 16, act='relu'), dict(type='flatten'),
+                                           _rand_dense(r, 65 * (h - 4) * 16, 3, 'softmax')],
+    'same_pad_stride2_bn_before_act': lambda r, h: [_rand_conv(r, 3, 3, 1, 8, padding='same'), _rand_bn(r, 8),
+                                                    dict(type='activation', fn='relu'),
+                                                    _rand_conv(r, 3, 3, 8, 20, strides=(2, 2), padding='same', act='tanh'),
+                                                    dict(type='maxpool', pool=(2, 2), strides=(2, 2), padding='valid'),
+                                                    dict(type='flatten'), _rand_dense(r, 17 * ((-(-h // 2)) // 2) * 20, 2, 'softmax')],
+    'bn_after_act_avgpool_global': lambda r, h: [_rand_conv(r, 5, 3, 1, 12, act='relu', bias=False), _rand_bn(r, 12),
+                                                 dict(type='avgpool', pool=(3, 2), strides=(2, 2), padding='valid'),
+                                                 _rand_conv(r, 1, 1, 12, 7, act='sigmoid'),
+                                                 dict(type='globalavgpool'), _rand_dense(r, 7, 3, 'linear'),
+                                                 dict(type='activation', fn='softmax')],
+    'cin_not_multiple_of_4': lambda r, h: [_rand_conv(r, 2, 2, 1, 6, act='relu'), _rand_conv(r, 3, 2, 6, 10, act='relu'),
+                                           dict(type='maxpool', pool=(3, 3), strides=(3, 3), padding='same'),
+                                           dict(type='globalmaxpool'), _rand_dense(r, 10, 2, 'softmax')],
+    'standalone_bn_first': lambda r, h: [_rand_bn(r, 1), _rand_conv(r, 3, 3, 1, 4, act='relu'), dict(type='dropout'),
+                                         dict(type='flatten'), _rand_dense(r, 66 * (h - 2) * 4, 64, 'relu'), _rand_bn(r, 64),
+                                         _rand_dense(r, 64, 2, 'softmax')],
+}
+
+
+@pytest.mark.parametrize('name', sorted(TOPOLOGIES))
+@pytest.mark.parametrize('nmel', [21, 24])
+def test_layer_semantics(ctx, name, nmel):
+    rng = np.random.default_rng(sum(map(ord, name)) + nmel)
+    layers = TOPOLOGIES[name](rng, nmel)
+    comp = KM.compile_layers(layers, (68, nmel, 1))
+    ctx.cnn_load(2, comp)
+    mspec = _mspec(rng, 400)
+    ctx.set_mspec(mspec)
+    rows = rng.integers(0, 400 - 68, 301).astype(np.int32)
+    probs, fin = ctx.cnn_probs(2, rows)
+    ref, rfin = _oracle_probs(layers, mspec, nmel, rows)
+    assert np.array_equal(fin, rfin)
+    err = np.abs(probs - ref).max()
+    assert err < 1e-4, (name, err)
+
+
+@pytest.mark.parametrize('net,nmel,ncls', [('smn', 21, 3), ('gender', 24, 2)])
+def test_ina_like_net_on_real_features(ctx, net, nmel, ncls):
+    g = np.load(os.path.join(GOLDEN, 'sidekit_feats.npz'))
+    mspec = g['musanmix_mspec']
+    layers, shp = KM.synthetic_ina_like(nmel, ncls, seed=3)
+    comp = KM.compile_layers(layers, shp)
+    ctx.cnn_load(3, comp)
+    assert ctx.cnn_flops(3) == ocnn.flops_per_sample(layers, shp)
+    ctx.set_mspec(mspec)
+    rows = S._window_rows(len(mspec))
+    probs, fin = ctx.cnn_probs(3, rows)
+    patches, rfin = oseg.get_patches(mspec[:, :nmel].copy(), 68, 2)
+    assert np.array_equal(fin, rfin)
+    x = np.where(rfin[:, None, None], patches, 0)[..., None].astype(np.float32)
+    ref = ocnn.forward(layers, x)
+    ref[~rfin] = 0.5
+    err = np.abs(probs - ref).max()
+    print(f'{net}: max |p_gpu - p_oracle| = {err:.2e} over {len(rows)} slots')
+    assert err < PROB_TOL
+    assert np.array_equal(probs.argmax(1), ref.argmax(1)) or err < 1e-5
+
+
+def test_non_finite_and_constant_windows(ctx):
+    rng = np.random.default_rng(11)
+    layers, shp = KM.synthetic_ina_like(21, 3, seed=5)
+    ctx.cnn_load(3, KM.compile_layers(layers, shp))
+    mspec = _mspec(rng, 300)
+    mspec[100:110, 3] = -np.inf                  # digital silence -> log(0)
+    mspec[200:268, :] = 1.25                     # constant window -> std 0 -> nan
+    ctx.set_mspec(mspec)
+    rows = np.arange(0, 300 - 68 + 1, dtype=np.int32)
+    probs, fin = ctx.cnn_probs(3, rows)
+    ref, rfin = _oracle_probs(layers, mspec, 21, rows)
+    assert np.array_equal(fin, rfin) and (~fin).sum() > 70
+    assert np.all(probs[~fin] == 0.5)
+    assert np.abs(probs - ref).max() < PROB_TOL
+
+
+def test_chunked_passes_agree(ctx):
+    """Same slots through a tiny activation workspace (many passes) and a large one."""
+    rng = np.random.default_rng(12)
+    layers, shp = KM.synthetic_ina_like(24, 2, seed=6)
+    ctx.cnn_load(3, KM.compile_layers(layers, shp))
+    mspec = _mspec(rng, 1000)
+    ctx.set_mspec(mspec)
+    rows = rng.integers(0, 1000 - 68, 1500).astype(np.int32)
+    ctx.set_workspace_limit(64 << 20)
+    a, _ = ctx.cnn_probs(3, rows)
+    ctx.set_workspace_limit(6 << 30)
+    b, _ = ctx.cnn_probs(3, rows)
+    assert np.array_equal(a, b)
+    c, _ = ctx.cnn_probs(3, rows[:1])
+    assert np.array_equal(c[0], a[0])
+    assert ctx.cnn_probs(3, rows[:0])[0].shape == (0, 2)
+
+
+def test_generic_forward_nhwc(ctx):
+    rng = np.random.default_rng(13)
+    layers = [_rand_conv(rng, 3, 3, 8, 16, padding='same', act='relu'), _rand_conv(rng, 1, 1, 16, 32, strides=(2, 2)),
+              dict(type='flatten'), _rand_dense(rng, 5 * 6 * 32, 10)]
+    comp = KM.compile_layers(layers, (9, 11, 8), patch_input=False)
+    ctx.cnn_load(4, comp)
+    x = rng.normal(0, 1, (37, 9, 11, 8)).astype(np.float32)
+    out = ctx.cnn_forward(4, x)
+    ref = ocnn.forward(layers, x)
+    assert np.abs(out - ref).max() < 1e-4 * max(1, np.abs(ref).max())

@@ -1,0 +1,99 @@
+"""GPU parity: SIDEKIT front-end kernel (through the C ABI) vs the committed reference outputs
+and the oracle.  Tolerances: log-energy 2e-6 abs (float32 log differs by <= 1 ulp; partial sums
+are bit-identical), log-mel 1e-4 abs (float32 mel summation order differs from BLAS)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sidekit as osk
+from conftest import GOLDEN, read_wav_int16, synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+LOGE_TOL = 2e-6
+MSPEC_TOL = 1e-4
+
+
+def _run(ctx, sig):
+    ctx.set_signal(sig)
+    T = ctx.sidekit()
+    return ctx.get_loge(), ctx.get_mspec(), T
+
+
+def _check(loge, mspec, ref_loge, ref_mspec, tag):
+    assert loge.shape == ref_loge.shape and mspec.shape == ref_mspec.shape, tag
+    fin = np.isfinite(ref_loge)
+    assert np.array_equal(np.isfinite(loge), fin), tag
+    assert np.array_equal(loge[~fin], ref_loge[~fin]), tag                  # -inf on digital silence
+    assert np.abs(loge[fin] - ref_loge[fin]).max() <= LOGE_TOL * max(1.0, np.abs(ref_loge[fin]).max()), tag
+    finm = np.isfinite(ref_mspec)
+    assert np.array_equal(np.isfinite(mspec), finm), tag
+    assert np.array_equal(mspec[~finm], ref_mspec[~finm]), tag
+    if finm.any():
+        err = np.abs(mspec[finm] - ref_mspec[finm]).max()
+        assert err <= MSPEC_TOL, (tag, err)
+
+
+def test_golden_reference_outputs(ctx):
+    g = np.load(os.path.join(GOLDEN, 'sidekit_feats.npz'))
+    cases = {'musanmix': read_wav_int16(os.path.join(GOLDEN, 'musanmix.wav')),
+             'silence': read_wav_int16(os.path.join(GOLDEN, 'silence2sec.wav')),
+             'synth': synth_pcm(1234, 48000), 'short': synth_pcm(77, 16000)[7000:17000]}
+    for tag, pcm in cases.items():
+        loge, mspec, T = _run(ctx, pcm)
+        _check(loge, mspec, g[tag + '_loge'], g[tag + '_mspec'], tag)
+    # how close: report the share of bit-identical log-energies on the real recording
+    loge, mspec, _ = _run(ctx, cases['musanmix'])
+    same = np.mean(loge == g['musanmix_loge'])
+    print(f'musanmix: {same * 100:.1f}% of log-energies bit-identical, '
+          f'mspec max abs err {np.abs(mspec - g["musanmix_mspec"]).max():.2e}')
+    assert same > 0.5
+
+
+def test_float32_input_path(ctx):
+    pcm = synth_pcm(5, 32000)
+    sig = (pcm / 32768.0).astype(np.float32)
+    a = _run(ctx, pcm)
+    b = _run(ctx, sig)
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
+
+
+@pytest.mark.parametrize('n', [400, 559, 560, 561, 16000, 160 * 2048 * 4 + 400 + 3])
+def test_ragged_lengths_vs_oracle(ctx, n):
+    rng = np.random.default_rng(n)
+    pcm = np.clip(rng.normal(0, 3000, n), -32768, 32767).astype(np.int16)
+    loge, mspec, T = _run(ctx, pcm)
+    assert T == (n - 400) // 160 + 1
+    ref_loge, ref_mspec = osk.mfcc_mspec((pcm / 32768.0).astype(np.float32))
+    _check(loge, mspec, ref_loge, ref_mspec, n)
+
+
+def test_full_scale_and_dc(ctx):
+    n = 8000
+    for pcm in (np.full(n, 32767, np.int16), np.full(n, -32768, np.int16),
+                np.where(np.arange(n) % 2, 32767, -32768).astype(np.int16)):
+        loge, mspec, _ = _run(ctx, pcm)
+        ref_loge, ref_mspec = osk.mfcc_mspec((pcm / 32768.0).astype(np.float32))
+        _check(loge, mspec, ref_loge, ref_mspec, 'fullscale')
+
+
+def test_one_hour_properties(ctx):
+    """Config-2 size (57.6 M samples): frame count, shift invariance (frame t of x == frame 0 of
+    x[160 t:]) and equality with the oracle on sampled frames."""
+    n = 57_600_000
+    rng = np.random.default_rng(2025)
+    pcm = (rng.standard_normal(n, dtype=np.float32) * 2000).astype(np.int16)
+    pcm[10_000_000:10_400_000] = 0
+    loge, mspec, T = _run(ctx, pcm)
+    assert T == 359_998
+    for t in (0, 1, 62_500, 62_600, 200_001, T - 1):
+        seg = pcm[160 * t:160 * t + 400 + 160 * 3]
+        l2, m2 = osk.mfcc_mspec((seg / 32768.0).astype(np.float32))
+        _check(loge[t:t + 4], mspec[t:t + 4], l2, m2, t)
+    assert np.all(np.isneginf(loge[62_600:64_000]))
+
+
+def test_short_signal_rejected(ctx):
+    ctx.set_signal(np.zeros(399, np.int16))
+    assert ctx.sidekit() == 0

@@ -1,0 +1,204 @@
+"""CPU: host-side product code (no device calls): C-ABI exports, compiled Viterbi, tables, WAV
+reader, exporters, window arithmetic, Keras lowering, sharding."""
+import ctypes
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from inaspeechsegmenter_amd import _native, tables, segmenter as S, keras_model as KM
+from inaspeechsegmenter_amd import export_funcs, io as iss_io
+from oracle import segment as oseg, viterbi as ovit, vbx as ovbx, keras_cnn as ocnn
+from conftest import GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'iss.h')).read()
+    declared = set(re.findall(r'\b(iss_[a-z0-9_]+)\s*\(', hdr))
+    L = ctypes.CDLL(_native.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert declared == set(_native.lib()._iss_symbols)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'inaspeechsegmenter_amd')
+    for f in os.listdir(pkg):
+        if f.endswith('.py'):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_native.NativeError):
+        _native.Context(0)
+
+
+def test_compiled_viterbi_golden_and_oracle():
+    g = np.load(os.path.join(GOLDEN, 'viterbi_cases.npz'))
+    for i in range(6):
+        assert np.array_equal(_native.viterbi(g[f'em{i}'], g[f'tr{i}']), g[f'st{i}'].astype(np.int32))
+    rng = np.random.default_rng(3)
+    for K in (2, 3, 5):
+        em = np.log(rng.dirichlet(np.ones(K), 3000))
+        em[rng.random(3000) < 0.1] = np.log(0.5)
+        em[5] = -np.inf
+        tr = S.diag_trans_exp(3, K)
+        assert np.array_equal(_native.viterbi(em, tr), ovit.viterbi_decoding(em, tr).astype(np.int32))
+        assert np.array_equal(_native.viterbi(em.astype(np.float32), tr),
+                              ovit.viterbi_decoding(em.astype(np.float32), tr).astype(np.int32))
+
+
+def test_energy_activity_golden():
+    f = np.load(os.path.join(GOLDEN, 'sidekit_feats.npz'))
+    g = np.load(os.path.join(GOLDEN, 'viterbi_cases.npz'))
+    assert np.array_equal(S._energy_activity(f['musanmix_loge'], 0.03), g['energy_states_musanmix'])
+    assert not S._energy_activity(f['silence_loge'], 0.03).any()
+    assert np.array_equal(S.pred2logemission([0, 1, 1]), ovit.pred2logemission([0, 1, 1]))
+    assert np.array_equal(S.log_trans_exp(150, cost0=-5), ovit.log_trans_exp(150, cost0=-5))
+    assert np.array_equal(S.diag_trans_exp(80, 3), ovit.diag_trans_exp(80, 3))
+
+
+def test_tables_match_reference():
+    assert np.array_equal(tables.sidekit_melbank(), np.load(os.path.join(GOLDEN, 'sidekit_melbank.npy')))
+    assert np.array_equal(tables.vbx_melbank(), ovbx.mel_bank())
+    assert np.array_equal(tables.vbx_window(), ovbx.povey_window())
+
+
+def test_window_rows_equal_get_patches():
+    rng = np.random.default_rng(0)
+    for T in (68, 69, 70, 71, 131, 298):
+        m = rng.normal(0, 1, (T, 24)).astype(np.float32)
+        patches, _ = oseg.get_patches(m, 68, 2)
+        rows = S._window_rows(T)
+        assert len(rows) == len(patches) == -(-T // 2)
+        for i in range(len(rows)):
+            w = m[rows[i]:rows[i] + 68]
+            assert np.allclose((w - w.mean()) / w.std(), patches[i], atol=2e-5)
+    assert len(S._window_rows(68, difflen=2)) == 33          # 66-frame media -> 33 slots (0021.mp3)
+
+
+def test_binidx2seglist():
+    for seq in ([0], [1, 1], [0, 0, 1, 1, 1, 0], list('ffbbbv')):
+        assert S._binidx2seglist(np.array(seq)) == oseg.binidx2seglist(seq)
+
+
+def test_wav_reader(tmp_path):
+    pcm = iss_io.decode_pcm(os.path.join(GOLDEN, 'musanmix.wav'), ffmpeg=None)      # has a LIST chunk
+    assert pcm.dtype == np.int16 and pcm.shape == (1192367,)
+    f = iss_io.decode_pcm(os.path.join(GOLDEN, 'lamartine.wav'), ffmpeg=None)        # IEEE float + extra chunks
+    assert f.dtype == np.float32 and f.shape == (234282,)
+    import scipy.io.wavfile as wf
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        sr, ref = wf.read(os.path.join(GOLDEN, 'lamartine.wav'))
+    assert np.array_equal(ref, f)
+    s64 = iss_io.media2sig16kmono(os.path.join(GOLDEN, 'musanmix.wav'), ffmpeg=None)
+    assert s64.dtype == np.float64 and np.array_equal(s64, pcm / 32768.0)
+    with pytest.raises(NotImplementedError):
+        iss_io.media2sig16kmono('x.wav', start_sec=1.0, ffmpeg=None)
+    with pytest.raises(NotImplementedError):
+        iss_io.media2sig16kmono('http://a/b.wav', ffmpeg=None)
+    # 8 kHz file is refused like the reference (io.py:53-55)
+    import struct
+    p = tmp_path / 'a.wav'
+    d = np.zeros(100, np.int16).tobytes()
+    p.write_bytes(b'RIFF' + struct.pack('<I', 36 + len(d)) + b'WAVEfmt ' + struct.pack('<IHHIIHH', 16, 1, 1, 8000, 16000, 2, 16)
+                  + b'data' + struct.pack('<I', len(d)) + d)
+    with pytest.raises(AssertionError):
+        iss_io.decode_pcm(str(p), ffmpeg=None)
+
+
+def test_exporters_byte_identical_to_reference_goldens(tmp_path):
+    rows = [l.rstrip('\n').split('\t') for l in open(os.path.join(GOLDEN, 'musanmix-smn-gender.csv'))][1:]
+    lseg = [(r[0], float(r[1]), float(r[2])) for r in rows]
+    out = tmp_path / 'a.csv'
+    export_funcs.seg2csv(lseg, str(out))
+    assert out.read_bytes() == open(os.path.join(GOLDEN, 'musanmix-smn-gender.csv'), 'rb').read()
+    tg = tmp_path / 'a.TextGrid'
+    export_funcs.seg2textgrid(lseg, str(tg))
+    assert tg.read_bytes() == open(os.path.join(GOLDEN, 'musanmix-smn-gender.TextGrid'), 'rb').read()
+    # and against pandas itself on awkward floats
+    import pandas as pd
+    rng = np.random.default_rng(1)
+    lseg = [('speech', float(a) * .02, float(b) * .02 + 3.0) for a, b in rng.integers(0, 10 ** 6, (200, 2))]
+    s = io.StringIO()
+    pd.DataFrame.from_records(lseg, columns=['labels', 'start', 'stop']).to_csv(s, sep='\t', index=False)
+    t = io.StringIO()
+    export_funcs.seg2csv(lseg, t)
+    assert s.getvalue() == t.getvalue()
+
+
+def _keras_cfg_and_weights(rng):
+    cfg = {'class_name': 'Sequential', 'config': {'name': 'm', 'layers': [
+        {'class_name': 'Conv2D', 'config': {'name': 'c1', 'batch_input_shape': [None, 68, 21, 1], 'filters': 8,
+                                            'kernel_size': [3, 3], 'strides': [1, 1], 'padding': 'same',
+                                            'activation': 'linear', 'use_bias': True}},
+        {'class_name': 'BatchNormalization', 'config': {'name': 'b1', 'axis': [3], 'epsilon': 0.001}},
+        {'class_name': 'Activation', 'config': {'name': 'a1', 'activation': 'relu'}},
+        {'class_name': 'MaxPooling2D', 'config': {'name': 'p1', 'pool_size': [2, 2], 'strides': None, 'padding': 'valid'}},
+        {'class_name': 'Dropout', 'config': {'name': 'd', 'rate': 0.5}},
+        {'class_name': 'Flatten', 'config': {'name': 'f'}},
+        {'class_name': 'Dense', 'config': {'name': 'fc', 'units': 3, 'activation': 'softmax', 'use_bias': True}}]}}
+    w = {'c1': {'kernel': rng.normal(0, 1, (3, 3, 1, 8)), 'bias': rng.normal(0, 1, 8)},
+         'b1': {'gamma': rng.uniform(.5, 1.5, 8), 'beta': rng.normal(0, 1, 8), 'moving_mean': rng.normal(0, 1, 8),
+                'moving_variance': rng.uniform(.5, 1.5, 8)},
+         'fc': {'kernel': rng.normal(0, .05, (34 * 10 * 8, 3)), 'bias': rng.normal(0, 1, 3)}}
+    return cfg, w
+
+
+def test_keras_config_parse_and_lowering(tmp_path):
+    rng = np.random.default_rng(0)
+    cfg, w = _keras_cfg_and_weights(rng)
+    layers, shp = KM.layers_from_keras_config(cfg, w)
+    assert shp == (68, 21, 1) and [l['type'] for l in layers] == ['conv2d', 'batchnorm', 'activation', 'maxpool',
+                                                                  'dropout', 'flatten', 'dense']
+    c = KM.compile_layers(layers, shp)
+    ops = list(c.prog[:, _native.C_OP])
+    assert ops == [_native.OP_CONV, _native.OP_POOL, _native.OP_CONV, _native.OP_SOFTMAX]   # BN+relu fused
+    assert c.prog[0, _native.C_INMODE] == 1 and c.prog[0, _native.C_ACT] == 1 and c.out_dim == 3
+    assert c.flops_per_sample == ocnn.flops_per_sample(layers, shp)
+    # flat .npz round trip (what scripts/convert_keras_hdf5.py writes)
+    flat = {'model_config': np.array(json.dumps(cfg))}
+    for ln, d in w.items():
+        for wn, a in d.items():
+            flat[f'{ln}/{ln}/{wn}:0'] = a
+    np.savez(tmp_path / 'm.npz', **flat)
+    layers2, shp2 = KM.load_model_file(str(tmp_path / 'm.npz'))
+    assert shp2 == shp and np.array_equal(layers2[0]['W'], layers[0]['W'])
+    with pytest.raises(NotImplementedError):
+        KM.layers_from_keras_config({'class_name': 'Sequential', 'config': {'layers': [
+            {'class_name': 'LSTM', 'config': {'name': 'l', 'batch_input_shape': [None, 68, 21, 1]}}]}}, {})
+
+
+def test_oracle_cnn_two_implementations_agree():
+    rng = np.random.default_rng(2)
+    cfg, w = _keras_cfg_and_weights(rng)
+    layers, shp = KM.layers_from_keras_config(cfg, w)
+    x = rng.normal(0, 1, (3, 68, 21, 1)).astype(np.float32)
+    a, b = ocnn.forward(layers, x), ocnn.forward_naive(layers, x)
+    assert np.abs(a - b).max() < 1e-5 and np.allclose(a.sum(1), 1, atol=1e-5)
+    layers, shp = KM.synthetic_ina_like(21, 3, seed=1)
+    x = rng.normal(0, 1, (2, 68, 21, 1)).astype(np.float32)
+    assert np.abs(ocnn.forward(layers, x) - ocnn.forward_naive(layers, x)).max() < 1e-4
+
+
+def test_resnet_lowering_shapes():
+    params = ovbx.resnet101_random_params(0)
+    c = KM.compile_resnet101(params)
+    assert c.out_dim == 256 and c.in_shape == (64, 144, 1)
+    assert abs(c.flops_per_sample / 2 - 5.65e9) < 0.05e9          # 5.65 GMAC / window
+    assert sum(a.size for a in params.values() if a.ndim > 1) < c.blob.size
+
+
+def test_model_locator_message():
+    with pytest.raises(FileNotFoundError) as e:
+        S.locate_model('keras_speech_music_noise_cnn.hdf5')
+    assert 'releases/download/models' in str(e.value)
