@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- hours-of-audio segmented per second (smn + gender, 16 kHz mono) on N MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
+RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1] input, with the metric's smn + gender nets): every rank holds
+ONE 1 h synthetic 16 kHz mono PCM16 recording, already resident in HBM when the timed region
+starts (SURVEY.md section 8(d) generator: silence / -30 dBFS noise / harmonic "voiced" source /
+sustained chords, seeded with 20250926 + file index).  One step = one pass of the whole hot path
+over that recording:
+
+    PCM16 in HBM -> SIDEKIT log-mel kernel -> log-energy to host -> energy Viterbi (compiled host)
+                 -> VAD CNN on every 20 ms slot -> per-segment Viterbi
+                 -> gender CNN on every 20 ms slot -> per-segment Viterbi
+                 -> slot-unit segment table -> (N > 1) one RCCL all-gather of the tables
+
+"dense" mode: both networks are evaluated on 100 % of the slots, which is the most work the
+reference semantics can ever require (it runs the VAD net on `energy` slots and the gender net on
+`speech` slots only, segmenter.py:157-159) and makes the device work independent of what the
+seeded stand-in weights decide.  The reference-semantics rate is reported next to it in `config`.
+Weights are seeded stand-ins of the reference's I/O contract ((68,nmel,1) -> softmax, ~1.25 M
+parameters, Dockerfile:18): the real Keras files are release assets that cannot be fetched here.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FS = 16000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # dense f32-input MFMA peak (v_mfma_f32_32x32x2_f32)
+
+
+# ------------------------------------------------------------------------------ synthetic audio
+def synth_recording(file_index, n_samples, device):
+    """concatenation of U(2,20) s segments; kinds: exact silence 10 %, Gaussian
+    noise -30 dBFS 20 %, voiced (<= 30 harmonics of f0 in {110,200} Hz, 1/k roll-off, 4 Hz AM,
+    -20 dBFS) 40 %, music (3-5 sustained sines with slow tremolo, -18 dBFS) 30 %.  Returns a torch
+    int16 tensor on `device`.  The plan (kinds, durations, frequencies) comes from numpy's
+    default_rng(20250926 + file_index); the noise samples from a torch generator with the same seed."""
+    import torch
+    rng = np.random.default_rng(20250926 + file_index)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(20250926 + file_index)
+    out = torch.zeros(n_samples, dtype=torch.float32, device=device)
+    pos = 0
+    while pos < n_samples:
+        dur = int(rng.uniform(2.0, 20.0) * FS)
+        kind = rng.choice(4, p=[0.1, 0.2, 0.4, 0.3])
+        f0 = float(rng.choice([110.0, 200.0]))
+        nch = int(rng.integers(3, 6))
+        chord = rng.uniform(130.0, 1000.0, size=5)
+        trem = float(rng.uniform(0.2, 1.0))
+        n = min(dur, n_samples - pos)
+        if kind == 1:
+            out[pos:pos + n] = torch.randn(n, generator=gen, device=device, dtype=torch.float32) * 10 ** (-30 / 20)
+        elif kind >= 2:
+            t = torch.arange(n, device=device, dtype=torch.float32) / FS
+            if kind == 2:
+                x = torch.zeros(n, device=device)
+                for k in range(1, 31):
+                    if f0 * k < 7600:
+                        x += torch.sin(2 * np.pi * f0 * k * t) / k
+                x *= 0.6 + 0.4 * torch.sin(2 * np.pi * 4.0 * t)
+                level = 10 ** (-20 / 20)
+            else:
+                x = torch.zeros(n, device=device)
+                for f in chord[:nch]:
+                    x += torch.sin(2 * np.pi * float(f) * t)
+                x *= 0.8 + 0.2 * torch.sin(2 * np.pi * trem * t)
+                level = 10 ** (-18 / 20)
+            x *= level / torch.sqrt(torch.mean(x * x) + 1e-20)
+            out[pos:pos + n] = x
+        pos += n
+    return torch.clamp(torch.round(out * 32768.0), -32768, 32767).to(torch.int16)
+
+
+# ------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(seg, pcm_host, target_s=15.0):
+    """The oracle (numpy restatement of the reference feature path + torch-CPU Keras-semantics
+    forward + the reference-order Viterbi) on a bounded sample of the same recording."""
+    import torch
+    from oracle import sidekit as osk, segment as oseg, keras_cnn as ocnn
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    vad_layers, gen_layers = seg.vad.layers, seg.gender.layers
+
+    def run(nsec):
+        sig = (pcm_host[:nsec * FS] / 32768.0).astype(np.float32)
+        t0 = time.perf_counter()
+        mspec, loge, difflen = osk.media2feats(sig)
+        oseg.segment_feats(mspec, loge, difflen, 0, 'smn',
+                           lambda b: ocnn.forward(vad_layers, b, batch_size=1024),
+                           lambda b: ocnn.forward(gen_layers, b, batch_size=1024))
+        return time.perf_counter() - t0
+
+    probe = 20
+    t_probe = run(probe)
+    nsec = int(max(probe, min(len(pcm_host) // FS, probe * target_s / max(t_probe, 1e-3))))
+    nsec = min(nsec, 600)
+    t = run(nsec) if nsec > probe else t_probe
+    return {"value": (nsec / 3600.0) / t, "unit": "hours-of-audio/s", "cores": threads, "kind": "port",
+            "sample": f"first {nsec} s of the rank-0 recording, reference semantics (VAD on energy slots, gender on "
+                      f"speech slots), oracle/ numpy feature path + torch-CPU Keras-semantics CNN forward at "
+                      f"batch_size 1024 + reference-order Python Viterbi; {t:.2f} s wall; "
+                      f"stand-in for the TensorFlow/CPU path (TensorFlow is not installable here)",
+            "x_realtime": nsec / t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--minutes', type=float, default=60.0, help='length of each rank\'s recording')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from inaspeechsegmenter_amd import Segmenter
+    from inaspeechsegmenter_amd.sharding import pack_segments, allgather_segment_tables
+
+    seg = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models='synthetic', device=local_rank)
+    n = int(args.minutes * 60 * FS)
+    pcm = synth_recording(rank, n, dev)
+    torch.cuda.synchronize()
+    hours = n / FS / 3600.0
+
+    def step(dense=True):
+        lseg = seg.segment_device_pcm(pcm.data_ptr(), n, dense=dense)
+        rows = pack_segments(rank, lseg)
+        if world > 1:
+            rows = allgather_segment_tables(rows, capacity=8192, device=dev)
+        return lseg, rows
+
+    for _ in range(args.warmup):
+        step()
+
+    def timed(k, dense):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            out = step(dense)
+        seg.ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    dt, (lseg, rows) = timed(args.steps, True)
+    value = world * args.steps * hours / dt
+
+    # reference-semantics rate (VAD on energy slots, gender on speech slots), one step, for the record
+    step(False)
+    dt_ref, (lseg_ref, _) = timed(1, False)
+    assert lseg_ref == lseg, "dense and reference-semantics passes disagree"
+    P = (seg.ctx.T + 1) // 2
+    slots = {lab: 0 for lab in ('noEnergy', 'music', 'noise', 'female', 'male')}
+    for lab, a, b in lseg:
+        slots[lab] = slots.get(lab, 0) + (b - a)
+
+    # ---- roofline of the dominant kernel class (conv/dense implicit GEMM on f32 MFMA), measured live
+    # with HIP events on the library's own stream around every launch of one extra dense step
+    seg.ctx.prof_enable(True)
+    seg.ctx.prof_reset()
+    step(True)
+    conv_ms, conv_launches, conv_flops = seg.ctx.prof_get(0)
+    sk_ms, sk_launches, _ = seg.ctx.prof_get(1)
+    other_ms, other_launches, _ = seg.ctx.prof_get(2)
+    seg.ctx.prof_enable(False)
+    achieved_tf = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get('conv_igemm_hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    sk_bytes = n * 2 + seg.ctx.T * 25 * 4                # PCM16 in + (24 mel + 1 loge) f32 out
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel (conv2d/dense implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": achieved_tf / MFMA_F32_PEAK_TF, "traffic": traffic,
+                "flops_per_launch": conv_flops / max(conv_launches, 1), "avg_launch_ms": conv_ms / max(conv_launches, 1),
+                "launches_per_step": conv_launches, "kernel_ms_per_step": conv_ms,
+                "secondary": {"kernel": "sidekit_kernel (PCM16 -> log-energy + 24-band log-mel)", "bound": "hbm",
+                              "achieved": sk_bytes / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": (sk_bytes / (sk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sk_ms > 0 else 0.0,
+                              "kernel_ms_per_step": sk_ms, "algorithmic_bytes": sk_bytes},
+                "other_kernels_ms_per_step": other_ms}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(seg, pcm[:min(n, 600 * FS)].cpu().numpy())
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        vad_f = seg.ctx.cnn_flops(0)
+        gen_f = seg.ctx.cnn_flops(1)
+        line = {
+            "metric": "hours-of-audio segmented/sec (smn+gender, 16 kHz mono)",
+            "value": value, "unit": "hours-of-audio/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (f64 FFT)", "data": "synthetic",
+            "x_realtime_per_gpu": value * 3600.0 / world,
+            "config": {"workload": f"BASELINE.json configs[1] input ({args.minutes:g} min synthetic 16 kHz mono PCM16 per GPU, "
+                                   "resident in HBM) through smn VAD + gender (the metric's nets; configs[1] itself lists smn only), "
+                                   "dense mode: both CNNs on 100% of the 20 ms slots",
+                       "audio_hours_per_step_per_gpu": hours, "slots_per_step_per_gpu": P,
+                       "weights": "seeded stand-ins, (68,21,1)->3 and (68,24,1)->2, ~1.25 M params each (real Keras files are un-vendored release assets)",
+                       "vad_flops_per_slot": vad_f, "gender_flops_per_slot": gen_f,
+                       "parallelism": f"file-parallel x{world}, one all-gather of segment tables per step" if world > 1 else "single GPU",
+                       "segments": len(lseg), "label_slots": slots,
+                       "reference_semantics": {"value": world * hours / dt_ref, "unit": "hours-of-audio/s",
+                                               "ms_per_step": dt_ref * 1e3,
+                                               "vad_slot_frac": 1.0 - slots['noEnergy'] / P,
+                                               "gender_slot_frac": (slots['female'] + slots['male']) / P}},
+            "roofline": roofline,
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -21,6 +21,14 @@
 #include "iss_internal.h"
 #include "fft256.h"
 
+// The reference rounds every float32 product and sum separately (numpy ufuncs); hipcc's default
+// -ffp-contract=fast would fuse `x - 0.97*prev` and `acc + v*v` into FMAs and move the
+// pre-emphasised samples by 1 ulp, which shows up as a -150 dB noise floor in the spectrum
+// (6e-4 on log-mel values 18 nepers below the frame maximum).  HIP's __fmul_rn/__fsub_rn are plain
+// operators inlined from a header, so the pragma alone is not enough: the Makefile also passes
+// -ffp-contract=off (explicit fma()/fmaf() calls are still honoured).
+#pragma clang fp contract(off)
+
 namespace {
 
 __device__ __forceinline__ float sample_at(const int16_t* p, int64_t i) { return (float)p[i] * (1.0f / 32768.0f); }

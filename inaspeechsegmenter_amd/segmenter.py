@@ -144,16 +144,22 @@ class DnnSegmenter:
         """(n,C) float32 probabilities (+ finite mask) for the given slots of the resident mspec."""
         return self.ctx.cnn_probs(self.net_id, win_rows)
 
-    def __call__(self, mspec, lseg, difflen=0):
+    def __call__(self, mspec, lseg, difflen=0, dense=False):
         """mspec: the RESIDENT mel spectrogram's frame count holder (`_Resident`) or a (T,24)
         array (uploaded first).  lseg: [(label, start, stop)] in 20 ms slots.  Returns the
-        refined list, like segmenter.py:135-179."""
+        refined list, like segmenter.py:135-179.
+        dense=True evaluates the network on EVERY slot of the file and then keeps the rows of
+        the `inlabel` segments (same result; input-independent device work, used by bench.py)."""
         nframes = _ensure_resident(self.ctx, mspec)
         rows = _window_rows(nframes, difflen)
         todo = [(start, stop) for lab, start, stop in lseg if lab == self.inlabel]
         if todo:
             idx = np.concatenate([np.arange(s, e) for s, e in todo])
-            rawpred, _finite = self.predict_slots(rows[idx])      # non-finite windows already at 0.5 (:175)
+            if dense:
+                allpred, _finite = self.predict_slots(rows)
+                rawpred = allpred[idx]
+            else:
+                rawpred, _finite = self.predict_slots(rows[idx])  # non-finite windows already at 0.5 (:175)
         ret = []
         trans = diag_trans_exp(self.viterbi_arg, len(self.outlabels))
         pos = 0
@@ -276,15 +282,31 @@ class Segmenter:
         if detect_gender:
             self.gender = Gender(batch_size, self.ctx, models)
 
-    def segment_feats(self, mspec, loge, difflen, start_sec):
-        """segmenter.py:250-276.  `mspec` may be a (T,24) array or the resident handle."""
+    def segment_slots(self, mspec, loge, difflen, dense=False):
+        """The body of segmenter.py:250-275 in 20 ms slot units: [(label, start_slot, stop_slot)]."""
         lseg = []
         for lab, start, stop in _binidx2seglist(_energy_activity(loge, self.energy_ratio)[::2]):
             lseg.append(('noEnergy' if lab == 0 else 'energy', start, stop))
-        lseg = self.vad(mspec, lseg, difflen)
+        lseg = self.vad(mspec, lseg, difflen, dense=dense)
         if self.detect_gender:
-            lseg = self.gender(mspec, lseg, difflen)
+            lseg = self.gender(mspec, lseg, difflen, dense=dense)
+        return lseg
+
+    def segment_feats(self, mspec, loge, difflen, start_sec):
+        """segmenter.py:250-276.  `mspec` may be a (T,24) array or the resident handle."""
+        lseg = self.segment_slots(mspec, loge, difflen)
         return [(lab, start_sec + start * .02, start_sec + stop * .02) for lab, start, stop in lseg]
+
+    def segment_device_pcm(self, dev_ptr, n, dense=False):
+        """Hot-path entry for PCM16 samples that are ALREADY in this GPU's HBM (`dev_ptr` = a
+        hipMalloc'ed address, e.g. a torch int16 tensor's data_ptr(); it must stay alive during
+        the call).  Returns slot-unit segments [(label, start_slot, stop_slot)]."""
+        if n < 400 + 160 * 67:
+            raise ValueError("segment_device_pcm needs at least 68 frames (use segment_signal for short media)")
+        self.ctx.set_signal_device(dev_ptr, n)
+        nframes = self.ctx.sidekit()
+        loge = self.ctx.get_loge()
+        return self.segment_slots(_Resident(self.ctx, nframes), loge, 0, dense=dense)
 
     def segment_signal(self, sig, start_sec=0):
         """Native-path entry for an already decoded 16 kHz mono signal (int16 or float32)."""
