@@ -14,7 +14,9 @@ LIB_PATH = os.path.join(_HERE, 'libiss_hip.so')
 PROG_COLS = 32
 OP_CONV, OP_POOL, OP_SOFTMAX, OP_STATPOOL = 1, 2, 3, 4
 (C_OP, C_IN, C_OUT, C_RES, C_H, C_W, C_CIN, C_HO, C_WO, C_COUT, C_KH, C_KW, C_SH, C_SW, C_PT, C_PL,
- C_ACT, C_WOFF, C_BOFF, C_PSOFF, C_PTOFF, C_INMODE, C_POOLKIND, C_ORDER) = range(24)
+ C_ACT, C_WOFF, C_BOFF, C_PSOFF, C_PTOFF, C_INMODE, C_POOLKIND, C_ORDER, C_FPOOLH, C_FPOOLW) = range(26)
+PREC_BF16X3, PREC_F32 = 0, 1
+K_ALIGN = 32          # conv weight rows are padded to a multiple of this many k
 BUF_INPUT = -2
 MAX_NETS = 8
 
@@ -59,6 +61,7 @@ def lib():
         'iss_cnn_probs': (C.c_int, [vp, C.c_int, pi32, i32, pf, pu8]),
         'iss_cnn_forward': (C.c_int, [vp, C.c_int, pf, i32, pf]),
         'iss_cnn_flops': (C.c_int, [vp, C.c_int, pd]),
+        'iss_set_precision': (C.c_int, [vp, C.c_int]),
         'iss_vbx_tables': (C.c_int, [vp, pd, pd]),
         'iss_vbx_features': (C.c_int, [vp, pi32, pd, i64, pf, pi32]),
         'iss_prof_enable': (C.c_int, [vp, C.c_int]),
@@ -204,6 +207,10 @@ class Context:
         f = C.c_double()
         self._ck(self._L.iss_cnn_flops(self._h, net_id, C.byref(f)), 'iss_cnn_flops')
         return f.value
+
+    def set_precision(self, mode):
+        """PREC_BF16X3 (default: split-bf16 MFMA, float32-class results) or PREC_F32 (exact f32 MFMA)."""
+        self._ck(self._L.iss_set_precision(self._h, int(mode)), 'iss_set_precision')
 
     def set_workspace_limit(self, nbytes):
         self._ck(self._L.iss_set_workspace_limit(self._h, int(nbytes)), 'iss_set_workspace_limit')

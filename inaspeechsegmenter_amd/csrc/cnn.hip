@@ -8,10 +8,16 @@
 //
 // Kernels
 //   patch_stats_kernel   per-slot mean / population-std / finite flag     (segmenter.py:82,86)
-//   conv_igemm_kernel    conv2d + dense as implicit GEMM on v_mfma_f32_32x32x2_f32
-//                        (exact f32, 157 TFLOP/s peak); fused bias, residual add,
-//                        activation, post-activation scale/shift (BatchNorm), NHWC in/out
-//   pool_kernel          max / average pooling, NHWC
+//   conv_x3_kernel       conv2d + dense as implicit GEMM on v_mfma_f32_32x32x16_bf16 with both
+//                        operands split into bf16 hi + lo and three MFMAs per k-step
+//                        (hi*hi + hi*lo + lo*hi, f32 accumulate): 2^-16 relative operand error,
+//                        i.e. float32-class results at 16/3 x the f32-MFMA rate (gfx950 has no
+//                        xf32/TF32).  Default.
+//   conv_igemm_kernel    the same GEMM on v_mfma_f32_32x32x2_f32 (exact f32, 157 TFLOP/s peak);
+//                        iss_set_precision(ctx, ISS_PREC_F32)
+//   both: fused bias, residual add, activation, post-activation scale/shift (BatchNorm),
+//         optional fused non-overlapping max/avg pooling of 2 or 4 outputs, NHWC in/out
+//   pool_kernel          max / average pooling, NHWC (pools that cannot be fused)
 //   softmax_kernel       softmax over channels
 //   statpool_kernel      mean || std over time                           (resnet.py:123-127)
 #include "iss_internal.h"
@@ -22,15 +28,22 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128;      // GEMM rows (output pixels) per workgroup
 constexpr int BN = 64;       // GEMM cols (output channels) per workgroup
-constexpr int BK = 16;       // k-tile
+constexpr int BK = 16;       // k-tile of the f32 kernel
 constexpr int LDK = BK + 4;  // padded LDS row (floats): conflict-free ds_read_b128
+constexpr int XBK = 32;      // k-tile of the bf16x3 kernel (two k16 MFMA steps)
+constexpr int XLD = XBK + 8; // padded LDS row (bf16): 80 B, conflict-free ds_read_b128
+constexpr int KALIGN = 32;   // weight rows are padded to this many k
 
 struct ConvArgs {
     const float* in;
-    const float* w;          // [Cout][Kpad]
+    const float* w;          // [Cout][Kpad] f32
+    const uint16_t* wh;      // [Cout][Kpad] bf16 hi part
+    const uint16_t* wl;      // [Cout][Kpad] bf16 lo part
     const float* bias;       // [Cout] or null
     const float* ps;         // post-activation scale [Cout] or null
     const float* pt;         // post-activation shift
@@ -40,13 +53,43 @@ struct ConvArgs {
     const int32_t* win_row;  // PATCH mode
     const float* stats;      // PATCH mode: {mean, std} per sample
     const uint8_t* finite;   // PATCH mode
-    long long M;             // samples * Ho * Wo
+    long long M;             // samples * Hq * Wq * pp   (GEMM rows)
     long long img_stride;    // floats per input sample
-    int H, W, Cin, Ho, Wo, Cout;
+    int H, W, Cin, Cout;
+    int Hq, Wq;              // output grid the GEMM rows enumerate: pooled grid when pp > 1, else (Ho, Wo)
+    int ph, pw, pp;          // fused pool window (1,1,1 = none); rows m = q*pp + (dy*pw + dx)
+    int poolkind;            // 0 max, 1 avg
+    int H_k, kw;             // kernel height / width (vectorised loaders walk taps)
     int sh, sw, pt_, pl_;
     int row_stride, pix_stride;
     int act, Kpad, mode;
+    unsigned nblk;           // M tiles (grid.x)
 };
+
+// GEMM row -> (sample, oy, ox) of the convolution output it stands for
+__device__ __forceinline__ void map_row(const ConvArgs& p, long long m, int& b, int& oy, int& ox) {
+    long long q = m;
+    int dy = 0, dx = 0;
+    if (p.pp > 1) {
+        q = m / p.pp;
+        const int j = (int)(m - q * p.pp);
+        dy = j / p.pw; dx = j - dy * p.pw;
+    }
+    const int hw = p.Hq * p.Wq;
+    b = (int)(q / hw);
+    const int rem = (int)(q - (long long)b * hw);
+    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    oy = qy * p.ph + dy;
+    ox = qx * p.pw + dx;
+}
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed); give every XCD one contiguous
+// range of M tiles so that neighbouring tiles (which share im2col halos) hit the same L2.
+__device__ __forceinline__ unsigned tile_of_block(unsigned bid, unsigned nblk) {
+    const unsigned per = nblk >> 3;
+    if (per == 0 || bid >= per * 8) return bid;
+    return (bid & 7) * per + (bid >> 3);
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
@@ -56,8 +99,103 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Implicit-GEMM convolution.  C[m][n] = sum_k A[m][k] * Wt[n][k],
-//   m = (sample, oy, ox), n = cout, k = (ky, kx, cin)   (NHWC, weights [Cout][kh*kw*Cin]).
+// Shared epilogue.  C/D layout of the 32x32 MFMAs (f32 and bf16 alike): col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5): every lane holds 4 groups of 4 CONSECUTIVE rows, so a
+// fused pool over 2 or 4 consecutive GEMM rows (rows are enumerated pool-window-major, see
+// map_row) is a max/mean over registers of one lane -- no shuffles, no LDS.
+__device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
+    if (n >= p.Cout) return;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const float s = p.ps ? p.ps[n] : 1.f;
+    const float sh = p.pt ? p.pt[n] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const long long mb = mrow0 + 8 * g + 4 * lh;        // first of this lane's 4 consecutive rows
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x = acc[4 * g + i] + bias;
+            if (p.res && mb + i < p.M) x += p.res[(size_t)(mb + i) * p.Cout + n];
+            x = apply_act(x, p.act);
+            if (p.ps) x = x * s + sh;
+            v[i] = x;
+        }
+        if (p.pp == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (mb + i < p.M) p.out[(size_t)(mb + i) * p.Cout + n] = v[i];
+        } else if (p.pp == 4) {
+            if (mb < p.M) {
+                const float r = p.poolkind == 0 ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]))
+                                                : (v[0] + v[1] + v[2] + v[3]) * 0.25f;
+                p.out[(size_t)(mb >> 2) * p.Cout + n] = r;
+            }
+        } else {                                             // pp == 2
+#pragma unroll
+            for (int i = 0; i < 4; i += 2)
+                if (mb + i < p.M) {
+                    const float r = p.poolkind == 0 ? fmaxf(v[i], v[i + 1]) : (v[i] + v[i + 1]) * 0.5f;
+                    p.out[(size_t)((mb + i) >> 1) * p.Cout + n] = r;
+                }
+        }
+    }
+}
+
+// Unconditional loads: a load inside a divergent `if` makes hipcc put an `s_waitcnt vmcnt(0)` at the
+// join, right behind the load, which exposes the full memory latency in every k iteration.  So:
+// always load from a valid address (the tensor base when the element is out of bounds) and
+// select afterwards.
+__device__ __forceinline__ float4 ld4_or_zero(const float* base, long long off, bool ok) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (ok ? off : 0));
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ uint4 ldu4_or_zero(const uint16_t* base, size_t off, bool ok) {
+    const uint4 v = *reinterpret_cast<const uint4*>(base + (ok ? off : 0));
+    return ok ? v : make_uint4(0, 0, 0, 0);
+}
+
+// per-thread gather bookkeeping of one A row
+struct RowSrc {
+    long long base;
+    int iy0, ix0;
+    float mean, sd;
+    bool ok;
+};
+
+template <int MODE>
+__device__ __forceinline__ RowSrc row_source(const ConvArgs& p, long long m) {
+    RowSrc r;
+    r.ok = m < p.M;
+    int b, oy, ox;
+    map_row(p, r.ok ? m : 0, b, oy, ox);
+    r.iy0 = oy * p.sh - p.pt_;
+    r.ix0 = ox * p.sw - p.pl_;
+    r.mean = 0.f; r.sd = 1.f;
+    if (MODE == 2) {
+        r.base = (long long)p.win_row[b] * 24 + (long long)r.iy0 * 24 + r.ix0;
+        r.mean = p.stats[2 * b];
+        r.sd = p.stats[2 * b + 1];
+        r.ok = r.ok && p.finite[b];
+    } else {
+        r.base = (long long)b * p.img_stride + (long long)r.iy0 * p.row_stride + (long long)r.ix0 * p.pix_stride;
+    }
+    return r;
+}
+
+// one A element through the im2col table (scalar path: any Cin, and the z-normalised PATCH input)
+template <int MODE>
+__device__ __forceinline__ float gather_scalar(const ConvArgs& p, const RowSrc& r, int k) {
+    const int2 e = reinterpret_cast<const int2*>(p.ktab)[k];
+    const int iy = r.iy0 + (e.y >> 16), ix = r.ix0 + (e.y & 0xffff);
+    const bool ok = r.ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    float x = p.in[ok ? r.base + e.x : 0];
+    if (MODE == 2) x = (x - r.mean) / r.sd;
+    return ok ? x : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution, exact f32.  C[m][n] = sum_k A[m][k] * Wt[n][k],
+//   m = GEMM row (map_row), n = cout, k = (ky, kx, cin)   (NHWC, weights [Cout][Kpad]).
 // 256 threads = 4 wavefronts; wave w owns rows [32w, 32w+32) x 64 cols = two 32x32 MFMA tiles.
 // MODE: 0 = NHWC with Cin % 4 == 0 (float4 gathers), 1 = NHWC scalar gathers, 2 = z-normed patch.
 template <int MODE>
@@ -66,36 +204,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float sB[2][BN * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long m0 = (long long)blockIdx.x * BM;
+    const long long m0 = (long long)tile_of_block(blockIdx.x, p.nblk) * BM;
     const int n0 = blockIdx.y * BN;
 
-    // ---- per-thread gather bookkeeping: this thread fills (row r, k4) and (row r+64, k4) of sA
+    // this thread fills (row lr, k4) and (row lr+64, k4) of sA
     const int k4 = tid & 3;
     const int lr = tid >> 2;
-    long long base[2];
-    int iy0[2], ix0[2];
-    float mean[2] = {0.f, 0.f}, sd[2] = {1.f, 1.f};
-    bool ok[2];
-    const int hw = p.Ho * p.Wo;
+    RowSrc rs[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const long long m = m0 + lr + 64 * j;
-        ok[j] = m < p.M;
-        const long long mm = ok[j] ? m : 0;
-        const int b = (int)(mm / hw);
-        const int rem = (int)(mm - (long long)b * hw);
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        iy0[j] = oy * p.sh - p.pt_;
-        ix0[j] = ox * p.sw - p.pl_;
-        if (MODE == 2) {
-            base[j] = (long long)p.win_row[b] * 24 + (long long)iy0[j] * 24 + ix0[j];
-            mean[j] = p.stats[2 * b];
-            sd[j] = p.stats[2 * b + 1];
-            ok[j] = ok[j] && p.finite[b];
-        } else {
-            base[j] = (long long)b * p.img_stride + (long long)iy0[j] * p.row_stride + (long long)ix0[j] * p.pix_stride;
-        }
-    }
+    for (int j = 0; j < 2; ++j) rs[j] = row_source<MODE>(p, m0 + lr + 64 * j);
     const int bn = n0 + lr;                       // weight row this thread stages
     const bool bok = bn < p.Cout;
     const float* wrow = p.w + (size_t)(bok ? bn : 0) * p.Kpad + k4 * 4;
@@ -108,32 +225,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
             const int ky = e.y >> 16, kx = e.y & 0xffff;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int iy = iy0[j] + ky, ix = ix0[j] + kx;
-                if (ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                    ra[j] = *reinterpret_cast<const float4*>(p.in + base[j] + e.x);
-                else
-                    ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int iy = rs[j].iy0 + ky, ix = rs[j].ix0 + kx;
+                ra[j] = ld4_or_zero(p.in, rs[j].base + e.x,
+                                    rs[j].ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int2 e = reinterpret_cast<const int2*>(p.ktab)[kbase + q];
-                    const int ky = e.y >> 16, kx = e.y & 0xffff;
-                    const int iy = iy0[j] + ky, ix = ix0[j] + kx;
-                    float x = 0.f;
-                    if (ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-                        x = p.in[base[j] + e.x];
-                        if (MODE == 2) x = (x - mean[j]) / sd[j];
-                    }
-                    v[q] = x;
-                }
-                ra[j] = make_float4(v[0], v[1], v[2], v[3]);
-            }
+            for (int j = 0; j < 2; ++j)
+                ra[j] = make_float4(gather_scalar<MODE>(p, rs[j], kbase), gather_scalar<MODE>(p, rs[j], kbase + 1),
+                                    gather_scalar<MODE>(p, rs[j], kbase + 2), gather_scalar<MODE>(p, rs[j], kbase + 3));
         }
-        rb = bok ? *reinterpret_cast<const float4*>(wrow + (size_t)kt * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb = *reinterpret_cast<const float4*>(wrow + (size_t)kt * BK);        // rows >= Cout read row 0: never stored
     };
     auto stage = [&](int buf) {
         *reinterpret_cast<float4*>(&sA[buf][lr * LDK + k4 * 4]) = ra[0];
@@ -173,28 +275,270 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         if (kt + 1 < nk) stage(cur ^ 1);
         __syncthreads();
     }
+    epilogue_tile(p, acc0, m0 + wv * 32, n0 + li, lh);
+    epilogue_tile(p, acc1, m0 + wv * 32, n0 + 32 + li, lh);
+}
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// ------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on bf16 MFMA with split operands ("bf16x3").
+//   x = hi + lo,  hi = bf16(x),  lo = bf16(x - hi)   (|x - hi - lo| <= 2^-17 |x|)
+//   a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi        (dropped a_lo*b_lo <= 2^-16 |a b|)
+// Weights are split once on the host side of iss_cnn_load; activations stay f32 in HBM and
+// are split while they are staged into LDS (v_cvt_pk_bf16_f32).  Same 128 x 64 tile / wave
+// layout / epilogue as the f32 kernel, k-tile 32 = two v_mfma_f32_32x32x16_bf16 steps, i.e.
+// 12 MFMAs per wave per k-tile.  LDS: 2 stages x (A hi+lo 20 KB + B hi+lo 10 KB) = 60 KB
+// -> two workgroups per CU, one staging while the other is on the matrix pipe.
+// MODE: 0 = NHWC with Cin % 32 == 0 (a k-tile is 32 consecutive channels of ONE tap: float4
+//           gathers, no table), 1 = NHWC scalar gathers, 2 = z-normed patch.
+__device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& l) {
+    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+    l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) uint16_t sAh[2][BM * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sAl[2][BM * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBh[2][BN * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBl[2][BN * XLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long m0 = (long long)tile_of_block(blockIdx.x, p.nblk) * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // A staging: thread fills k columns [4*k8, 4*k8+4) of rows lr, lr+32, lr+64, lr+96
+    const int k8 = tid & 7;
+    const int lr = tid >> 3;
+    RowSrc rs[4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int n = n0 + t * 32 + li;
-        if (n >= p.Cout) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        const float s = p.ps ? p.ps[n] : 1.f;
-        const float sh = p.pt ? p.pt[n] : 0.f;
+    for (int j = 0; j < 4; ++j) rs[j] = row_source<MODE>(p, m0 + lr + 32 * j);
+    // B staging: thread fills 8 bf16 (16 B) of weight row br, for hi and lo
+    const int br = tid >> 2, bseg = tid & 3;
+    const bool bok = n0 + br < p.Cout;
+    const size_t boff = (size_t)(bok ? n0 + br : 0) * p.Kpad + bseg * 8;
+
+    float4 ra[4];
+    uint4 rbh, rbl;
+    int tap_ky = 0, tap_kx = 0, tap_c = 0;          // MODE 0: tap walked by the NEXT gather
+    auto gather = [&](int kt) {
+        if (MODE == 0) {
+            const int off = (tap_ky * p.W + tap_kx) * p.Cin + tap_c + k8 * 4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const long long m = m0 + wv * 32 + row;
-            if (m >= p.M) continue;
-            float v = (t == 0 ? acc0[r] : acc1[r]) + bias;
-            const size_t o = (size_t)m * p.Cout + n;
-            if (p.res) v += p.res[o];
-            v = apply_act(v, p.act);
-            if (p.ps) v = v * s + sh;
-            p.out[o] = v;
+            for (int j = 0; j < 4; ++j) {
+                const int iy = rs[j].iy0 + tap_ky, ix = rs[j].ix0 + tap_kx;
+                ra[j] = ld4_or_zero(p.in, rs[j].base + off,
+                                    rs[j].ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W);
+            }
+            tap_c += XBK;
+            if (tap_c >= p.Cin) { tap_c = 0; if (++tap_kx == p.kw) { tap_kx = 0; ++tap_ky; } }
+        } else {
+            const int kbase = kt * XBK + k8 * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                ra[j] = make_float4(gather_scalar<MODE>(p, rs[j], kbase), gather_scalar<MODE>(p, rs[j], kbase + 1),
+                                    gather_scalar<MODE>(p, rs[j], kbase + 2), gather_scalar<MODE>(p, rs[j], kbase + 3));
+        }
+        rbh = *reinterpret_cast<const uint4*>(p.wh + boff + (size_t)kt * XBK);   // rows >= Cout read row 0: never stored
+        rbl = *reinterpret_cast<const uint4*>(p.wl + boff + (size_t)kt * XBK);
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 h, l;
+            split4(ra[j], h, l);
+            *reinterpret_cast<bf16x4*>(&sAh[buf][(lr + 32 * j) * XLD + k8 * 4]) = h;
+            *reinterpret_cast<bf16x4*>(&sAl[buf][(lr + 32 * j) * XLD + k8 * 4]) = l;
+        }
+        *reinterpret_cast<uint4*>(&sBh[buf][br * XLD + bseg * 8]) = rbh;
+        *reinterpret_cast<uint4*>(&sBl[buf][br * XLD + bseg * 8]) = rbl;
+    };
+
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    const int nk = p.Kpad / XBK;
+    gather(0);
+    stage(0);
+    __syncthreads();
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int aoff = (wv * 32 + li) * XLD + lh * 8;
+    const int boff_s = li * XLD + lh * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gather(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sAh[cur][aoff + ks * 16]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sAl[cur][aoff + ks * 16]);
+            const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + ks * 16]);
+            const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + ks * 16]);
+            const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + 32 * XLD + ks * 16]);
+            const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + 32 * XLD + ks * 16]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
+        }
+        if (kt + 1 < nk) stage(cur ^ 1);
+        __syncthreads();
+    }
+    epilogue_tile(p, acc0, m0 + wv * 32, n0 + li, lh);
+    epilogue_tile(p, acc1, m0 + wv * 32, n0 + 32 + li, lh);
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16x3 implicit GEMM with an LDS-resident input footprint (kh*kw > 1, Cin % 32 == 0).
+//
+// conv_x3_kernel re-gathers every A element once per tap: 16 KB of f32 activations per 384 MFMA
+// cycles and workgroup, which saturates the per-CU L1/L2 path (~56 B/clk) long before the matrix
+// pipe.  Here the k loop is re-ordered to (channel chunk of 32) x (ky, kx): the input pixels a
+// 128-row M tile touches form ONE contiguous range [p_lo, p_hi] of the flattened (sample, iy, ix)
+// pixel index (NHWC), so per chunk that range is loaded from global memory ONCE, split into
+// bf16 hi/lo and kept in LDS; every tap then reads its MFMA A fragments straight from that
+// footprint at a per-lane pixel offset (+ ky*W + kx).  Global A traffic drops by ~kh*kw; only
+// the 8 KB weight tile per tap still streams (double-buffered) from L2.
+constexpr int FPIX = 256;    // footprint capacity in pixels (validated on the host per launch)
+
+template <bool PADDED>
+__global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) uint16_t sFh[FPIX * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sFl[FPIX * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBh[2][BN * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBl[2][BN * XLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long m0 = (long long)tile_of_block(blockIdx.x, p.nblk) * BM;
+    const int n0 = blockIdx.y * BN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- tile geometry (uniform): pixel range touched by rows [m0, m_last]
+    long long p_lo;
+    int npix;
+    {
+        int b, oy, ox;
+        map_row(p, m0, b, oy, ox);
+        p_lo = ((long long)b * p.H + (oy * p.sh - p.pt_)) * p.W + (ox * p.sw - p.pl_);
+        const long long m_last = (m0 + BM <= p.M ? m0 + BM : p.M) - 1;
+        map_row(p, m_last, b, oy, ox);
+        const long long p_hi = ((long long)b * p.H + (oy * p.sh - p.pt_ + p.H_k - 1)) * p.W + (ox * p.sw - p.pl_ + p.kw - 1);
+        npix = (int)(p_hi - p_lo + 1);
+        if (npix > FPIX) npix = FPIX;              // cannot happen (host-validated); keeps LDS writes in range
+    }
+    // ---- this lane's A row (GEMM row m0 + 32 wv + li)
+    int lanepix, iy0, ix0;
+    {
+        const long long m = m0 + wv * 32 + li;
+        int b, oy, ox;
+        map_row(p, m < p.M ? m : m0, b, oy, ox);
+        iy0 = oy * p.sh - p.pt_;
+        ix0 = ox * p.sw - p.pl_;
+        lanepix = (int)(((long long)b * p.H + iy0) * p.W + ix0 - p_lo);
+    }
+    const long long totpix = p.img_stride / p.Cin * (p.M / ((long long)p.Hq * p.Wq * p.pp));   // samples * H * W
+
+    // ---- B staging bookkeeping
+    const int br = tid >> 2, bseg = tid & 3;
+    const bool bok = n0 + br < p.Cout;
+    const size_t boff = (size_t)(bok ? n0 + br : 0) * p.Kpad + bseg * 8;
+    const int ntap = p.H_k * p.kw;
+    uint4 rbh, rbl;
+    auto fetch_b = [&](int tap, int c0) {
+        // rows >= Cout read row 0 instead: their output columns are never stored, so no masking
+        rbh = *reinterpret_cast<const uint4*>(p.wh + boff + (size_t)tap * p.Cin + c0);
+        rbl = *reinterpret_cast<const uint4*>(p.wl + boff + (size_t)tap * p.Cin + c0);
+    };
+    auto stage_b = [&](int buf) {
+        *reinterpret_cast<uint4*>(&sBh[buf][br * XLD + bseg * 8]) = rbh;
+        *reinterpret_cast<uint4*>(&sBl[buf][br * XLD + bseg * 8]) = rbl;
+    };
+
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    const int k8 = tid & 7, prow = tid >> 3;
+    const int boff_s = li * XLD + lh * 8;
+    // footprint prefetch registers: pixel prow + 32 q, channels [c0 + 4 k8, +4)
+    float4 fv[FPIX / 32];
+    // Pixels outside [0, totpix) are clamped to a valid address: only rows >= M or zero-padded
+    // taps ever read them (the latter are zeroed after the LDS read), so the loads need no mask --
+    // a masked load would come with a zero-init of its destination registers and an
+    // `s_waitcnt vmcnt(0)` in front of it.
+    auto fetch_fp_part = [&](int q, int c0) {
+        long long gp = p_lo + prow + 32 * q;
+        gp = gp < 0 ? 0 : (gp > totpix - 1 ? totpix - 1 : gp);
+        fv[q] = *reinterpret_cast<const float4*>(p.in + gp * p.Cin + c0 + k8 * 4);
+    };
+    auto stage_fp = [&]() {
+#pragma unroll
+        for (int q = 0; q < FPIX / 32; ++q) {
+            bf16x4 h, l;
+            split4(fv[q], h, l);
+            *reinterpret_cast<bf16x4*>(&sFh[(prow + 32 * q) * XLD + k8 * 4]) = h;
+            *reinterpret_cast<bf16x4*>(&sFl[(prow + 32 * q) * XLD + k8 * 4]) = l;
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < FPIX / 32; ++q) fetch_fp_part(q, 0);
+    fetch_b(0, 0);
+    stage_b(0);
+    int it = 0;                                     // running tap counter: B buffer parity
+    // vmcnt is an in-order counter: the wait in front of every tap's B ds_write also drains any
+    // older load.  So the next chunk's footprint is fetched in slices, `fpt` float4 per thread at
+    // the top of each of the first taps, where the tap's own 12 MFMAs cover the latency.
+    const int fpt = (FPIX / 32 + ntap - 1) / ntap;
+    for (int c0 = 0; c0 < p.Cin; c0 += XBK) {
+        // every wave passed the barrier behind the previous chunk's last tap: the footprint is free
+        stage_fp();
+        __syncthreads();
+        const bool next_chunk = c0 + XBK < p.Cin;
+        int ky = 0, kx = 0;
+        for (int tap = 0; tap < ntap; ++tap, ++it) {
+            const int cur = it & 1;
+            const bool last_tap = tap + 1 == ntap;
+            const bool more = !last_tap || next_chunk;
+            if (more) fetch_b(last_tap ? 0 : tap + 1, last_tap ? c0 + XBK : c0);
+            if (next_chunk) {                        // after the B loads: see the vmcnt note above
+#pragma unroll
+                for (int q = 0; q < FPIX / 32; ++q)
+                    if (q / fpt == tap) fetch_fp_part(q, c0 + XBK);
+            }
+            int pix = lanepix + ky * p.W + kx;
+            pix = pix < 0 ? 0 : (pix > FPIX - 1 ? FPIX - 1 : pix);
+            bool ok = true;
+            if (PADDED) ok = (unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W;
+            const int aoff = pix * XLD + lh * 8;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sFh[aoff + ks * 16]);
+                bf16x8 al = *reinterpret_cast<const bf16x8*>(&sFl[aoff + ks * 16]);
+                if (PADDED && !ok) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { ah[q] = (__bf16)0.f; al[q] = (__bf16)0.f; }
+                }
+                const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + ks * 16]);
+                const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + ks * 16]);
+                const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + 32 * XLD + ks * 16]);
+                const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + 32 * XLD + ks * 16]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
+            }
+            if (more) stage_b(cur ^ 1);
+            if (++kx == p.kw) { kx = 0; ++ky; }
+            __syncthreads();
         }
     }
+    epilogue_tile(p, acc0, m0 + wv * 32, n0 + li, lh);
+    epilogue_tile(p, acc1, m0 + wv * 32, n0 + 32 + li, lh);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -302,6 +646,25 @@ __global__ void mask_probs_kernel(float* probs, const uint8_t* finite, long long
 
 inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
 
+// float -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does); weights are finite
+inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+// fused-pool window of a conv row (1,1 when absent)
+inline void fused_pool_of(const int32_t* R, int& ph, int& pw) {
+    ph = R[ISS_C_FPOOLH] > 1 ? R[ISS_C_FPOOLH] : 1;
+    pw = R[ISS_C_FPOOLW] > 1 ? R[ISS_C_FPOOLW] : 1;
+}
+
 }  // namespace
 
 // ============================================================================ host side
@@ -309,6 +672,8 @@ int iss_cnn_free(iss_ctx* c, int id) {
     if (!c || id < 0 || id >= ISS_MAX_NETS) return ISS_EINVAL;
     IssNet& n = c->nets[id];
     if (n.d_blob) (void)hipFree(n.d_blob);
+    if (n.d_wh) (void)hipFree(n.d_wh);
+    if (n.d_wl) (void)hipFree(n.d_wl);
     if (n.d_ktab) (void)hipFree(n.d_ktab);
     n = IssNet();
     return ISS_OK;
@@ -336,12 +701,17 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
         if (R[ISS_C_OUT] < 0 || R[ISS_C_OUT] >= nbuf) return bad("OUT buffer id");
         if (R[ISS_C_OP] == ISS_OP_CONV) {
             const int K = R[ISS_C_KH] * R[ISS_C_KW] * R[ISS_C_CIN];
-            const int Kpad = roundup(K, BK);
+            const int Kpad = roundup(K, KALIGN);
             if (K <= 0 || R[ISS_C_COUT] <= 0) return bad("conv shape");
-            if (R[ISS_C_WOFF] < 0 || (int64_t)R[ISS_C_WOFF] + (int64_t)R[ISS_C_COUT] * Kpad > blob_floats)
-                return bad("weight offset outside blob (weights must be [Cout][roundup16(K)])");
+            if (R[ISS_C_WOFF] < 0 || (R[ISS_C_WOFF] & 7) || (int64_t)R[ISS_C_WOFF] + (int64_t)R[ISS_C_COUT] * Kpad > blob_floats)
+                return bad("weight offset misaligned or outside blob (weights must be [Cout][roundup32(K)], offset % 8 == 0)");
             if (R[ISS_C_RES] >= nbuf) return bad("RES buffer id");
             if (R[ISS_C_KH] > 32767 || R[ISS_C_KW] > 32767) return bad("kernel too large");
+            int fph, fpw;
+            fused_pool_of(R, fph, fpw);
+            if (fph * fpw != 1 && fph * fpw != 2 && fph * fpw != 4) return bad("fused pool window must cover 2 or 4 outputs");
+            if (fph * fpw > 1 && (R[ISS_C_RES] >= 0 || R[ISS_C_HO] / fph < 1 || R[ISS_C_WO] / fpw < 1))
+                return bad("fused pool with residual / empty pooled output");
             const bool patch = R[ISS_C_INMODE] == 1;
             if (patch && (R[ISS_C_CIN] != 1 || R[ISS_C_H] != 68 || R[ISS_C_W] > 24)) return bad("patch-mode conv must read (68, <=24, 1)");
             const int rs = patch ? 24 : R[ISS_C_W] * R[ISS_C_CIN], ps = patch ? 1 : R[ISS_C_CIN];
@@ -357,7 +727,7 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
                     ktab.push_back((0x7fff << 16) | 0x7fff);
                 }
             }
-            flops += 2.0 * K * R[ISS_C_COUT] * R[ISS_C_HO] * R[ISS_C_WO];
+            flops += 2.0 * K * R[ISS_C_COUT] * (double)(R[ISS_C_HO] / fph * fph) * (double)(R[ISS_C_WO] / fpw * fpw);
         } else if (R[ISS_C_OP] != ISS_OP_POOL && R[ISS_C_OP] != ISS_OP_SOFTMAX && R[ISS_C_OP] != ISS_OP_STATPOOL) {
             return bad("unknown op");
         }
@@ -365,11 +735,29 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
     n.flops_per_sample = flops; n.blob_floats = blob_floats;
     ISS_HIP(c, hipMalloc((void**)&n.d_blob, (size_t)blob_floats * sizeof(float)));
     ISS_HIP(c, hipMemcpy(n.d_blob, blob, (size_t)blob_floats * sizeof(float), hipMemcpyHostToDevice));
+    {   // bf16 hi / lo parts of every parameter, same offsets as the f32 blob (conv_x3_kernel operands)
+        std::vector<uint16_t> hi((size_t)blob_floats), lo((size_t)blob_floats);
+        for (int64_t i = 0; i < blob_floats; ++i) {
+            hi[i] = bf16_rne(blob[i]);
+            lo[i] = bf16_rne(blob[i] - bf16_to_f32(hi[i]));
+        }
+        ISS_HIP(c, hipMalloc((void**)&n.d_wh, (size_t)blob_floats * 2 + 16));
+        ISS_HIP(c, hipMalloc((void**)&n.d_wl, (size_t)blob_floats * 2 + 16));
+        ISS_HIP(c, hipMemcpy(n.d_wh, hi.data(), (size_t)blob_floats * 2, hipMemcpyHostToDevice));
+        ISS_HIP(c, hipMemcpy(n.d_wl, lo.data(), (size_t)blob_floats * 2, hipMemcpyHostToDevice));
+    }
     if (!ktab.empty()) {
         ISS_HIP(c, hipMalloc((void**)&n.d_ktab, ktab.size() * sizeof(int32_t)));
         ISS_HIP(c, hipMemcpy(n.d_ktab, ktab.data(), ktab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     n.loaded = true;
+    return ISS_OK;
+}
+
+extern "C" int iss_set_precision(iss_ctx* c, int mode) {
+    if (!c) return ISS_EINVAL;
+    if (mode != ISS_PREC_BF16X3 && mode != ISS_PREC_F32) return iss_fail(c, ISS_EINVAL, "iss_set_precision: unknown mode %d", mode);
+    c->precision = mode;
     return ISS_OK;
 }
 
@@ -381,6 +769,35 @@ extern "C" int iss_cnn_flops(iss_ctx* c, int id, double* f) {
 }
 
 namespace {
+
+// Host replica of the device's row mapping / footprint arithmetic: does every 128-row tile of this
+// launch touch at most FPIX pixels?  The pattern is periodic in the sample index (period <= BM
+// samples), so tiles covering the first BM + 2 samples decide.
+bool footprint_fits(const ConvArgs& a) {
+    const long long rows_per_sample = (long long)a.Hq * a.Wq * a.pp;
+    const long long samples = a.M / rows_per_sample;
+    const long long lim_rows = std::min<long long>(a.M, rows_per_sample * std::min<long long>(samples, BM + 2));
+    auto pix_of = [&](long long m, int ky, int kx) {
+        long long q = m;
+        int dy = 0, dx = 0;
+        if (a.pp > 1) { q = m / a.pp; const int j = (int)(m - q * a.pp); dy = j / a.pw; dx = j - dy * a.pw; }
+        const int hw = a.Hq * a.Wq;
+        const long long b = q / hw;
+        const int rem = (int)(q - b * hw);
+        const int qy = rem / a.Wq, qx = rem - qy * a.Wq;
+        const int oy = qy * a.ph + dy, ox = qx * a.pw + dx;
+        return (b * a.H + (oy * a.sh - a.pt_ + ky)) * a.W + (ox * a.sw - a.pl_ + kx);
+    };
+    for (long long m0 = 0; m0 < lim_rows; m0 += BM) {
+        const long long m_last = std::min<long long>(m0 + BM, a.M) - 1;
+        const long long lo = pix_of(m0, 0, 0), hi = pix_of(m_last, a.H_k - 1, a.kw - 1);
+        if (hi - lo + 1 > FPIX) return false;
+        // rows inside the tile never reach below lo / above hi (row-major or pool-window-major order); check anyway
+        for (long long m = m0; m <= m_last; ++m)
+            if (pix_of(m, 0, 0) < lo || pix_of(m, a.H_k - 1, a.kw - 1) > hi) return false;
+    }
+    return true;
+}
 
 // Run the op program on `bc` samples.  src: PATCH mode uses (d_winrow + s0, stats, finite),
 // otherwise `d_input` is an NHWC batch.  The result is left in act[last OUT].
@@ -402,13 +819,20 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             a.res = R[ISS_C_RES] >= 0 ? (const float*)c->act[R[ISS_C_RES]].p : nullptr;
             a.out = out;
             a.ktab = n.d_ktab + n.ktab_off[r];
-            a.H = R[ISS_C_H]; a.W = R[ISS_C_W]; a.Cin = R[ISS_C_CIN];
-            a.Ho = R[ISS_C_HO]; a.Wo = R[ISS_C_WO]; a.Cout = R[ISS_C_COUT];
+            a.wh = n.d_wh + R[ISS_C_WOFF];
+            a.wl = n.d_wl + R[ISS_C_WOFF];
+            a.H = R[ISS_C_H]; a.W = R[ISS_C_W]; a.Cin = R[ISS_C_CIN]; a.Cout = R[ISS_C_COUT];
+            fused_pool_of(R, a.ph, a.pw);
+            a.pp = a.ph * a.pw;
+            a.poolkind = R[ISS_C_POOLKIND];
+            a.Hq = R[ISS_C_HO] / a.ph; a.Wq = R[ISS_C_WO] / a.pw;
+            a.H_k = R[ISS_C_KH]; a.kw = R[ISS_C_KW];
             a.sh = R[ISS_C_SH]; a.sw = R[ISS_C_SW]; a.pt_ = R[ISS_C_PT]; a.pl_ = R[ISS_C_PL];
             a.act = R[ISS_C_ACT]; a.Kpad = n.kpad[r];
-            a.M = (long long)bc * a.Ho * a.Wo;
+            a.M = (long long)bc * a.Hq * a.Wq * a.pp;
             const bool patch = R[ISS_C_INMODE] == 1;
-            a.mode = patch ? 2 : ((a.Cin % 4 == 0) ? 0 : 1);
+            const bool x3 = c->precision == ISS_PREC_BF16X3;
+            a.mode = patch ? 2 : ((a.Cin % (x3 ? XBK : 4) == 0) ? 0 : 1);
             if (patch) {
                 if (!d_winrow) return iss_fail(c, ISS_ESTATE, "patch-mode network run without a window list");
                 a.in = (const float*)c->mspec.p; a.win_row = d_winrow; a.stats = d_stats; a.finite = d_fin;
@@ -417,12 +841,31 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 if (!in) return iss_fail(c, ISS_ESTATE, "network input missing");
                 a.row_stride = a.W * a.Cin; a.pix_stride = a.Cin; a.img_stride = (long long)a.H * a.W * a.Cin;
             }
-            dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
+            a.nblk = (unsigned)((a.M + BM - 1) / BM);
+            dim3 grid(a.nblk, (unsigned)((a.Cout + BN - 1) / BN));
             const double fl = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * a.Cin * (double)a.Cout * (double)a.M;
             iss_prof_begin(c, 0, fl);
-            if (a.mode == 0) hipLaunchKernelGGL(conv_igemm_kernel<0>, grid, dim3(256), 0, c->stream, a);
-            else if (a.mode == 1) hipLaunchKernelGGL(conv_igemm_kernel<1>, grid, dim3(256), 0, c->stream, a);
-            else hipLaunchKernelGGL(conv_igemm_kernel<2>, grid, dim3(256), 0, c->stream, a);
+            bool fp = false;
+            if (x3 && a.mode == 0 && a.H_k * a.kw > 1) {
+                const long long key = ((long long)r << 32) | (unsigned)bc;
+                auto it = n.fp_ok.find(key);
+                if (it == n.fp_ok.end()) it = n.fp_ok.emplace(key, footprint_fits(a)).first;
+                fp = it->second;
+            }
+            if (fp) {
+                const bool padded = a.pt_ != 0 || a.pl_ != 0 ||
+                                    (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
+                if (padded) hipLaunchKernelGGL(conv_x3_fp_kernel<true>, grid, dim3(256), 0, c->stream, a);
+                else hipLaunchKernelGGL(conv_x3_fp_kernel<false>, grid, dim3(256), 0, c->stream, a);
+            } else if (x3) {
+                if (a.mode == 0) hipLaunchKernelGGL(conv_x3_kernel<0>, grid, dim3(256), 0, c->stream, a);
+                else if (a.mode == 1) hipLaunchKernelGGL(conv_x3_kernel<1>, grid, dim3(256), 0, c->stream, a);
+                else hipLaunchKernelGGL(conv_x3_kernel<2>, grid, dim3(256), 0, c->stream, a);
+            } else {
+                if (a.mode == 0) hipLaunchKernelGGL(conv_igemm_kernel<0>, grid, dim3(256), 0, c->stream, a);
+                else if (a.mode == 1) hipLaunchKernelGGL(conv_igemm_kernel<1>, grid, dim3(256), 0, c->stream, a);
+                else hipLaunchKernelGGL(conv_igemm_kernel<2>, grid, dim3(256), 0, c->stream, a);
+            }
             iss_prof_end(c);
         } else if (op == ISS_OP_POOL) {
             const long long total = (long long)bc * R[ISS_C_HO] * R[ISS_C_WO] * R[ISS_C_CIN];

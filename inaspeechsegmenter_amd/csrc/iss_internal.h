@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <string>
 #include <vector>
+#include <unordered_map>
 #include "../../include/iss.h"
 
 struct DevBuf {
@@ -19,7 +20,9 @@ struct IssNet {
     bool loaded = false;
     std::vector<int32_t> prog;            // nrows * ISS_PROG_COLS
     int nrows = 0;
-    float* d_blob = nullptr;              // parameters (conv weights re-laid [Cout][Kpad])
+    float* d_blob = nullptr;              // parameters (conv weights [Cout][Kpad])
+    uint16_t* d_wh = nullptr;             // bf16 hi part of every blob element (same offsets)
+    uint16_t* d_wl = nullptr;             // bf16 lo part
     int64_t blob_floats = 0;
     std::vector<int64_t> w_dev_off;       // per row: offset of the padded weight matrix in d_blob
     std::vector<int32_t> kpad;            // per row: K padded to the GEMM k-tile
@@ -29,6 +32,7 @@ struct IssNet {
     std::vector<int64_t> buf_elems;
     int in_h = 0, in_w = 0, in_c = 0, out_dim = 0;
     double flops_per_sample = 0;
+    std::unordered_map<long long, bool> fp_ok;   // (row << 32 | samples) -> LDS-footprint kernel usable
 };
 
 struct iss_ctx {
@@ -57,6 +61,7 @@ struct iss_ctx {
     // CNN engine
     IssNet nets[ISS_MAX_NETS];
     uint64_t ws_limit = 6ull << 30;
+    int precision = ISS_PREC_BF16X3;
     std::vector<DevBuf> act;              // activation buffers (grown on demand)
     DevBuf d_winrow, d_stats, d_finite, d_out, d_in;
 

@@ -14,7 +14,7 @@ channels-last activations, HWIO conv kernels, (in,out) dense kernels, TF 'same' 
 
 File formats accepted by `load_model_file`:
   *.hdf5 / *.h5   Keras HDF5 (needs h5py at run time)
-  *.npz           flat export written by scripts/convert_keras_hdf5.py (numpy only):
+  *.npz           flat export written by tools/convert_keras_hdf5.py (numpy only):
                   key 'model_config' (JSON string) + one array per '<layer>/<weight>'.
 """
 import json
@@ -146,7 +146,7 @@ def load_model_file(path):
     except ImportError as e:
         raise ImportError(
             f"{path}: reading Keras HDF5 needs h5py, which is not installed in this interpreter. "
-            "Convert once with scripts/convert_keras_hdf5.py (any python with h5py) and place the "
+            "Convert once with tools/convert_keras_hdf5.py (any python with h5py) and place the "
             ".npz next to the .hdf5.") from e
     with h5py.File(path, 'r') as f:
         mc = f.attrs['model_config']
@@ -181,7 +181,7 @@ class _Builder:
     def add_blob(self, a):
         a = np.ascontiguousarray(a, dtype=np.float32).ravel()
         off = self.nblob
-        pad = (-a.size) % 4
+        pad = (-a.size) % 8                     # 8 floats: keeps the bf16 hi/lo copies 16-byte aligned
         self.blob.append(a)
         if pad:
             self.blob.append(np.zeros(pad, np.float32))
@@ -192,12 +192,13 @@ class _Builder:
         self.buf_elems[b] = max(self.buf_elems.get(b, 0), int(elems))
 
     def conv(self, src, dst, shape_in, Wm, kh, kw, sh, sw, pt, pl, ho, wo, bias=None, act=0, ps=None, pt_=None,
-             res=-1, inmode=0):
-        """Wm: (Cout, kh*kw*Cin) in (ky,kx,cin) order."""
+             res=-1, inmode=0, fpool=None):
+        """Wm: (Cout, kh*kw*Cin) in (ky,kx,cin) order.  fpool = (ph, pw, kind) fuses a non-overlapping
+        pool over ph*pw in {2,4} conv outputs into the epilogue; the OUT buffer then holds the pooled map."""
         h, w, cin = shape_in
         cout, K = Wm.shape
         assert K == kh * kw * cin
-        kpad = -(-K // 16) * 16
+        kpad = -(-K // N.K_ALIGN) * N.K_ALIGN
         Wp = np.zeros((cout, kpad), np.float32)
         Wp[:, :K] = Wm
         r = [0] * N.PROG_COLS
@@ -212,9 +213,16 @@ class _Builder:
         r[N.C_PSOFF] = self.add_blob(ps) if ps is not None else -1
         r[N.C_PTOFF] = self.add_blob(pt_) if pt_ is not None else -1
         r[N.C_INMODE] = inmode
+        if fpool is not None:
+            ph, pw, kind = fpool
+            assert ph * pw in (2, 4) and res < 0 and ho // ph >= 1 and wo // pw >= 1
+            r[N.C_FPOOLH], r[N.C_FPOOLW], r[N.C_POOLKIND] = ph, pw, kind
+            self.flops += 2 * K * cout * (ho // ph * ph) * (wo // pw * pw)     # only the pooled region is computed
+            ho, wo = ho // ph, wo // pw
+        else:
+            self.flops += 2 * K * cout * ho * wo
         self.rows.append(r)
         self.use_buf(dst, ho * wo * cout)
-        self.flops += 2 * K * cout * ho * wo
         return (ho, wo, cout)
 
     def pool(self, src, dst, shape_in, kh, kw, sh, sw, pt, pl, ho, wo, kind):
@@ -272,10 +280,11 @@ def _bn_affine(L):
     return sc, sh
 
 
-def compile_layers(layers, in_shape, patch_input=True):
+def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True):
     """Lower a sequential layer list onto the op program.  Fusions: conv/dense + bias,
     + BatchNorm directly after (folded into W, b), + relu/sigmoid/tanh, + BatchNorm after the
-    activation (epilogue scale/shift).  Anything left over becomes an identity 1x1 conv."""
+    activation (epilogue scale/shift), + a non-overlapping 'valid' max/avg pool over 2 or 4 outputs.
+    Anything left over becomes an identity 1x1 conv."""
     B = _Builder()
     shape = tuple(int(v) for v in in_shape)
     cur = N.BUF_INPUT
@@ -359,6 +368,16 @@ def compile_layers(layers, in_shape, patch_input=True):
                 sc, sft = _bn_affine(layers[j])
                 ps, pt_ = sc.astype(np.float32), sft.astype(np.float32)
                 j = peek(j + 1)
+            # non-overlapping 'valid' pool of 2 or 4 outputs right after -> epilogue
+            fpool = None
+            if fuse_pool and not softmax_after and j < n and layers[j]['type'] in ('maxpool', 'avgpool'):
+                PL = layers[j]
+                pph, ppw = PL['pool']
+                pst = tuple(PL.get('strides') or PL['pool'])
+                if PL.get('padding', 'valid') == 'valid' and pst == (pph, ppw) and pph * ppw in (2, 4) \
+                        and ho // pph >= 1 and wo // ppw >= 1:
+                    fpool = (pph, ppw, 0 if PL['type'] == 'maxpool' else 1)
+                    j = peek(j + 1)
             if j == i:                               # nothing consumed (cannot happen) -> avoid a loop
                 raise RuntimeError("lowering made no progress")
             dst = nxt_buf()
@@ -367,7 +386,7 @@ def compile_layers(layers, in_shape, patch_input=True):
                 raise ValueError(f"patch input must be (68, <=24, 1); got {shape}")
             shape = B.conv(cur, dst, (h, w, cin), Wm.astype(np.float32), kh, kw, sh, sw, pt, pl, ho, wo,
                            bias=None if bias is None else np.asarray(bias, np.float32),
-                           act=_ACT_CODE[act_name], ps=ps, pt_=pt_, inmode=inmode)
+                           act=_ACT_CODE[act_name], ps=ps, pt_=pt_, inmode=inmode, fpool=fpool)
             cur, first = dst, False
             if softmax_after:
                 dst = nxt_buf()

@@ -113,7 +113,7 @@ def locate_model(model_fname):
     raise FileNotFoundError(
         f"model file {model_fname} not found in {_MODEL_DIRS}. Download it from "
         f"https://github.com/ina-foss/inaSpeechSegmenter/releases/download/models/{model_fname} "
-        "(or its scripts/convert_keras_hdf5.py .npz export) into one of these directories, or "
+        "(or its tools/convert_keras_hdf5.py .npz export) into one of these directories, or "
         "construct Segmenter(..., models='synthetic') for seeded stand-in weights.")
 
 

@@ -67,9 +67,9 @@ def allgather_segment_tables(rows, capacity=4096, device=None, group=None):
         k = min(len(rows), cap)
         buf[1:1 + k] = rows[:k]
         send = torch.from_numpy(buf).to(device)
-        recv = torch.empty((world, cap + 1, 4), dtype=torch.int32, device=device)
+        recv = torch.empty((world * (cap + 1), 4), dtype=torch.int32, device=device)
         dist.all_gather_into_tensor(recv, send, group=group)
-        return recv.cpu().numpy()
+        return recv.cpu().numpy().reshape(world, cap + 1, 4)
 
     got = gather(int(capacity))
     need = int(got[:, 0, 0].max())

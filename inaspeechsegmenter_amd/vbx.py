@@ -1,0 +1,104 @@
+"""Host mirror of the x-vector half of vbx_segmenter.py on the gfx950 kernels (config 5).
+
+Mirrors, for the hot path only:
+  get_features(signal)                 vbx_segmenter.py:72-89   -> iss_vbx_features (csrc/vbx.hip)
+  VBxExtractor.__call__(basename, fea, duration)   :217-246     -> window bookkeeping here,
+  OnnxBackendExtractor.get_embedding(fea)          :262-266        ResNet-101 of resnet.py:78-135 as an
+                                                                   op program run by iss_cnn_forward, many
+                                                                   windows per launch sequence instead of
+                                                                   one onnxruntime call per window.
+The VAD filtering / MLP scoring tail of VoiceFemininityScoring (:129-202) is SURVEY 8(f) "next".
+"""
+import logging
+import os
+
+import numpy as np
+
+from . import _native
+from . import tables
+from . import keras_model
+
+STEP = 24        # vbx_segmenter.py:21
+WINLEN = 144     # vbx_segmenter.py:22
+FEAT_DIM = 64    # vbx_segmenter.py:23
+EMBED_DIM = 256  # vbx_segmenter.py:24
+SR = 16000       # vbx_segmenter.py:25
+
+logger = logging.getLogger(__name__)
+
+
+def dither_stream(n, seed=3):
+    """`np.random.seed(3)` + `np.random.rand(n)` (vbx_segmenter.py:84, features_vbx.py:127-128):
+    an MT19937 stream, generated on the host and uploaded."""
+    return np.random.RandomState(seed).rand(n)
+
+
+class FeatureExtractor:
+    """get_features (vbx_segmenter.py:72-89) bound to one device context."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        ctx.vbx_tables(tables.vbx_window(), tables.vbx_melbank())
+
+    def __call__(self, signal):
+        signal = np.asarray(signal, dtype=np.float64)
+        sig_i = (signal * 2 ** 15).astype(int)                       # :85 truncation toward zero
+        return self.ctx.vbx_features(sig_i.astype(np.int32), dither_stream(len(signal)))
+
+
+class VBxExtractor:
+    """x-vector extraction with the reference's window bookkeeping (vbx_segmenter.py:217-246).
+
+    params: state_dict-like mapping of resnet.py's ResNet101 (conv OIHW, BN weight / bias /
+    running_mean / running_var, embedding.weight / bias) as numpy arrays."""
+    _NET_BASE = 4            # net ids 4.. are used for the per-length programs
+
+    def __init__(self, ctx, params, batch_windows=256):
+        self.ctx = ctx
+        self.params = params
+        self.batch_windows = batch_windows
+        self._nets = {}      # frames -> net_id
+
+    def _net_for(self, frames):
+        if frames not in self._nets:
+            if len(self._nets) >= _native.MAX_NETS - self._NET_BASE:
+                raise _native.NativeError("too many distinct window lengths loaded")
+            nid = self._NET_BASE + len(self._nets)
+            self.ctx.cnn_load(nid, keras_model.compile_resnet101(self.params, FEAT_DIM, frames))
+            self._nets[frames] = nid
+        return self._nets[frames]
+
+    def get_embeddings(self, fea, starts, frames):
+        """(len(starts), 256) embeddings of fea[s:s+frames] (feature-major input like :265)."""
+        nid = self._net_for(frames)
+        out = np.empty((len(starts), EMBED_DIM), dtype=np.float32)
+        for i in range(0, len(starts), self.batch_windows):
+            st = starts[i:i + self.batch_windows]
+            x = np.stack([fea[s:s + frames].T for s in st])[..., None]       # (n, 64, frames, 1) NHWC
+            out[i:i + len(st)] = self.ctx.cnn_forward(nid, x.astype(np.float32))
+        return out
+
+    def get_embedding(self, fea):
+        """Single-window form of OnnxBackendExtractor.get_embedding (vbx_segmenter.py:262-266)."""
+        return self.get_embeddings(np.asarray(fea), [0], len(fea))[0]
+
+    def __call__(self, basename, fea, duration):
+        fea = np.asarray(fea)
+        xvectors = []
+        starts = list(range(0, len(fea) - WINLEN, STEP))
+        start = starts[-1] if starts else 0
+        emb = self.get_embeddings(fea, starts, WINLEN) if starts else np.zeros((0, EMBED_DIM), np.float32)
+        for s, xvector in zip(starts, emb):
+            key = f'{basename}_{s:08}-{(s + WINLEN):08}'
+            if np.isnan(xvector).any():
+                logger.warning(f'NaN found, not processing: {key}{os.linesep}')
+            else:
+                xvectors.append((key, (round(s / 100.0, 3), round(s / 100.0 + WINLEN / 100.0, 3)), xvector))
+        if len(fea) - start - STEP >= 10:                               # last, shorter window (:234-243)
+            xvector = self.get_embeddings(fea, [start + STEP], len(fea) - start - STEP)[0]
+            key = f'{basename}_{(start + STEP):08}-{len(fea):08}'
+            if np.isnan(xvector).any():
+                logger.warning(f'NaN found, not processing: {key}{os.linesep}')
+            else:
+                xvectors.append((key, (round((start + STEP) / 100.0, 3), round(duration, 3)), xvector))
+        return [(key, seg, x * 10) for key, seg, x in xvectors]           # :246

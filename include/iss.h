@@ -86,7 +86,7 @@ int iss_set_mspec(iss_ctx* ctx, const float* mspec, int32_t T);
 #define ISS_PROG_COLS  32
 
 enum {
-    ISS_OP_CONV     = 1,  /* conv2d / dense as implicit GEMM (MFMA f32) + fused epilogue */
+    ISS_OP_CONV     = 1,  /* conv2d / dense as implicit GEMM (MFMA) + fused epilogue (+ fused pool) */
     ISS_OP_POOL     = 2,  /* max / average pooling, NHWC                                 */
     ISS_OP_SOFTMAX  = 3,  /* softmax over the channel axis                               */
     ISS_OP_STATPOOL = 4,  /* mean || std over the time axis (resnet.py:123-127)          */
@@ -97,11 +97,15 @@ enum {
     ISS_C_H, ISS_C_W, ISS_C_CIN, ISS_C_HO, ISS_C_WO, ISS_C_COUT,
     ISS_C_KH, ISS_C_KW, ISS_C_SH, ISS_C_SW, ISS_C_PT, ISS_C_PL,
     ISS_C_ACT,                                          /* 0 none 1 relu 2 sigmoid 3 tanh   */
-    ISS_C_WOFF, ISS_C_BOFF,                             /* blob offsets: W [Cout][kh*kw*Cin], bias */
+    ISS_C_WOFF, ISS_C_BOFF,                             /* blob offsets: W [Cout][roundup32(kh*kw*Cin)] (WOFF % 8 == 0), bias */
     ISS_C_PSOFF, ISS_C_PTOFF,                           /* post-activation scale / shift   */
     ISS_C_INMODE,                                       /* 0 NHWC buffer, 1 z-normed mspec patch */
     ISS_C_POOLKIND,                                     /* POOL: 0 max 1 avg               */
     ISS_C_ORDER,                                        /* STATPOOL out order: 0 = (c,h) torch flatten */
+    ISS_C_FPOOLH, ISS_C_FPOOLW,                         /* CONV: fused non-overlapping pool window applied after
+                                                           the epilogue (0/1 = none; FPOOLH*FPOOLW in {2,4};
+                                                           kind in ISS_C_POOLKIND).  HO/WO stay the conv's own
+                                                           output size; OUT holds (HO/FPOOLH, WO/FPOOLW, COUT) */
 };
 #define ISS_BUF_INPUT  (-2)   /* IN: the network input (patch source or iss_cnn_forward input) */
 
@@ -126,7 +130,16 @@ int iss_cnn_probs(iss_ctx* ctx, int net_id, const int32_t* win_row, int32_t n,
  * of resnet.py:78-135, one launch sequence for many windows instead of batch 1).  */
 int iss_cnn_forward(iss_ctx* ctx, int net_id, const float* x, int32_t n, float* out /* n*out_dim */);
 
-/* FLOPs (2*MAC of conv/dense ops) per sample of a loaded network.               */
+/* Arithmetic mode of the conv/dense GEMMs (default ISS_PREC_BF16X3):
+ *   ISS_PREC_BF16X3  both operands split into bf16 hi+lo, three v_mfma_f32_32x32x16_bf16 per k-step,
+ *                    f32 accumulate: operand error 2^-16 relative (float32-class results, measured
+ *                    <= 1e-5 on probabilities), 16/3 x the f32-MFMA rate;
+ *   ISS_PREC_F32     v_mfma_f32_32x32x2_f32, bit-wise an fmaf chain (reference-grade, slower).        */
+#define ISS_PREC_BF16X3 0
+#define ISS_PREC_F32    1
+int iss_set_precision(iss_ctx* ctx, int mode);
+
+/* FLOPs (2*MAC of the conv/dense outputs actually computed) per sample of a loaded network. */
 int iss_cnn_flops(iss_ctx* ctx, int net_id, double* flops_per_sample);
 
 /* ------------------------------------------------ VBx 64-band fbank front end

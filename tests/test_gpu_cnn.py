@@ -1,17 +1,25 @@
-"""GPU parity: CNN engine (patch gather + z-norm + implicit-GEMM conv/dense on f32 MFMA + pooling
-+ softmax) vs the Keras-semantics oracle, on seeded synthetic weights.  Tolerance 1e-3 on
-probabilities is the north-star bound; observed errors are ~1e-6."""
+"""GPU parity: CNN engine (patch gather + z-norm + implicit-GEMM conv/dense on MFMA + fused / stand-alone
+pooling + softmax) vs the Keras-semantics oracle, on seeded synthetic weights, in both arithmetic
+modes: split-bf16 MFMA (default; operand error 2^-16) and exact-f32 MFMA.  Tolerance 1e-3 on
+probabilities is the north-star bound; the tests hold both modes to 1e-4 (observed ~1e-6 .. 1e-5)."""
 import os
 
 import numpy as np
 import pytest
 
-from inaspeechsegmenter_amd import keras_model as KM, segmenter as S
+from inaspeechsegmenter_amd import keras_model as KM, segmenter as S, _native
 from oracle import keras_cnn as ocnn, segment as oseg
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 PROB_TOL = 1e-3
+
+
+@pytest.fixture(params=['bf16x3', 'f32'])
+def prec(request, ctx):
+    ctx.set_precision(_native.PREC_F32 if request.param == 'f32' else _native.PREC_BF16X3)
+    yield request.param
+    ctx.set_precision(_native.PREC_BF16X3)
 
 
 def _rand_conv(rng, kh, kw, cin, cout, strides=(1, 1), padding='valid', act='linear', bias=True):
@@ -59,6 +67,14 @@ TOPOLOGIES = {
                                                  _rand_conv(r, 1, 1, 12, 7, act='sigmoid'),
                                                  dict(type='globalavgpool'), _rand_dense(r, 7, 3, 'linear'),
                                                  dict(type='activation', fn='softmax')],
+    'fused_pools_2x1_1x2_avg2x2_cin32': lambda r, h: [_rand_conv(r, 3, 3, 1, 32, act='relu'),
+                                                      dict(type='maxpool', pool=(2, 1), strides=(2, 1), padding='valid'),
+                                                      _rand_conv(r, 3, 3, 32, 64, act='relu'), _rand_bn(r, 64),
+                                                      dict(type='maxpool', pool=(1, 2), strides=(1, 2), padding='valid'),
+                                                      _rand_conv(r, 2, 2, 64, 32, padding='same', act='tanh'),
+                                                      dict(type='avgpool', pool=(2, 2), strides=(2, 2), padding='valid'),
+                                                      dict(type='flatten'),
+                                                      _rand_dense(r, 15 * (((h - 2) - 2) // 2 // 2) * 32, 3, 'softmax')],
     'cin_not_multiple_of_4': lambda r, h: [_rand_conv(r, 2, 2, 1, 6, act='relu'), _rand_conv(r, 3, 2, 6, 10, act='relu'),
                                            dict(type='maxpool', pool=(3, 3), strides=(3, 3), padding='same'),
                                            dict(type='globalmaxpool'), _rand_dense(r, 10, 2, 'softmax')],
@@ -70,7 +86,7 @@ TOPOLOGIES = {
 
 @pytest.mark.parametrize('name', sorted(TOPOLOGIES))
 @pytest.mark.parametrize('nmel', [21, 24])
-def test_layer_semantics(ctx, name, nmel):
+def test_layer_semantics(ctx, prec, name, nmel):
     rng = np.random.default_rng(sum(map(ord, name)) + nmel)
     layers = TOPOLOGIES[name](rng, nmel)
     comp = KM.compile_layers(layers, (68, nmel, 1))
@@ -86,13 +102,13 @@ def test_layer_semantics(ctx, name, nmel):
 
 
 @pytest.mark.parametrize('net,nmel,ncls', [('smn', 21, 3), ('gender', 24, 2)])
-def test_ina_like_net_on_real_features(ctx, net, nmel, ncls):
+def test_ina_like_net_on_real_features(ctx, prec, net, nmel, ncls):
     g = np.load(os.path.join(GOLDEN, 'sidekit_feats.npz'))
     mspec = g['musanmix_mspec']
     layers, shp = KM.synthetic_ina_like(nmel, ncls, seed=3)
     comp = KM.compile_layers(layers, shp)
     ctx.cnn_load(3, comp)
-    assert ctx.cnn_flops(3) == ocnn.flops_per_sample(layers, shp)
+    assert ctx.cnn_flops(3) == comp.flops_per_sample <= ocnn.flops_per_sample(layers, shp)   # fused pools skip dropped rows
     ctx.set_mspec(mspec)
     rows = S._window_rows(len(mspec))
     probs, fin = ctx.cnn_probs(3, rows)
@@ -102,9 +118,12 @@ def test_ina_like_net_on_real_features(ctx, net, nmel, ncls):
     ref = ocnn.forward(layers, x)
     ref[~rfin] = 0.5
     err = np.abs(probs - ref).max()
-    print(f'{net}: max |p_gpu - p_oracle| = {err:.2e} over {len(rows)} slots')
-    assert err < PROB_TOL
-    assert np.array_equal(probs.argmax(1), ref.argmax(1)) or err < 1e-5
+    print(f'{net} [{prec}]: max |p_gpu - p_oracle| = {err:.2e} over {len(rows)} slots')
+    assert err < 1e-4
+    # the unfused program (stand-alone pool kernels) must give the same answer
+    ctx.cnn_load(3, KM.compile_layers(layers, shp, fuse_pool=False))
+    probs2, _ = ctx.cnn_probs(3, rows)
+    assert np.abs(probs2 - ref).max() < 1e-4 and np.abs(probs2 - probs).max() < 2e-5
 
 
 def test_non_finite_and_constant_windows(ctx):
@@ -136,12 +155,12 @@ def test_chunked_passes_agree(ctx):
     ctx.set_workspace_limit(6 << 30)
     b, _ = ctx.cnn_probs(3, rows)
     assert np.array_equal(a, b)
-    c, _ = ctx.cnn_probs(3, rows[:1])
-    assert np.array_equal(c[0], a[0])
+    c, _ = ctx.cnn_probs(3, rows[:1])          # a 1-slot pass may take another kernel variant (k order differs)
+    assert np.abs(c[0] - a[0]).max() < 1e-6
     assert ctx.cnn_probs(3, rows[:0])[0].shape == (0, 2)
 
 
-def test_generic_forward_nhwc(ctx):
+def test_generic_forward_nhwc(ctx, prec):
     rng = np.random.default_rng(13)
     layers = [_rand_conv(rng, 3, 3, 8, 16, padding='same', act='relu'), _rand_conv(rng, 1, 1, 16, 32, strides=(2, 2)),
               dict(type='flatten'), _rand_dense(rng, 5 * 6 * 32, 10)]

@@ -1,0 +1,83 @@
+"""GPU parity, config 5: VBx 64-band fbank front end and the ResNet-101 x-vector network through
+the C ABI, against the committed reference outputs (media/test.h5, reference get_features) and
+the oracle.  Tolerances: features 2e-5 abs (float64 pipeline, float32 result: FFT rounding differs
+from pocketfft at 1e-16, a few results land on the other side of a float32 rounding boundary);
+embeddings 1e-3 of the embedding scale (101 layers of float32 accumulation in a different order)."""
+import os
+
+import numpy as np
+import pytest
+
+from inaspeechsegmenter_amd import vbx as V
+from oracle import vbx as ovbx
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+FEA_TOL = 2e-5
+
+
+@pytest.fixture(scope='module')
+def golden_vbx():
+    return np.load(os.path.join(GOLDEN, 'vbx_feats.npz'))
+
+
+def test_features_match_reference_outputs(ctx, golden_vbx):
+    g = golden_vbx
+    sig = g['lamartine_pcm16'].astype(np.float64) / 32768.0           # what ffmpeg's pcm_s16le hop yields
+    fea = V.FeatureExtractor(ctx)(sig)
+    assert fea.shape == g['lamartine_fea'].shape and fea.dtype == np.float32
+    err = np.abs(fea - g['lamartine_fea']).max()
+    same = np.mean(fea == g['lamartine_fea'])
+    print(f'lamartine: max abs err {err:.2e}, {same * 100:.2f}% bit-identical')
+    assert err <= FEA_TOL
+    assert same > 0.9
+    assert np.abs(fea[:144] - g['test_h5_melbands']).max() <= FEA_TOL      # run_test.py:189-195 input fixture
+
+
+@pytest.mark.parametrize('n', [200, 1000, 16000, 48000 + 37, 160 * 301])
+def test_features_ragged_lengths_vs_oracle(ctx, n):
+    """n < 300 frames exercises the global-mean branch of cmvn_floating_kaldi (features_vbx.py:143)."""
+    rng = np.random.default_rng(n)
+    sig = np.clip(rng.normal(0, 0.1, n), -1, 1)
+    fea = V.FeatureExtractor(ctx)(sig)
+    ref = ovbx.get_features(sig)
+    assert fea.shape == ref.shape
+    assert np.abs(fea - ref).max() <= FEA_TOL
+
+
+@pytest.fixture(scope='module')
+def extractor(ctx):
+    return V.VBxExtractor(ctx, ovbx.resnet101_random_params(0), batch_windows=8)
+
+
+def test_resnet101_matches_reference_topology_golden(extractor):
+    """tests/golden/resnet_golden.npz was produced by the reference's own resnet.py (torch-CPU) with the
+    oracle's seeded parameters: pins the topology/lowering (Bottleneck [3,4,23,3], stats pooling)."""
+    g = np.load(os.path.join(GOLDEN, 'resnet_golden.npz'))
+    x = g['x']                                                        # (2, 64, 144) feature-major
+    fea = [xi.T for xi in x]                                          # (144, 64) each, as VBxExtractor sees them
+    emb = np.stack([extractor.get_embedding(f) for f in fea])
+    scale = np.abs(g['emb']).max()
+    assert np.abs(emb - g['emb']).max() <= 1e-3 * scale, (np.abs(emb - g['emb']).max(), scale)
+
+
+def test_window_loop_and_tail_window(extractor):
+    rng = np.random.default_rng(5)
+    T = 144 + 24 * 3 + 17                                             # 3 full windows + a 65-frame tail
+    fea = rng.normal(0, 1, (T, 64)).astype(np.float32)
+    got = extractor('utt', fea, T / 100.0)
+    wins = ovbx.window_list(T)
+    assert [k for k, _, _ in got] == [f'utt_{a:08}-{b:08}' for a, b in wins]
+    assert got[0][1] == (0.0, 1.44) and got[-1][1] == (round(wins[-1][0] / 100.0, 3), round(T / 100.0, 3))
+    for (key, seg, x), (a, b) in zip(got, wins):
+        ref = ovbx.resnet101_forward(extractor.params, fea[a:b].T[None])[0] * 10
+        assert np.abs(x - ref).max() <= 1e-3 * np.abs(ref).max(), key
+
+
+def test_batched_equals_single(extractor):
+    rng = np.random.default_rng(6)
+    fea = rng.normal(0, 1, (144 + 24 * 10, 64)).astype(np.float32)
+    starts = list(range(0, 24 * 10, 24))
+    a = extractor.get_embeddings(fea, starts, 144)
+    b = np.stack([extractor.get_embedding(fea[s:s + 144]) for s in starts])
+    assert np.array_equal(a, b)

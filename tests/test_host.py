@@ -202,3 +202,39 @@ def test_model_locator_message():
     with pytest.raises(FileNotFoundError) as e:
         S.locate_model('keras_speech_music_noise_cnn.hdf5')
     assert 'releases/download/models' in str(e.value)
+
+
+def test_hdf5_converter_roundtrip(tmp_path):
+    """tools/convert_keras_hdf5.py on a file laid out like Keras' HDF5 (model_config attribute,
+    model_weights/<layer>/<layer>/<weight>:0 datasets + weight_names attributes); needs an interpreter
+    with h5py (the image has one under /opt/conda)."""
+    import shutil
+    import subprocess
+    py = next((p for p in ('/opt/conda/bin/python3.9', shutil.which('python3') or '') if p and subprocess.run(
+        [p, '-c', 'import h5py'], capture_output=True).returncode == 0), None)
+    if py is None:
+        pytest.skip('no interpreter with h5py')
+    rng = np.random.default_rng(4)
+    cfg, w = _keras_cfg_and_weights(rng)
+    np.savez(tmp_path / 'w.npz', **{f'{ln}|{wn}': a.astype(np.float32) for ln, d in w.items() for wn, a in d.items()})
+    (tmp_path / 'cfg.json').write_text(json.dumps(cfg))
+    mk = ("import h5py, json, numpy as np, sys\n"
+          "z = np.load(sys.argv[1]); cfg = open(sys.argv[2]).read()\n"
+          "f = h5py.File(sys.argv[3], 'w'); f.attrs['model_config'] = cfg.encode('utf-8'); g = f.create_group('model_weights')\n"
+          "names = {}\n"
+          "for k in z.files:\n"
+          "    ln, wn = k.split('|'); names.setdefault(ln, []).append(wn)\n"
+          "    g.require_group(ln).require_group(ln).create_dataset(wn + ':0', data=z[k])\n"
+          "for ln, ws in names.items():\n"
+          "    g[ln].attrs['weight_names'] = [(ln + '/' + wn + ':0').encode() for wn in ws]\n"
+          "f.close()\n")
+    subprocess.run([py, '-c', mk, str(tmp_path / 'w.npz'), str(tmp_path / 'cfg.json'), str(tmp_path / 'm.hdf5')], check=True)
+    tool = os.path.join(os.path.dirname(GOLDEN), '..', 'tools', 'convert_keras_hdf5.py')
+    subprocess.run([py, tool, str(tmp_path / 'm.hdf5')], check=True)
+    layers, shp = KM.load_model_file(str(tmp_path / 'm.npz'))
+    ref_layers, _ = KM.layers_from_keras_config(cfg, w)
+    assert shp == (68, 21, 1) and len(layers) == len(ref_layers)
+    for a, b in zip(layers, ref_layers):
+        for k in ('W', 'b', 'gamma', 'beta', 'mean', 'var'):
+            if k in b and b[k] is not None:
+                assert np.array_equal(a[k], np.asarray(b[k], np.float32)), (a['type'], k)
