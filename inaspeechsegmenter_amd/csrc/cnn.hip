@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstring>
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -64,6 +65,7 @@ struct ConvArgs {
     int row_stride, pix_stride;
     int act, Kpad, mode;
     unsigned nblk;           // M tiles (grid.x)
+    int dbg;                 // ISS_DBG experiment bits (0 in production)
 };
 
 // GEMM row -> (sample, oy, ox) of the convolution output it stands for
@@ -123,12 +125,12 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const floatx16&
         if (p.pp == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (mb + i < p.M) p.out[(size_t)(mb + i) * p.Cout + n] = v[i];
+                if (mb + i < p.M && (!(p.dbg & 16) || v[i] == 1234.5678f)) p.out[(size_t)(mb + i) * p.Cout + n] = v[i];
         } else if (p.pp == 4) {
             if (mb < p.M) {
                 const float r = p.poolkind == 0 ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]))
                                                 : (v[0] + v[1] + v[2] + v[3]) * 0.25f;
-                p.out[(size_t)(mb >> 2) * p.Cout + n] = r;
+                if (!(p.dbg & 16) || r == 1234.5678f) p.out[(size_t)(mb >> 2) * p.Cout + n] = r;
             }
         } else {                                             // pp == 2
 #pragma unroll
@@ -402,143 +404,218 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs p) {
 // bf16 hi/lo and kept in LDS; every tap then reads its MFMA A fragments straight from that
 // footprint at a per-lane pixel offset (+ ky*W + kx).  Global A traffic drops by ~kh*kw; only
 // the 8 KB weight tile per tap still streams (double-buffered) from L2.
-constexpr int FPIX = 256;    // footprint capacity in pixels (validated on the host per launch)
+constexpr int FPIX = 360;    // footprint capacity in pixels (host-validated per launch): 56 KB of LDS as bf16 hi+lo
 
-template <bool PADDED>
+// MFMA operand fragments of one k16 step of one tap (A rows hi/lo, two 32-column B tiles hi/lo)
+struct Frags { bf16x8 ah, al, b0h, b0l, b1h, b1l; };
+
+// KH x KW are compile-time so that the tap loop unrolls completely: tap coordinates, LDS offsets,
+// B-stage parity and the footprint-slice schedule become constants.  (With a run-time tap loop the
+// scalar bookkeeping alone was ~80 SALU instructions + a dozen taken branches per 12 MFMAs, more
+// than the five issue slots a wave has between two back-to-back MFMAs.)
+// 32-bit replica of map_row (the launch guarantees M < 2^31): 64-bit integer division is ~100 scalar
+// instructions on gfx950 and this runs once per lane per tile.
+__device__ __forceinline__ void map_row32(const ConvArgs& p, int m, int& b, int& oy, int& ox) {
+    int q = m, dy = 0, dx = 0;
+    if (p.pp > 1) {
+        q = m / p.pp;
+        const int j = m - q * p.pp;
+        dy = j / p.pw; dx = j - dy * p.pw;
+    }
+    const int hw = p.Hq * p.Wq;
+    b = q / hw;
+    const int rem = q - b * hw;
+    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    oy = qy * p.ph + dy;
+    ox = qx * p.pw + dx;
+}
+
+// Persistent workgroups: a 128-row tile is only 7-14 k cycles of MFMA work, while filling the
+// pipeline (footprint + weight loads from HBM/L2, geometry) and draining it (32 stores per lane)
+// cost several thousand cycles -- one-tile-per-workgroup launches measured 33 % matrix-pipe
+// utilisation.  Here 2 x 256 workgroups each walk a contiguous range of M tiles and the software
+// pipeline runs ACROSS tiles: the next tile's first footprint and weight tiles are fetched during
+// the current tile's last taps, exactly like the next channel chunk's.
+template <int KH, int KW, bool PADDED>
 __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
+    constexpr int NT = KH * KW;
+    static_assert(NT >= 2, "1x1 convolutions use conv_x3_kernel");
     __shared__ __attribute__((aligned(16))) uint16_t sFh[FPIX * XLD];
     __shared__ __attribute__((aligned(16))) uint16_t sFl[FPIX * XLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sBh[2][BN * XLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sBl[2][BN * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBh[2 * BN * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBl[2 * BN * XLD];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long m0 = (long long)tile_of_block(blockIdx.x, p.nblk) * BM;
     const int n0 = blockIdx.y * BN;
     const int li = lane & 31, lh = lane >> 5;
+    const int M = (int)p.M;
+    const int totpix = (int)(p.img_stride / p.Cin) * (M / (p.Hq * p.Wq * p.pp));     // samples * H * W
 
-    // ---- tile geometry (uniform): pixel range touched by rows [m0, m_last]
-    long long p_lo;
-    int npix;
-    {
-        int b, oy, ox;
-        map_row(p, m0, b, oy, ox);
-        p_lo = ((long long)b * p.H + (oy * p.sh - p.pt_)) * p.W + (ox * p.sw - p.pl_);
-        const long long m_last = (m0 + BM <= p.M ? m0 + BM : p.M) - 1;
-        map_row(p, m_last, b, oy, ox);
-        const long long p_hi = ((long long)b * p.H + (oy * p.sh - p.pt_ + p.H_k - 1)) * p.W + (ox * p.sw - p.pl_ + p.kw - 1);
-        npix = (int)(p_hi - p_lo + 1);
-        if (npix > FPIX) npix = FPIX;              // cannot happen (host-validated); keeps LDS writes in range
-    }
-    // ---- this lane's A row (GEMM row m0 + 32 wv + li)
-    int lanepix, iy0, ix0;
-    {
-        const long long m = m0 + wv * 32 + li;
-        int b, oy, ox;
-        map_row(p, m < p.M ? m : m0, b, oy, ox);
-        iy0 = oy * p.sh - p.pt_;
-        ix0 = ox * p.sw - p.pl_;
-        lanepix = (int)(((long long)b * p.H + iy0) * p.W + ix0 - p_lo);
-    }
-    const long long totpix = p.img_stride / p.Cin * (p.M / ((long long)p.Hq * p.Wq * p.pp));   // samples * H * W
+    // contiguous tile range of this workgroup (neighbouring tiles share im2col halos -> same L2 / L1)
+    const int per = ((int)p.nblk + (int)gridDim.x - 1) / (int)gridDim.x;
+    int tile = (int)blockIdx.x * per;
+    const int tile_end = tile + per < (int)p.nblk ? tile + per : (int)p.nblk;
+    if (tile >= tile_end) return;
 
-    // ---- B staging bookkeeping
+    // ---- per-tile geometry: first pixel of the tile (uniform) and this lane's A row
+    struct Geom { int p_lo, abase, iy0, ix0; };
+    auto geometry = [&](int t) {
+        Geom g;
+        const int m0 = t * BM;
+        int b, oy, ox;
+        map_row32(p, m0, b, oy, ox);
+        g.p_lo = (b * p.H + (oy * p.sh - p.pt_)) * p.W + (ox * p.sw - p.pl_);
+        const int m = m0 + wv * 32 + li;
+        map_row32(p, m < M ? m : m0, b, oy, ox);
+        g.iy0 = oy * p.sh - p.pt_;
+        g.ix0 = ox * p.sw - p.pl_;
+        int lanepix = (b * p.H + g.iy0) * p.W + g.ix0 - g.p_lo;
+        const int hi = FPIX - 1 - ((KH - 1) * p.W + (KW - 1));   // keeps every tap of a row >= M inside the buffer
+        lanepix = lanepix < 0 ? 0 : (lanepix > hi ? hi : lanepix);
+        g.abase = lanepix * XLD + lh * 8;
+        if (p.dbg & 8) g.abase = (wv * 32 + li) * XLD + lh * 8;   // experiment: conflict-free A reads (wrong results)
+        return g;
+    };
+    Geom g = geometry(tile), gn = g;
+
+    // ---- B staging: thread -> 8 bf16 (16 B) of weight row br, hi and lo.  Rows >= Cout read row 0
+    // instead: their output columns are never stored, so no masking.
     const int br = tid >> 2, bseg = tid & 3;
-    const bool bok = n0 + br < p.Cout;
-    const size_t boff = (size_t)(bok ? n0 + br : 0) * p.Kpad + bseg * 8;
-    const int ntap = p.H_k * p.kw;
+    const size_t boff = (size_t)(n0 + br < p.Cout ? n0 + br : 0) * p.Kpad + bseg * 8;
+    const int bdst = br * XLD + bseg * 8;
     uint4 rbh, rbl;
     auto fetch_b = [&](int tap, int c0) {
-        // rows >= Cout read row 0 instead: their output columns are never stored, so no masking
         rbh = *reinterpret_cast<const uint4*>(p.wh + boff + (size_t)tap * p.Cin + c0);
         rbl = *reinterpret_cast<const uint4*>(p.wl + boff + (size_t)tap * p.Cin + c0);
     };
-    auto stage_b = [&](int buf) {
-        *reinterpret_cast<uint4*>(&sBh[buf][br * XLD + bseg * 8]) = rbh;
-        *reinterpret_cast<uint4*>(&sBl[buf][br * XLD + bseg * 8]) = rbl;
+    auto stage_b = [&](int stage_off) {
+        *reinterpret_cast<uint4*>(&sBh[stage_off + bdst]) = rbh;
+        *reinterpret_cast<uint4*>(&sBl[stage_off + bdst]) = rbl;
     };
 
     floatx16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
 
+    // ---- footprint prefetch registers: pixel prow + 32 q, channels [c0 + 4 k8, +4).  Pixels outside
+    // [0, totpix) are clamped to a valid address: only rows >= M or zero-padded taps ever read them
+    // (the latter are zeroed after the LDS read), so the loads need no mask.
     const int k8 = tid & 7, prow = tid >> 3;
-    const int boff_s = li * XLD + lh * 8;
-    // footprint prefetch registers: pixel prow + 32 q, channels [c0 + 4 k8, +4)
-    float4 fv[FPIX / 32];
-    // Pixels outside [0, totpix) are clamped to a valid address: only rows >= M or zero-padded
-    // taps ever read them (the latter are zeroed after the LDS read), so the loads need no mask --
-    // a masked load would come with a zero-init of its destination registers and an
-    // `s_waitcnt vmcnt(0)` in front of it.
-    auto fetch_fp_part = [&](int q, int c0) {
-        long long gp = p_lo + prow + 32 * q;
+    constexpr int NFV = (FPIX + 31) / 32;
+    float4 fv[NFV];
+    auto fetch_fp_part = [&](int q, int p_lo, int c0) {
+        int gp = p_lo + prow + 32 * q;
         gp = gp < 0 ? 0 : (gp > totpix - 1 ? totpix - 1 : gp);
-        fv[q] = *reinterpret_cast<const float4*>(p.in + gp * p.Cin + c0 + k8 * 4);
+        fv[q] = *reinterpret_cast<const float4*>(p.in + ((unsigned)gp * (unsigned)p.Cin + (unsigned)(c0 + k8 * 4)));
     };
     auto stage_fp = [&]() {
 #pragma unroll
-        for (int q = 0; q < FPIX / 32; ++q) {
+        for (int q = 0; q < NFV; ++q) {
+            if (prow + 32 * q >= FPIX) continue;
             bf16x4 h, l;
             split4(fv[q], h, l);
             *reinterpret_cast<bf16x4*>(&sFh[(prow + 32 * q) * XLD + k8 * 4]) = h;
             *reinterpret_cast<bf16x4*>(&sFl[(prow + 32 * q) * XLD + k8 * 4]) = l;
         }
     };
+
+    const int boff_s = li * XLD + lh * 8;
+    auto read_frags = [&](Frags& f, const Geom& gg, int ky, int kx, int ks, int stage_off) {
+        const int aoff = gg.abase + (ky * p.W + kx) * XLD + ks * 16;
+        f.ah = *reinterpret_cast<const bf16x8*>(&sFh[aoff]);
+        f.al = *reinterpret_cast<const bf16x8*>(&sFl[aoff]);
+        if (PADDED) {
+            const bool ok = (unsigned)(gg.iy0 + ky) < (unsigned)p.H && (unsigned)(gg.ix0 + kx) < (unsigned)p.W;
+            if (!ok) {
 #pragma unroll
-    for (int q = 0; q < FPIX / 32; ++q) fetch_fp_part(q, 0);
-    fetch_b(0, 0);
-    stage_b(0);
-    int it = 0;                                     // running tap counter: B buffer parity
-    // vmcnt is an in-order counter: the wait in front of every tap's B ds_write also drains any
-    // older load.  So the next chunk's footprint is fetched in slices, `fpt` float4 per thread at
-    // the top of each of the first taps, where the tap's own 12 MFMAs cover the latency.
-    const int fpt = (FPIX / 32 + ntap - 1) / ntap;
-    for (int c0 = 0; c0 < p.Cin; c0 += XBK) {
-        // every wave passed the barrier behind the previous chunk's last tap: the footprint is free
-        stage_fp();
-        __syncthreads();
-        const bool next_chunk = c0 + XBK < p.Cin;
-        int ky = 0, kx = 0;
-        for (int tap = 0; tap < ntap; ++tap, ++it) {
-            const int cur = it & 1;
-            const bool last_tap = tap + 1 == ntap;
-            const bool more = !last_tap || next_chunk;
-            if (more) fetch_b(last_tap ? 0 : tap + 1, last_tap ? c0 + XBK : c0);
-            if (next_chunk) {                        // after the B loads: see the vmcnt note above
-#pragma unroll
-                for (int q = 0; q < FPIX / 32; ++q)
-                    if (q / fpt == tap) fetch_fp_part(q, c0 + XBK);
+                for (int q = 0; q < 8; ++q) { f.ah[q] = (__bf16)0.f; f.al[q] = (__bf16)0.f; }
             }
-            int pix = lanepix + ky * p.W + kx;
-            pix = pix < 0 ? 0 : (pix > FPIX - 1 ? FPIX - 1 : pix);
-            bool ok = true;
-            if (PADDED) ok = (unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W;
-            const int aoff = pix * XLD + lh * 8;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sFh[aoff + ks * 16]);
-                bf16x8 al = *reinterpret_cast<const bf16x8*>(&sFl[aoff + ks * 16]);
-                if (PADDED && !ok) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { ah[q] = (__bf16)0.f; al[q] = (__bf16)0.f; }
-                }
-                const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + ks * 16]);
-                const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + ks * 16]);
-                const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + 32 * XLD + ks * 16]);
-                const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + 32 * XLD + ks * 16]);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
-            }
-            if (more) stage_b(cur ^ 1);
-            if (++kx == p.kw) { kx = 0; ++ky; }
-            __syncthreads();
         }
+        f.b0h = *reinterpret_cast<const bf16x8*>(&sBh[stage_off + boff_s + ks * 16]);
+        f.b0l = *reinterpret_cast<const bf16x8*>(&sBl[stage_off + boff_s + ks * 16]);
+        f.b1h = *reinterpret_cast<const bf16x8*>(&sBh[stage_off + boff_s + 32 * XLD + ks * 16]);
+        f.b1l = *reinterpret_cast<const bf16x8*>(&sBl[stage_off + boff_s + 32 * XLD + ks * 16]);
+    };
+    auto mfma6 = [&](const Frags& f) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b0h, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b1h, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0l, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1l, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0h, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1h, acc1, 0, 0, 0);
+    };
+
+    // ---- software pipeline over the (tile, chunk, tap) sequence.  LDS holds B(t), B(t+1) (2 stages)
+    //   and the footprint of tap t's chunk.  Tap t:
+    //     global: fetch B(t+2) and a slice of the next chunk's (or next tile's first) footprint
+    //     LDS   : read the fragments of t's second k16 step          (covered by the 6 MFMAs below)
+    //     6 MFMAs on the first k16 step (fragments read during tap t-1)
+    //     barrier (all reads of B(t)'s stage are back)
+    //     LDS   : read the fragments of (t+1)'s first k16 step       (covered by the 6 MFMAs below)
+    //     6 MFMAs on the second k16 step
+    //     write B(t+2) over B(t)'s stage, barrier.
+    //   The last tap of a chunk additionally swaps the footprint between its two MFMA groups; the
+    //   last tap of a tile is followed by the epilogue (stores drain behind the next tile's taps).
+    constexpr int FPT = (NFV + NT - 2) / (NT - 1);   // footprint slices per tap (taps 0 .. NT-2 of a chunk)
+    const int nchunk = (p.dbg & 32) ? 0 : p.Cin / XBK;   // experiment 32: no main loop at all
+#pragma unroll
+    for (int q = 0; q < NFV; ++q) fetch_fp_part(q, g.p_lo, 0);
+    fetch_b(0, 0);
+    stage_fp();
+    stage_b(0);
+    fetch_b(1, 0);
+    stage_b(BN * XLD);
+    __syncthreads();
+    Frags fa, fb;                                    // fa: first k16 step of the current tap, fb: second
+    read_frags(fa, g, 0, 0, 0, 0);
+    int sA = 0, sB = BN * XLD;                       // B stage of this chunk's even / odd taps
+
+    for (; tile < tile_end; ++tile) {
+        const bool last_tile = tile + 1 == tile_end;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int c0 = ch * XBK;
+            const bool last_chunk = ch + 1 == nchunk;
+            const bool fin = last_chunk && last_tile;            // nothing follows this chunk
+            if (last_chunk && !last_tile) gn = geometry(tile + 1);
+            const int nx_plo = last_chunk ? gn.p_lo : g.p_lo;    // where the next chunk's footprint comes from
+            const int nx_c0 = last_chunk ? 0 : c0 + XBK;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const bool has1 = j + 1 < NT || !fin;
+                const bool has2 = j + 2 < NT || !fin;
+                const int st_cur = (j & 1) ? sB : sA, st_nxt = (j & 1) ? sA : sB;
+                if (has2 && !(p.dbg & 1)) fetch_b((j + 2) % NT, (j + 2) >= NT ? nx_c0 : c0);
+                if (!fin && j < NT - 1 && !(p.dbg & 4)) {
+#pragma unroll
+                    for (int q = j * FPT; q < (j + 1) * FPT && q < NFV; ++q) fetch_fp_part(q, nx_plo, nx_c0);
+                }
+                read_frags(fb, g, j / KW, j % KW, 1, st_cur);
+                mfma6(fa);
+                // Every wave must have its fb reads (B(t)'s stage, this chunk's footprint) back before
+                // anyone overwrites either: B(t+2) goes into that stage at the end of this tap.
+                if (!(p.dbg & 2)) __syncthreads();
+                if (has1) {
+                    if (j == NT - 1 && !(p.dbg & 4)) {   // tap t+1 opens the next chunk: swap the footprint
+                        stage_fp();
+                        __syncthreads();
+                    }
+                    read_frags(fa, (j == NT - 1 && last_chunk) ? gn : g, ((j + 1) % NT) / KW, ((j + 1) % NT) % KW, 0, st_nxt);
+                }
+                mfma6(fb);
+                if (has2 && !(p.dbg & 1)) stage_b(st_cur);   // B(t)'s stage: all of its fragments are in registers by now
+                // Drain vmcnt on EVERY path: otherwise hipcc cannot prove at the next tap that the registers
+                // its loads target have no load in flight, and waits for global memory in front of the MFMAs.
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+                if (!(p.dbg & 2)) __syncthreads();
+            }
+            if (NT & 1) { const int t = sA; sA = sB; sB = t; }   // odd tap count: next chunk starts on the other stage
+        }
+        epilogue_tile(p, acc0, (long long)tile * BM + wv * 32, n0 + li, lh);
+        epilogue_tile(p, acc1, (long long)tile * BM + wv * 32, n0 + 32 + li, lh);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        g = gn;
     }
-    epilogue_tile(p, acc0, m0 + wv * 32, n0 + li, lh);
-    epilogue_tile(p, acc1, m0 + wv * 32, n0 + 32 + li, lh);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -770,6 +847,16 @@ extern "C" int iss_cnn_flops(iss_ctx* c, int id, double* f) {
 
 namespace {
 
+// Kernel shapes conv_x3_fp_kernel is instantiated for (the tap loop is unrolled at compile time);
+// other shapes run on conv_x3_kernel.
+#define ISS_FP_SHAPES(X) X(3, 3) X(5, 3) X(3, 5) X(5, 5) X(2, 2) X(4, 4) X(1, 3) X(3, 1)
+inline bool fp_shape_compiled(int kh, int kw) {
+#define ISS_FP_HAS(KH_, KW_) if (kh == KH_ && kw == KW_) return true;
+    ISS_FP_SHAPES(ISS_FP_HAS)
+#undef ISS_FP_HAS
+    return false;
+}
+
 // Host replica of the device's row mapping / footprint arithmetic: does every 128-row tile of this
 // launch touch at most FPIX pixels?  The pattern is periodic in the sample index (period <= BM
 // samples), so tiles covering the first BM + 2 samples decide.
@@ -842,11 +929,13 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 a.row_stride = a.W * a.Cin; a.pix_stride = a.Cin; a.img_stride = (long long)a.H * a.W * a.Cin;
             }
             a.nblk = (unsigned)((a.M + BM - 1) / BM);
+            { static const int dbg = getenv("ISS_DBG") ? atoi(getenv("ISS_DBG")) : 0; a.dbg = dbg; }
             dim3 grid(a.nblk, (unsigned)((a.Cout + BN - 1) / BN));
             const double fl = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * a.Cin * (double)a.Cout * (double)a.M;
             iss_prof_begin(c, 0, fl);
             bool fp = false;
-            if (x3 && a.mode == 0 && a.H_k * a.kw > 1) {
+            if (x3 && a.mode == 0 && fp_shape_compiled(a.H_k, a.kw) && a.M < (1ll << 31) &&
+                (long long)bc * a.img_stride < (1ll << 32)) {
                 const long long key = ((long long)r << 32) | (unsigned)bc;
                 auto it = n.fp_ok.find(key);
                 if (it == n.fp_ok.end()) it = n.fp_ok.emplace(key, footprint_fits(a)).first;
@@ -855,8 +944,14 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             if (fp) {
                 const bool padded = a.pt_ != 0 || a.pl_ != 0 ||
                                     (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
-                if (padded) hipLaunchKernelGGL(conv_x3_fp_kernel<true>, grid, dim3(256), 0, c->stream, a);
-                else hipLaunchKernelGGL(conv_x3_fp_kernel<false>, grid, dim3(256), 0, c->stream, a);
+#define ISS_FP_CASE(KH_, KW_)                                                                              \
+    if (a.H_k == KH_ && a.kw == KW_) {                                                                     \
+        if (padded) hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, true>), pgrid, dim3(256), 0, c->stream, a);  \
+        else hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, false>), pgrid, dim3(256), 0, c->stream, a);        \
+    } else
+                const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent: 2 workgroups per CU
+                ISS_FP_SHAPES(ISS_FP_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no footprint kernel for %dx%d", a.H_k, a.kw); }
+#undef ISS_FP_CASE
             } else if (x3) {
                 if (a.mode == 0) hipLaunchKernelGGL(conv_x3_kernel<0>, grid, dim3(256), 0, c->stream, a);
                 else if (a.mode == 1) hipLaunchKernelGGL(conv_x3_kernel<1>, grid, dim3(256), 0, c->stream, a);
