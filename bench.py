@@ -91,7 +91,7 @@ def cpu_baseline(seg, pcm_host, target_s=15.0):
     forward + the reference-order Viterbi) on a bounded sample of the same recording."""
     import torch
     from oracle import sidekit as osk, segment as oseg, keras_cnn as ocnn
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 64)      # torch-CPU conv stops scaling (and oversubscribes) beyond ~64 threads
     torch.set_num_threads(threads)
     vad_layers, gen_layers = seg.vad.layers, seg.gender.layers
 
