@@ -117,6 +117,55 @@ def cpu_baseline(seg, pcm_host, target_s=15.0):
             "x_realtime": nsec / t}
 
 
+def bench_vbx(args, torch, dev, local_rank, rank, world):
+    """BASELINE.json configs[4]: 1 h of 16 kHz audio through get_features (VBx 64-band fbank + CMN) and the
+    ResNet-101 x-vector network (144-frame windows, hop 24) -- not the headline metric, printed for DESIGN.md."""
+    from inaspeechsegmenter_amd import _native, vbx as V
+    from oracle import vbx as ovbx                       # only for the seeded stand-in parameters
+    ctx = _native.Context(local_rank)
+    ctx.set_precision(_native.PREC_BF16X3 if args.precision == 'bf16x3' else _native.PREC_F32)
+    if args.workspace_mb:
+        ctx.set_workspace_limit(args.workspace_mb << 20)
+    fe = V.FeatureExtractor(ctx)
+    ex = V.VBxExtractor(ctx, ovbx.resnet101_random_params(0), batch_windows=512)
+    n = int(args.minutes * 60 * FS)
+    sig = synth_recording(rank, n, dev).cpu().numpy().astype(np.float64) / 32768.0
+    hours = n / FS / 3600.0
+
+    def step():
+        t0 = time.perf_counter()
+        fea = fe(sig)
+        t1 = time.perf_counter()
+        xv = ex('utt', fea, n / FS)
+        return t1 - t0, time.perf_counter() - t1, len(xv)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    tf = tx = 0.0
+    for _ in range(args.steps):
+        a, b, nwin = step()
+        tf += a
+        tx += b
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    step()
+    conv_ms, conv_launches, conv_flops = ctx.prof_get(0)
+    ctx.prof_enable(False)
+    print(json.dumps({"metric": "hours-of-audio through the vbx x-vector path per second", "value": args.steps * hours / dt,
+                      "unit": "hours-of-audio/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": dt / args.steps * 1e3, "x_realtime": args.steps * hours * 3600 / dt,
+                      "config": {"workload": f"BASELINE.json configs[4]: {args.minutes:g} min synthetic audio, get_features + ResNet-101 on "
+                                             f"{nwin} windows (seeded stand-in weights), host signal -> device",
+                                 "features_ms_per_step": tf / args.steps * 1e3, "xvectors_ms_per_step": tx / args.steps * 1e3},
+                      "roofline": {"bound": "mfma", "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0,
+                                   "unit": "TFLOP/s (algorithmic)", "kernel_ms_per_step": conv_ms, "launches_per_step": conv_launches,
+                                   "flops_per_step": conv_flops}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -124,6 +173,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--minutes', type=float, default=60.0, help='length of each rank\'s recording')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['segmenter', 'vbx'], default='segmenter',
+                    help="segmenter = the metric's workload (default); vbx = BASELINE.json configs[4] (x-vector path)")
+    ap.add_argument('--workspace-mb', type=int, default=0, help='activation workspace cap (0 = library default)')
     ap.add_argument('--precision', choices=['bf16x3', 'f32'], default='bf16x3',
                     help='conv/dense GEMM arithmetic: split-bf16 MFMA (default) or exact-f32 MFMA')
     args = ap.parse_args()
@@ -147,10 +199,14 @@ def main():
 
     from inaspeechsegmenter_amd import Segmenter, _native
     from inaspeechsegmenter_amd.sharding import pack_segments, allgather_segment_tables
+    if args.workload == 'vbx':
+        return bench_vbx(args, torch, dev, local_rank, rank, world)
 
     seg = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models='synthetic', device=local_rank)
     x3 = args.precision == 'bf16x3'
     seg.ctx.set_precision(_native.PREC_BF16X3 if x3 else _native.PREC_F32)
+    if args.workspace_mb:
+        seg.ctx.set_workspace_limit(args.workspace_mb << 20)
     n = int(args.minutes * 60 * FS)
     pcm = synth_recording(rank, n, dev)
     torch.cuda.synchronize()

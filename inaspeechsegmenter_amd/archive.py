@@ -1,0 +1,70 @@
+"""Long-archive driver: file-parallel over the GPUs of one node (BASELINE.json configs[3]).
+
+The reference scales out with a Pyro4 pull queue handing (src, dst) pairs to independent
+`batch_process` workers (scripts/ina_speech_segmenter_pyro_server.py:34-68, ..._client.py:64-74).
+Here the same independence is used inside one node: one process per GPU (launch with
+`python -m torch.distributed.run --nproc-per-node N ...`), files dealt to ranks by size
+(sharding.shard_files), every rank runs its own files through its own Segmenter and writes their
+outputs, and ONE all-gather of int32 segment tables (RCCL) leaves the complete
+{file: segments} table on every rank.  Without torch.distributed it degrades to a plain loop.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import sharding
+from .export_funcs import seg2csv, seg2textgrid
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        return dist if dist.is_available() and dist.is_initialized() else None
+    except ImportError:
+        return None
+
+
+def segment_archive(segment_file, linput, loutput=None, output_format='csv', sizes=None, skipifexist=False,
+                    capacity=None, device=None):
+    """segment_file(path) -> [(label, start_sec, stop_sec)] with times on the 20 ms grid (what
+    Segmenter.__call__ returns).  linput / loutput: all files, identical on every rank.
+    Returns (table, lmsg): table = {file_index: [(label, start_sec, stop_sec)]} for ALL files (gathered),
+    lmsg = this rank's [(dst, code, text)] in the reference's batch_process convention
+    (0 ok / 1 already exists / 2 error, segmenter.py:352,370,372)."""
+    dist = _dist()
+    world = dist.get_world_size() if dist else 1
+    rank = dist.get_rank() if dist else 0
+    if output_format not in ('csv', 'textgrid'):
+        raise NotImplementedError()
+    fexport = seg2csv if output_format == 'csv' else seg2textgrid
+    if sizes is None:
+        sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in linput]
+    mine = sharding.shard_files(sizes, world)[rank]
+    rows, lmsg = [], []
+    for i in sorted(mine):
+        dst = loutput[i] if loutput is not None else None
+        if skipifexist and dst is not None and os.path.exists(dst):
+            lmsg.append((dst, 1, 'already exists'))
+            continue
+        b = time.time()
+        try:
+            lseg = segment_file(linput[i])
+            if dst is not None:
+                d = os.path.dirname(dst)
+                if d and not os.path.isdir(d):
+                    os.makedirs(d, exist_ok=True)
+                fexport(lseg, dst)
+            slots = [(lab, int(round(s / .02)), int(round(e / .02))) for lab, s, e in lseg]
+            rows.append(sharding.pack_segments(i, slots))
+            lmsg.append((dst, 0, 'ok ' + str(time.time() - b)))
+        except Exception:                                     # per-file errors do not stop the archive (segmenter.py:364-370)
+            lmsg.append((dst, 2, 'error: ' + str(sys.exc_info()[0])))
+    local = np.concatenate(rows, axis=0) if rows else np.zeros((0, 4), np.int32)
+    if dist:
+        cap = capacity or max(1024, 64 * (len(linput) // world + 1))
+        allrows = sharding.allgather_segment_tables(local, capacity=cap, device=device)
+    else:
+        allrows = local
+    return sharding.unpack_segments(allrows), lmsg

@@ -1,0 +1,94 @@
+"""CPU: the long-archive driver (file sharding + per-file outputs + gathered table) with a stand-in
+`segment_file` and two gloo ranks; the CLI's argument surface against the reference's flags."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from inaspeechsegmenter_amd import archive
+
+
+def _fake_segment(path):
+    n = int(os.path.basename(path).split('_')[1].split('.')[0])
+    if n == 3:
+        raise IOError('decode failed')
+    return [('noEnergy', 0.0, n * .02), ('female' if n % 2 else 'music', n * .02, (2 * n + 5) * .02)]
+
+
+def _files(tmp_path, k=7):
+    lin = []
+    for i in range(k):
+        p = tmp_path / f'f_{i}.wav'
+        p.write_bytes(b'x' * (100 * (i + 1)))
+        lin.append(str(p))
+    return lin, [str(tmp_path / 'out' / f'f_{i}.csv') for i in range(k)]
+
+
+def test_single_process(tmp_path):
+    lin, lout = _files(tmp_path)
+    table, lmsg = archive.segment_archive(_fake_segment, lin, lout)
+    assert sorted(table) == [0, 1, 2, 4, 5, 6]                       # file 3 failed
+    assert [m[1] for m in lmsg] == [0, 0, 0, 2, 0, 0, 0] and lmsg[3][2].startswith('error: ')
+    assert table[5] == _fake_segment(lin[5])
+    assert open(lout[5]).read().splitlines()[0] == 'labels\tstart\tstop'
+    table2, lmsg2 = archive.segment_archive(_fake_segment, lin, lout, skipifexist=True)
+    assert [m[1] for m in lmsg2] == [1, 1, 1, 2, 1, 1, 1] and sorted(table2) == []
+    with pytest.raises(NotImplementedError):
+        archive.segment_archive(_fake_segment, lin, lout, output_format='json')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, port, lin, lout, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=2)
+    try:
+        table, lmsg = archive.segment_archive(_fake_segment, lin, lout, capacity=4)   # tiny capacity: overflow path too
+        q.put((rank, table, lmsg))
+    except Exception as e:
+        q.put((rank, repr(e), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gloo_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    lin, lout = _files(tmp_path)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, lin, lout, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    want, _ = archive.segment_archive(_fake_segment, lin, None)
+    for rank, table, lmsg in res:
+        assert lmsg is not None, table
+        assert table == want                                         # every rank holds the complete table
+    done = sorted(m[0] for r in res for m in r[2] if m[1] == 0)
+    assert done == sorted(lout[i] for i in want)                     # each file processed by exactly one rank
+    assert all(os.path.exists(f) for f in done)
+
+
+def test_cli_flags_match_reference():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts'))
+    import ina_speech_segmenter_amd as cli
+    a = cli.build_parser().parse_args(['-i', 'a.wav', 'b*.wav', '-o', '/tmp', '-d', 'sm', '-g', 'false', '-b', 'None',
+                                       '-e', 'textgrid', '-r', '0.05', '-s', '1024'])
+    assert a.input == ['a.wav', 'b*.wav'] and a.vad_engine == 'sm' and a.detect_gender is False
+    assert a.ffmpeg_binary == 'None' and a.export_format == 'textgrid' and a.energy_ratio == 0.05 and a.batch_size == 1024
+    d = cli.build_parser().parse_args(['-i', 'x', '-o', 'y'])
+    assert (d.vad_engine, d.detect_gender, d.ffmpeg_binary, d.export_format, d.energy_ratio, d.batch_size) == \
+        ('smn', True, 'ffmpeg', 'csv', 0.03, 32)

@@ -111,3 +111,19 @@ def test_segment_feats_accepts_host_arrays(seg):
     pcm = synth_pcm(1234, 48000)
     b = seg.segment_signal(pcm, start_sec=1.5)
     assert a == b
+
+
+def test_cli_end_to_end(tmp_path):
+    """run_test.py:136-148 test_program / test_program_smn shape: the CLI writes <basename>.csv per input; the
+    weight-free golden (silence2sec) is byte-identical."""
+    import subprocess
+    import sys
+    root = os.path.dirname(GOLDEN.rstrip('/').rsplit('/tests', 1)[0] + '/x')
+    cli = os.path.join(os.path.dirname(os.path.dirname(GOLDEN)), 'scripts', 'ina_speech_segmenter_amd.py')
+    r = subprocess.run([sys.executable, cli, '-i', os.path.join(GOLDEN, 'silence2sec.wav'), os.path.join(GOLDEN, 'musanmix.wav'),
+                        '-o', str(tmp_path), '-b', 'None', '--models', 'synthetic'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert filecmp.cmp(str(tmp_path / 'silence2sec.csv'), os.path.join(GOLDEN, 'silence2sec-smn-gender.csv'), shallow=False)
+    rows = _csv_rows(str(tmp_path / 'musanmix.csv'))
+    gold = _csv_rows(os.path.join(GOLDEN, 'musanmix-smn-gender.csv'))
+    assert [(s, e) for l, s, e in rows if l == 'noEnergy'] == [(s, e) for l, s, e in gold if l == 'noEnergy']
