@@ -160,11 +160,17 @@ def test_keras_config_parse_and_lowering(tmp_path):
     layers, shp = KM.layers_from_keras_config(cfg, w)
     assert shp == (68, 21, 1) and [l['type'] for l in layers] == ['conv2d', 'batchnorm', 'activation', 'maxpool',
                                                                   'dropout', 'flatten', 'dense']
-    c = KM.compile_layers(layers, shp)
+    c = KM.compile_layers(layers, shp, fuse_pool=False)
     ops = list(c.prog[:, _native.C_OP])
     assert ops == [_native.OP_CONV, _native.OP_POOL, _native.OP_CONV, _native.OP_SOFTMAX]   # BN+relu fused
     assert c.prog[0, _native.C_INMODE] == 1 and c.prog[0, _native.C_ACT] == 1 and c.out_dim == 3
     assert c.flops_per_sample == ocnn.flops_per_sample(layers, shp)
+    cf = KM.compile_layers(layers, shp)                                                    # 2x2 max-pool -> conv epilogue
+    assert list(cf.prog[:, _native.C_OP]) == [_native.OP_CONV, _native.OP_CONV, _native.OP_SOFTMAX]
+    assert tuple(cf.prog[0, [_native.C_FPOOLH, _native.C_FPOOLW, _native.C_POOLKIND]]) == (2, 2, 0)
+    assert tuple(cf.prog[0, [_native.C_HO, _native.C_WO]]) == (68, 21) and cf.buf_elems[cf.prog[0, _native.C_OUT]] == 34 * 10 * 8
+    assert cf.flops_per_sample == c.flops_per_sample - 2 * 9 * 8 * (68 * 21 - 68 * 20)       # the odd 21st column is never computed
+    assert cf.prog[0, _native.C_WOFF] % 8 == 0 and cf.prog[1, _native.C_WOFF] % 8 == 0
     # flat .npz round trip (what scripts/convert_keras_hdf5.py writes)
     flat = {'model_config': np.array(json.dumps(cfg))}
     for ln, d in w.items():
