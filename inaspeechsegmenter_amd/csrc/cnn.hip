@@ -436,16 +436,35 @@ __device__ __forceinline__ void map_row32(const ConvArgs& p, int m, int& b, int&
 // utilisation.  Here 2 x 256 workgroups each walk a contiguous range of M tiles and the software
 // pipeline runs ACROSS tiles: the next tile's first footprint and weight tiles are fetched during
 // the current tile's last taps, exactly like the next channel chunk's.
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS at (wave-uniform base + lane * 16); no VGPR
+// destination, no ds_write.  hipcc does not count this instruction in its s_waitcnt bookkeeping: the kernel
+// below waits for it with explicit vmcnt(N) statements.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
+}
+
+// 16-byte chunk swizzle of the unpadded LDS tiles (rows of 4 chunks = 32 bf16): logical chunk c of row r
+// lives at physical chunk c ^ ((r >> 2) & 3).  16 lanes of a ds_read_b128 group that read the same logical
+// chunk of 16 rows with distinct (r mod 16) hit 16 different 16-byte bank groups.
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
+
 template <int KH, int KW, bool PADDED>
 __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     constexpr int NT = KH * KW;
     static_assert(NT >= 2, "1x1 convolutions use conv_x3_kernel");
-    __shared__ __attribute__((aligned(16))) uint16_t sFh[FPIX * XLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sFl[FPIX * XLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sBh[2 * BN * XLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sBl[2 * BN * XLD];
+    constexpr int BSTAGE = BN * 64;                  // bytes of one plane of one weight stage (64 rows x 32 bf16)
+    __shared__ __attribute__((aligned(16))) uint16_t sFh[FPIX * 32];
+    __shared__ __attribute__((aligned(16))) uint16_t sFl[FPIX * 32];
+    __shared__ __attribute__((aligned(1024))) uint16_t sB[4 * 2 * BSTAGE / 2];      // [stage][hi | lo][row][32]
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = blockIdx.y * BN;
     const int li = lane & 31, lh = lane >> 5;
     const int M = (int)p.M;
@@ -458,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     if (tile >= tile_end) return;
 
     // ---- per-tile geometry: first pixel of the tile (uniform) and this lane's A row
-    struct Geom { int p_lo, abase, iy0, ix0; };
+    struct Geom { int p_lo, lanepix, iy0, ix0; };
     auto geometry = [&](int t) {
         Geom g;
         const int m0 = t * BM;
@@ -471,26 +490,21 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         g.ix0 = ox * p.sw - p.pl_;
         int lanepix = (b * p.H + g.iy0) * p.W + g.ix0 - g.p_lo;
         const int hi = FPIX - 1 - ((KH - 1) * p.W + (KW - 1));   // keeps every tap of a row >= M inside the buffer
-        lanepix = lanepix < 0 ? 0 : (lanepix > hi ? hi : lanepix);
-        g.abase = lanepix * XLD + lh * 8;
-        if (p.dbg & 8) g.abase = (wv * 32 + li) * XLD + lh * 8;   // experiment: conflict-free A reads (wrong results)
+        g.lanepix = lanepix < 0 ? 0 : (lanepix > hi ? hi : lanepix);
         return g;
     };
     Geom g = geometry(tile), gn = g;
 
-    // ---- B staging: thread -> 8 bf16 (16 B) of weight row br, hi and lo.  Rows >= Cout read row 0
-    // instead: their output columns are never stored, so no masking.
-    const int br = tid >> 2, bseg = tid & 3;
-    const size_t boff = (size_t)(n0 + br < p.Cout ? n0 + br : 0) * p.Kpad + bseg * 8;
-    const int bdst = br * XLD + bseg * 8;
-    uint4 rbh, rbl;
-    auto fetch_b = [&](int tap, int c0) {
-        rbh = *reinterpret_cast<const uint4*>(p.wh + boff + (size_t)tap * p.Cin + c0);
-        rbl = *reinterpret_cast<const uint4*>(p.wl + boff + (size_t)tap * p.Cin + c0);
-    };
-    auto stage_b = [&](int stage_off) {
-        *reinterpret_cast<uint4*>(&sBh[stage_off + bdst]) = rbh;
-        *reinterpret_cast<uint4*>(&sBl[stage_off + bdst]) = rbl;
+    // ---- weight tiles by LDS-DMA.  Wave wv moves slots [64 wv, 64 wv + 64) of the 256-slot tile: slot = row * 4 +
+    // physical chunk; lane reads the LOGICAL chunk that belongs there (swizzle on the source side, LDS linear).
+    // Rows >= Cout read row 0 instead: their output columns are never stored.
+    const int brow = wv * 16 + (lane >> 2);
+    const size_t boff = (size_t)(n0 + brow < p.Cout ? n0 + brow : 0) * p.Kpad + (size_t)(((lane & 3) ^ ((brow >> 2) & 3)) * 8);
+    const unsigned sB_base = (unsigned)(size_t)(&sB[0]);
+    auto dma_b = [&](int stage_off, int tap, int c0) {       // stage_off: byte offset of the stage inside sB
+        const size_t src = boff + (size_t)tap * p.Cin + c0;
+        glds16(p.wh + src, sB_base + stage_off + wv * 1024);
+        glds16(p.wl + src, sB_base + stage_off + BSTAGE + wv * 1024);
     };
 
     floatx16 acc0, acc1;
@@ -511,17 +525,22 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     auto stage_fp = [&]() {
 #pragma unroll
         for (int q = 0; q < NFV; ++q) {
-            if (prow + 32 * q >= FPIX) continue;
+            const int pix = prow + 32 * q;
+            if (pix >= FPIX) continue;
             bf16x4 h, l;
             split4(fv[q], h, l);
-            *reinterpret_cast<bf16x4*>(&sFh[(prow + 32 * q) * XLD + k8 * 4]) = h;
-            *reinterpret_cast<bf16x4*>(&sFl[(prow + 32 * q) * XLD + k8 * 4]) = l;
+            const int o = swz(pix, k8 >> 1) * 8 + (k8 & 1) * 4;          // bf16 units
+            *reinterpret_cast<bf16x4*>(&sFh[o]) = h;
+            *reinterpret_cast<bf16x4*>(&sFl[o]) = l;
         }
     };
 
-    const int boff_s = li * XLD + lh * 8;
+    const int b0s = swz(li, 0), b1s = swz(li + 32, 0);                   // chunk-0 slots of this lane's two weight rows
+    const int bx = (li >> 2) & 3;                                        // their swizzle key (same for li and li + 32)
     auto read_frags = [&](Frags& f, const Geom& gg, int ky, int kx, int ks, int stage_off) {
-        const int aoff = gg.abase + (ky * p.W + kx) * XLD + ks * 16;
+        const int pix = gg.lanepix + ky * p.W + kx;
+        const int lc = ks * 2 + lh;
+        const int aoff = swz(pix, lc) * 8;                               // bf16 units
         f.ah = *reinterpret_cast<const bf16x8*>(&sFh[aoff]);
         f.al = *reinterpret_cast<const bf16x8*>(&sFl[aoff]);
         if (PADDED) {
@@ -531,10 +550,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
                 for (int q = 0; q < 8; ++q) { f.ah[q] = (__bf16)0.f; f.al[q] = (__bf16)0.f; }
             }
         }
-        f.b0h = *reinterpret_cast<const bf16x8*>(&sBh[stage_off + boff_s + ks * 16]);
-        f.b0l = *reinterpret_cast<const bf16x8*>(&sBl[stage_off + boff_s + ks * 16]);
-        f.b1h = *reinterpret_cast<const bf16x8*>(&sBh[stage_off + boff_s + 32 * XLD + ks * 16]);
-        f.b1l = *reinterpret_cast<const bf16x8*>(&sBl[stage_off + boff_s + 32 * XLD + ks * 16]);
+        const int so = stage_off / 2;                                    // bf16 units
+        const int c = lc ^ bx;
+        f.b0h = *reinterpret_cast<const bf16x8*>(&sB[so + (b0s - (0 ^ bx) + c) * 8]);
+        f.b0l = *reinterpret_cast<const bf16x8*>(&sB[so + BSTAGE / 2 + (b0s - (0 ^ bx) + c) * 8]);
+        f.b1h = *reinterpret_cast<const bf16x8*>(&sB[so + (b1s - (0 ^ bx) + c) * 8]);
+        f.b1l = *reinterpret_cast<const bf16x8*>(&sB[so + BSTAGE / 2 + (b1s - (0 ^ bx) + c) * 8]);
     };
     auto mfma6 = [&](const Frags& f) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b0h, acc0, 0, 0, 0);
@@ -545,30 +566,31 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1h, acc1, 0, 0, 0);
     };
 
-    // ---- software pipeline over the (tile, chunk, tap) sequence.  LDS holds B(t), B(t+1) (2 stages)
-    //   and the footprint of tap t's chunk.  Tap t:
-    //     global: fetch B(t+2) and a slice of the next chunk's (or next tile's first) footprint
+    // ---- software pipeline over the (tile, chunk, tap) sequence.  LDS: three weight stages (B(t), B(t+1), and
+    //   the one B(t+2) is being DMA'd into) and the footprint of tap t's chunk.  Tap t:
+    //     global: a slice of the next chunk's (or next tile's first) footprint -> registers; DMA B(t+3) -> LDS
     //     LDS   : read the fragments of t's second k16 step          (covered by the 6 MFMAs below)
     //     6 MFMAs on the first k16 step (fragments read during tap t-1)
-    //     barrier (all reads of B(t)'s stage are back)
     //     LDS   : read the fragments of (t+1)'s first k16 step       (covered by the 6 MFMAs below)
     //     6 MFMAs on the second k16 step
-    //     write B(t+2) over B(t)'s stage, barrier.
-    //   The last tap of a chunk additionally swaps the footprint between its two MFMA groups; the
-    //   last tap of a tile is followed by the epilogue (stores drain behind the next tile's taps).
+    //     wait for this wave's share of B(t+2) (vmcnt counts in order: everything but this tap's own loads), barrier:
+    //     the next tap reads B(t+2) in its second half
+    //   The last tap of a chunk swaps the footprint between its two MFMA groups (two extra barriers); the last tap
+    //   of a tile is followed by the epilogue, whose stores drain behind the next tile's taps.
     constexpr int FPT = (NFV + NT - 2) / (NT - 1);   // footprint slices per tap (taps 0 .. NT-2 of a chunk)
-    const int nchunk = (p.dbg & 32) ? 0 : p.Cin / XBK;   // experiment 32: no main loop at all
+    const int nchunk = p.Cin / XBK;
 #pragma unroll
     for (int q = 0; q < NFV; ++q) fetch_fp_part(q, g.p_lo, 0);
-    fetch_b(0, 0);
+    static_assert(NT >= 3 || NT == 2, "");
+    dma_b(0, 0, 0);
+    dma_b(2 * BSTAGE, 1 % NT, (1 / NT) * XBK);
+    dma_b(4 * BSTAGE, 2 % NT, (2 / NT) * XBK);       // (a 2-tap kernel in a 1-chunk layer re-reads tap 0: harmless, never used)
     stage_fp();
-    stage_b(0);
-    fetch_b(1, 0);
-    stage_b(BN * XLD);
+    wait_vmcnt<0>();
     __syncthreads();
     Frags fa, fb;                                    // fa: first k16 step of the current tap, fb: second
     read_frags(fa, g, 0, 0, 0, 0);
-    int sA = 0, sB = BN * XLD;                       // B stage of this chunk's even / odd taps
+    int st[4] = {0, 2 * BSTAGE, 4 * BSTAGE, 6 * BSTAGE};   // byte offsets of the stages of B(t), B(t+1), B(t+2), B(t+3) at tap j = 0
 
     for (; tile < tile_end; ++tile) {
         const bool last_tile = tile + 1 == tile_end;
@@ -582,39 +604,147 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const bool has1 = j + 1 < NT || !fin;
-                const bool has2 = j + 2 < NT || !fin;
-                const int st_cur = (j & 1) ? sB : sA, st_nxt = (j & 1) ? sA : sB;
-                if (has2 && !(p.dbg & 1)) fetch_b((j + 2) % NT, (j + 2) >= NT ? nx_c0 : c0);
-                if (!fin && j < NT - 1 && !(p.dbg & 4)) {
+                const bool has3 = j + 3 < NT || !fin;
+                const int st0 = st[j % 4], st1 = st[(j + 1) % 4], st3 = st[(j + 3) % 4];   // stages of B(t), B(t+1), B(t+3)
+                // footprint slices of this tap (compile-time count: the wait below must know it exactly)
+                const int q_lo = j < NT - 1 ? (j * FPT < NFV ? j * FPT : NFV) : NFV;
+                const int q_hi = j < NT - 1 ? ((j + 1) * FPT < NFV ? (j + 1) * FPT : NFV) : NFV;
+                if (!fin) {
 #pragma unroll
-                    for (int q = j * FPT; q < (j + 1) * FPT && q < NFV; ++q) fetch_fp_part(q, nx_plo, nx_c0);
+                    for (int q = q_lo; q < q_hi; ++q) fetch_fp_part(q, nx_plo, nx_c0);
                 }
-                read_frags(fb, g, j / KW, j % KW, 1, st_cur);
+                if (has3) dma_b(st3, (j + 3) % NT, (j + 3) >= NT ? ((j + 3) >= 2 * NT ? nx_c0 + XBK : nx_c0) : c0);
+                read_frags(fb, g, j / KW, j % KW, 1, st0);
                 mfma6(fa);
-                // Every wave must have its fb reads (B(t)'s stage, this chunk's footprint) back before
-                // anyone overwrites either: B(t+2) goes into that stage at the end of this tap.
-                if (!(p.dbg & 2)) __syncthreads();
                 if (has1) {
-                    if (j == NT - 1 && !(p.dbg & 4)) {   // tap t+1 opens the next chunk: swap the footprint
+                    if (j == NT - 1) {               // tap t+1 opens the next chunk: swap the footprint.  Every wave
+                        __syncthreads();             // must have its fb reads back before anyone overwrites it
                         stage_fp();
                         __syncthreads();
                     }
-                    read_frags(fa, (j == NT - 1 && last_chunk) ? gn : g, ((j + 1) % NT) / KW, ((j + 1) % NT) % KW, 0, st_nxt);
+                    read_frags(fa, (j == NT - 1 && last_chunk) ? gn : g, ((j + 1) % NT) / KW, ((j + 1) % NT) % KW, 0, st1);
                 }
                 mfma6(fb);
-                if (has2 && !(p.dbg & 1)) stage_b(st_cur);   // B(t)'s stage: all of its fragments are in registers by now
-                // Drain vmcnt on EVERY path: otherwise hipcc cannot prove at the next tap that the registers
-                // its loads target have no load in flight, and waits for global memory in front of the MFMAs.
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
-                if (!(p.dbg & 2)) __syncthreads();
+                // B(t+1) was DMA'd during tap t-1; vmcnt counts in order, so allow exactly this tap's own VMEM
+                // operations (its footprint loads + 2 DMAs) to stay in flight.  hipcc's own waits for the footprint
+                // loads do not know about the DMAs, which only makes them stricter.
+                if (!fin) {
+                    if (q_hi - q_lo == 0) wait_vmcnt<2>();
+                    else if (q_hi - q_lo == 1) wait_vmcnt<3>();
+                    else if (q_hi - q_lo == 2) wait_vmcnt<4>();
+                    else if (q_hi - q_lo == 3) wait_vmcnt<5>();
+                    else if (q_hi - q_lo == 4) wait_vmcnt<6>();
+                    else wait_vmcnt<0>();
+                } else if (has3) {
+                    wait_vmcnt<2>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_s_barrier();
             }
-            if (NT & 1) { const int t = sA; sA = sB; sB = t; }   // odd tap count: next chunk starts on the other stage
+            // rotate the stage roles by NT taps
+            if (NT % 4 != 0) {
+                const int t0 = st[0], t1 = st[1], t2 = st[2], t3 = st[3];
+                const int r[4] = {t0, t1, t2, t3};
+                st[0] = r[NT % 4]; st[1] = r[(NT + 1) % 4]; st[2] = r[(NT + 2) % 4]; st[3] = r[(NT + 3) % 4];
+            }
         }
         epilogue_tile(p, acc0, (long long)tile * BM + wv * 32, n0 + li, lh);
         epilogue_tile(p, acc1, (long long)tile * BM + wv * 32, n0 + 32 + li, lh);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
         g = gn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// First layer on the z-normalised 68 x h log-mel window (PATCH input, Cin = 1, kh*kw <= 32), bf16x3.
+//
+// conv1 is 1.8 % of the flops but its output is the largest tensor of the net (283-333 KB per slot),
+// so the layer is bound by its stores; run through the generic kernel (table-driven scalar gathers into
+// an LDS A tile, a barrier per k-tile) it took 18 % of the step at 3.8 % MFMA-busy.  Here:
+//   * K fits ONE 32-wide k-tile, so each lane builds its own MFMA A fragments in registers -- 16 cached
+//     loads from the (T,24) log-mel (a 128-row tile touches ~11 rows of one window), (x - mean) * (1/std),
+//     bf16 hi/lo split -- no LDS A tile, no barrier at all;
+//   * the workgroup's 64 x 32 weight block (hi + lo) is loaded once into 32 VGPRs and stays there while
+//     the persistent workgroup walks its range of tiles: 12 MFMAs + the fused epilogue per tile.
+__global__ __launch_bounds__(256, 2) void conv1_patch_x3_kernel(const ConvArgs p) {
+    __shared__ int s_delta[XBK];                     // k -> ty * 24 + tx  (or -1 for the K padding)
+    __shared__ int s_tap[XBK];                       // k -> (ty << 16) | tx
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const int M = (int)p.M;
+    if (tid < XBK) {
+        const int K = p.H_k * p.kw;
+        const int ty = tid / p.kw, tx = tid - ty * p.kw;
+        s_delta[tid] = tid < K ? ty * 24 + tx : -1;
+        s_tap[tid] = (ty << 16) | tx;
+    }
+    // weight fragments of this workgroup's 64 columns: B[k][n] at lane (n = li, k = 8 lh + e), k16 step ks
+    bf16x8 b0h[2], b0l[2], b1h[2], b1l[2];
+    {
+        const int r0 = n0 + li < p.Cout ? n0 + li : 0, r1 = n0 + 32 + li < p.Cout ? n0 + 32 + li : 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            b0h[ks] = *reinterpret_cast<const bf16x8*>(p.wh + (size_t)r0 * p.Kpad + ks * 16 + lh * 8);
+            b0l[ks] = *reinterpret_cast<const bf16x8*>(p.wl + (size_t)r0 * p.Kpad + ks * 16 + lh * 8);
+            b1h[ks] = *reinterpret_cast<const bf16x8*>(p.wh + (size_t)r1 * p.Kpad + ks * 16 + lh * 8);
+            b1l[ks] = *reinterpret_cast<const bf16x8*>(p.wl + (size_t)r1 * p.Kpad + ks * 16 + lh * 8);
+        }
+    }
+    __syncthreads();
+    int dl[16], tp[16];                              // this lane's 16 k values: k = ks * 16 + lh * 8 + e
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int k = (q >> 3) * 16 + lh * 8 + (q & 7);
+        dl[q] = s_delta[k];
+        tp[q] = s_tap[k];
+    }
+    const int per = ((int)p.nblk + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tile_end = ((int)blockIdx.x + 1) * per < (int)p.nblk ? ((int)blockIdx.x + 1) * per : (int)p.nblk;
+    for (int tile = (int)blockIdx.x * per; tile < tile_end; ++tile) {
+        const int m = tile * BM + wv * 32 + li;
+        int b, oy, ox;
+        map_row32(p, m < M ? m : 0, b, oy, ox);
+        const int iy0 = oy * p.sh - p.pt_, ix0 = ox * p.sw - p.pl_;
+        const float* src = p.in + (size_t)p.win_row[b] * 24 + iy0 * 24 + ix0;
+        const float mean = p.stats[2 * b];
+        const float rsd = 1.0f / p.stats[2 * b + 1];
+        const bool live = m < M && p.finite[b];
+        float x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int iy = iy0 + (tp[q] >> 16), ix = ix0 + (tp[q] & 0xffff);
+            const bool ok = live && dl[q] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const float v = src[ok ? dl[q] : 0 - iy0 * 24 - ix0];       // row 0 of the window when masked: always mapped
+            x[q] = ok ? (v - mean) * rsd : 0.f;
+        }
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = x[ks * 8 + e];
+                const __bf16 h = (__bf16)v;
+                ah[ks][e] = h;
+                al[ks][e] = (__bf16)(v - (float)h);
+            }
+        }
+        floatx16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], b0h[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], b1h[ks], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b0l[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b1l[ks], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b0h[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b1h[ks], acc1, 0, 0, 0);
+        }
+        epilogue_tile(p, acc0, (long long)tile * BM + wv * 32, n0 + li, lh);
+        epilogue_tile(p, acc1, (long long)tile * BM + wv * 32, n0 + 32 + li, lh);
     }
 }
 
@@ -952,6 +1082,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent: 2 workgroups per CU
                 ISS_FP_SHAPES(ISS_FP_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no footprint kernel for %dx%d", a.H_k, a.kw); }
 #undef ISS_FP_CASE
+            } else if (x3 && patch && a.H_k * a.kw <= XBK && a.M < (1ll << 31)) {
+                const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent, no barriers: 2 workgroups per CU
+                hipLaunchKernelGGL(conv1_patch_x3_kernel, pgrid, dim3(256), 0, c->stream, a);
             } else if (x3) {
                 if (a.mode == 0) hipLaunchKernelGGL(conv_x3_kernel<0>, grid, dim3(256), 0, c->stream, a);
                 else if (a.mode == 1) hipLaunchKernelGGL(conv_x3_kernel<1>, grid, dim3(256), 0, c->stream, a);
