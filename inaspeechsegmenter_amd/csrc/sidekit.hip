@@ -34,6 +34,15 @@ namespace {
 __device__ __forceinline__ float sample_at(const int16_t* p, int64_t i) { return (float)p[i] * (1.0f / 32768.0f); }
 __device__ __forceinline__ float sample_at(const float* p, int64_t i) { return p[i]; }
 
+// Every wavefront owns its frame's LDS slices (y, z, spec): the stages only need the wave's own LDS writes to have
+// landed before its other lanes read them -- a wavefront-scope fence (s_waitcnt lgkmcnt(0)), not a workgroup barrier.
+// (With __syncthreads between the six stages the four waves ran in lock step: 1.0 ms per audio-hour.)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename SampleT>
 __global__ __launch_bounds__(256) void sidekit_kernel(const SampleT* __restrict__ sig, int T,
                                                       const double* __restrict__ window,
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(256) void sidekit_kernel(const SampleT* __restrict_
                 if (i < 400) y[i] = __fsub_rn(x, __fmul_rn(prev, 0.97f));
             }
         }
-        __syncthreads();
+        wave_sync();
 
         // ---- 2. log-energy in numpy's pairwise order (sidekit_mfcc.py:226) -------------------
         if (live) {
@@ -119,13 +128,13 @@ __global__ __launch_bounds__(256) void sidekit_kernel(const SampleT* __restrict_
             }
             fft256_stage0(z, lane, a, s_w256);
         }
-        __syncthreads();
+        wave_sync();
         if (live) bfly4(z, (lane >> 4) * 64, 16, lane & 15, 4, s_w256);
-        __syncthreads();
+        wave_sync();
         if (live) bfly4(z, (lane >> 2) * 16, 4, lane & 3, 16, s_w256);
-        __syncthreads();
+        wave_sync();
         if (live) bfly4(z, lane * 4, 1, 0, 0, s_w256);
-        __syncthreads();
+        wave_sync();
 
         // ---- 4. real-input untangle + power (sidekit_mfcc.py:232-233) -------------------------
         if (live) {
@@ -135,16 +144,29 @@ __global__ __launch_bounds__(256) void sidekit_kernel(const SampleT* __restrict_
                 spec[k] = (float)untangle_power(z, k, s_w512);
             }
         }
-        __syncthreads();
+        wave_sync();
 
         // ---- 5. mel bank + log (sidekit_mfcc.py:334) ----------------------------------------
         if (live && lane < 24) {
+            // up to 48 bins per filter: four independent float64 chains over 8-bin groups keep 16 LDS reads in
+            // flight instead of one dependent read+FMA per bin (this loop was the latency chain of the kernel)
             const int lo = s_lim[lane * 3], nb = s_lim[lane * 3 + 1], off = s_lim[lane * 3 + 2];
-            double acc = 0.0;
-            for (int i = 0; i < nb; ++i) acc += (double)spec[lo + i] * (double)s_melw[off + i];
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int i = 0;
+            for (; i + 8 <= nb; i += 8) {
+                float sp[8], w[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { sp[q] = spec[lo + i + q]; w[q] = s_melw[off + i + q]; }
+                a0 += (double)sp[0] * (double)w[0]; a1 += (double)sp[1] * (double)w[1];
+                a2 += (double)sp[2] * (double)w[2]; a3 += (double)sp[3] * (double)w[3];
+                a0 += (double)sp[4] * (double)w[4]; a1 += (double)sp[5] * (double)w[5];
+                a2 += (double)sp[6] * (double)w[6]; a3 += (double)sp[7] * (double)w[7];
+            }
+            for (; i < nb; ++i) a0 += (double)spec[lo + i] * (double)s_melw[off + i];
+            const double acc = (a0 + a1) + (a2 + a3);
             mspec[(size_t)t * 24 + lane] = (float)log((double)(float)acc);
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 

@@ -19,6 +19,13 @@
 
 namespace {
 
+// wavefront-scope LDS hand-off (see sidekit.hip): each wave owns its frame's LDS slices
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double seg_at(const int32_t* __restrict__ sig, const double* __restrict__ u, int64_t n,
                                          int64_t j) {
     // seg = r_[x[119::-1], x, x[-1:-201:-1]]  with x = sig + 8*(u*2-1)
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(256) void vbx_fbank_kernel(const int32_t* __restric
             const int64_t s0 = (int64_t)t * 160;
             for (int i = lane; i < 400; i += 64) x[i] = seg_at(sig, u, n, s0 + i);
         }
-        __syncthreads();
+        wave_sync();
         // frame mean, numpy pairwise order (features_vbx.py:100-101)
         double mean = 0.0;
         if (live) {
@@ -99,13 +106,13 @@ __global__ __launch_bounds__(256) void vbx_fbank_kernel(const int32_t* __restric
             }
             fft256_stage0(z, lane, a, s_w256);
         }
-        __syncthreads();
+        wave_sync();
         if (live) bfly4(z, (lane >> 4) * 64, 16, lane & 15, 4, s_w256);
-        __syncthreads();
+        wave_sync();
         if (live) bfly4(z, (lane >> 2) * 16, 4, lane & 3, 16, s_w256);
-        __syncthreads();
+        wave_sync();
         if (live) bfly4(z, lane * 4, 1, 0, 0, s_w256);
-        __syncthreads();
+        wave_sync();
         if (live) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -113,14 +120,14 @@ __global__ __launch_bounds__(256) void vbx_fbank_kernel(const int32_t* __restric
                 spec[k] = untangle_power(z, k, s_w512);
             }
         }
-        __syncthreads();
+        wave_sync();
         if (live) {   // lane = mel channel (64 of them), features_vbx.py:113
             const int lo = s_lim[lane * 3], nb = s_lim[lane * 3 + 1], off = s_lim[lane * 3 + 2];
             double acc = 0.0;
             for (int i = 0; i < nb; ++i) acc += spec[lo + i] * s_melw[off + i];
             fb[(size_t)t * 64 + lane] = log(fmax(1.0, acc));
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 

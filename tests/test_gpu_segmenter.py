@@ -127,3 +127,24 @@ def test_cli_end_to_end(tmp_path):
     rows = _csv_rows(str(tmp_path / 'musanmix.csv'))
     gold = _csv_rows(os.path.join(GOLDEN, 'musanmix-smn-gender.csv'))
     assert [(s, e) for l, s, e in rows if l == 'noEnergy'] == [(s, e) for l, s, e in gold if l == 'noEnergy']
+
+
+def test_batch_process_many_files_equals_single_calls(seg, tmp_path):
+    """configs[2] shape at test scale: several 1-minute WAV files through batch_process (decode thread, H2D,
+    device, Viterbi, CSV) give byte-identical CSVs to per-file __call__ + seg2csv."""
+    import struct
+    lin, lout = [], []
+    for i in range(5):
+        pcm = synth_pcm(100 + i, 16000 * 60 + 37 * i)
+        p = tmp_path / f'in{i}.wav'
+        with open(p, 'wb') as f:
+            f.write(b'RIFF' + struct.pack('<I', 36 + pcm.nbytes) + b'WAVEfmt ' + struct.pack('<IHHIIHH', 16, 1, 1, 16000, 32000, 2, 16)
+                    + b'data' + struct.pack('<I', pcm.nbytes) + pcm.tobytes())
+        lin.append(str(p))
+        lout.append(str(tmp_path / f'out{i}.csv'))
+    t, nb, avg, lmsg = seg.batch_process(lin, lout)
+    assert nb == 5 and all(m[1] == 0 for m in lmsg)
+    for src, dst in zip(lin, lout):
+        ref = str(tmp_path / 'ref.csv')
+        seg2csv(seg(src), ref)
+        assert filecmp.cmp(dst, ref, shallow=False), src
