@@ -538,7 +538,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     const int b0s = swz(li, 0), b1s = swz(li + 32, 0);                   // chunk-0 slots of this lane's two weight rows
     const int bx = (li >> 2) & 3;                                        // their swizzle key (same for li and li + 32)
     auto read_frags = [&](Frags& f, const Geom& gg, int ky, int kx, int ks, int stage_off) {
-        const int pix = gg.lanepix + ky * p.W + kx;
+        // opaque copy: without it hipcc hoists the 2 x KH x KW swizzled A addresses (they only depend on the tile)
+        // out of the chunk loop and keeps them live in 18-30 VGPRs; recomputing costs ~5 VALU per address
+        int lp = gg.lanepix;
+        asm volatile("" : "+v"(lp));
+        const int pix = lp + ky * p.W + kx;
         const int lc = ks * 2 + lh;
         const int aoff = swz(pix, lc) * 8;                               // bf16 units
         f.ah = *reinterpret_cast<const bf16x8*>(&sFh[aoff]);
