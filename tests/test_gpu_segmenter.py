@@ -148,3 +148,18 @@ def test_batch_process_many_files_equals_single_calls(seg, tmp_path):
         ref = str(tmp_path / 'ref.csv')
         seg2csv(seg(src), ref)
         assert filecmp.cmp(dst, ref, shallow=False), src
+
+
+def test_device_resident_pcm_entry_equals_host_path(seg):
+    """bench.py's entry (PCM16 already in HBM, slot-unit result, dense evaluation) == the host-signal path."""
+    import torch
+    pcm = synth_pcm(321, 16000 * 90 + 11)
+    t = torch.from_numpy(pcm).cuda()
+    torch.cuda.synchronize()
+    slots_dense = seg.segment_device_pcm(t.data_ptr(), t.numel(), dense=True)
+    slots_ref = seg.segment_device_pcm(t.data_ptr(), t.numel(), dense=False)
+    host = seg.segment_signal(pcm)
+    assert slots_dense == slots_ref
+    assert [(l, a * .02, b * .02) for l, a, b in slots_ref] == host
+    with pytest.raises(ValueError):
+        seg.segment_device_pcm(t.data_ptr(), 400 + 160 * 60)          # < 68 frames: use segment_signal
