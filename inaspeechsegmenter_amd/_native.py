@@ -38,6 +38,13 @@ def lib():
             f"{LIB_PATH} is missing: the HIP extension has not been built. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "There is no CPU fallback for the feature/CNN path.")
+    # PyTorch-ROCm ships its own HIP runtime (libamdhip64 with the same SONAME as /opt/rocm's).  Two HIP runtimes
+    # in one process do not both see the GPU ("No HIP GPUs are available" in whichever initialises second), so make
+    # the order deterministic: if torch is installed, let it load its runtime first and bind to that one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
     pf, pd, pi32, pi64, pu8, pi16 = (C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32),

@@ -68,3 +68,41 @@ def segment_archive(segment_file, linput, loutput=None, output_format='csv', siz
     else:
         allrows = local
     return sharding.unpack_segments(allrows), lmsg
+
+
+class JobList:
+    """The job-table half of the reference's Pyro job server (scripts/ina_speech_segmenter_pyro_server.py:34-68,
+    pinned by run_test.py:166-172) without the RPC layer: a CSV with columns `source_path, dest_path` is
+    stripped, de-duplicated and shuffled, and handed out in chunks of `nbjobs` (20 by default).  On one node the
+    chunks feed `segment_archive`; the Pyro daemon itself (network job dispatch) is out of scope."""
+
+    def __init__(self, csvjobs, shuffle=True, seed=None):
+        self.set_jobs(csvjobs, shuffle, seed)
+
+    def set_jobs(self, csvjobs, shuffle=True, seed=None):
+        import pandas as pd
+        df = pd.read_csv(csvjobs)
+        df.source_path = df.source_path.str.strip()
+        df.dest_path = df.dest_path.str.strip()
+        df = df.drop_duplicates()
+        if shuffle:
+            df = df.sample(frac=1, random_state=seed)
+        df = df.reset_index(drop=True)
+        self.lsource = list(df.source_path)
+        self.ldest = list(df.dest_path)
+        self.i = 0
+        return '%s jobs have been set' % csvjobs
+
+    def get_job(self, msg=''):
+        self.i += 1
+        return (self.lsource.pop(0), self.ldest.pop(0))
+
+    def get_njobs(self, msg='', nbjobs=20):
+        ret = (self.lsource[:nbjobs], self.ldest[:nbjobs])
+        self.lsource = self.lsource[nbjobs:]
+        self.ldest = self.ldest[nbjobs:]
+        self.i += nbjobs
+        return ret
+
+    def has_more_jobs(self):
+        return len(self.lsource) > 0

@@ -118,8 +118,10 @@ def layers_from_keras_config(model_config, weights):
             raise NotImplementedError(f"Keras layer {cn!r} ({name}) is not supported by the op program")
     if in_shape is None:
         raise ValueError("model_config carries no batch_input_shape")
+    if len(in_shape) == 1:                          # plain MLP on feature vectors (e.g. the x-vector gender model)
+        in_shape = (1, 1, in_shape[0])
     if len(in_shape) != 3:
-        raise NotImplementedError(f"input shape {in_shape}: need (H, W, C)")
+        raise NotImplementedError(f"input shape {in_shape}: need (H, W, C) or (C,)")
     return layers, in_shape
 
 

@@ -1,0 +1,165 @@
+"""Voice femininity scoring on top of the MI355X kernels: host mirror of vbx_segmenter.VoiceFemininityScoring
+(vbx_segmenter.py:92-202) -- SURVEY.md 8(f) item 3.
+
+Pipeline (same order as the reference's __call__, :147-202): decode -> smn VAD (Segmenter, no gender) ->
+get_features (csrc/vbx.hip) -> ResNet-101 x-vectors on every 144-frame window (engine, batched) -> keep the
+x-vectors whose midpoint lies in speech and that overlap speech by >= vad_thresh (:129-145, 28-52) -> gender MLP
+(a Keras Dense stack, run on the same engine) -> share of windows with p >= 0.5 (:55-61).
+
+The reference does the interval arithmetic with pyannote.core (Annotation / Timeline.crop); speech segments coming
+out of the segmenter are disjoint, so plain interval intersection gives the same numbers.  PARITY UNPINNED: the only
+reference test of this tail (run_test.py:177-187, score 0.534884 on lamartine.wav) needs the un-vendored weights
+(final.onnx / raw_81.pth, interspeech2023_*.hdf5); tests here check the host logic against a literal restatement.
+Known divergence: add_needed_vectors (:40-52) reads `s.stop` on a pyannote Segment, which has no such attribute --
+the branch would raise in the reference; here it does what the code evidently intends (append (key, (start, end), x)).
+"""
+import os
+
+import numpy as np
+
+from . import _native, keras_model
+from .io import media2sig16kmono
+from .segmenter import Segmenter, locate_model
+from .vbx import FeatureExtractor, VBxExtractor, SR
+
+_MLP_NET = 3          # engine net id of the gender MLP (0/1: VAD / gender CNNs, 4..: ResNet programs)
+
+
+def speech_intervals(vad_tuples):
+    """get_annot_VAD (vbx_segmenter.py:64-69): the 'speech' segments."""
+    return [(float(s), float(e)) for lab, s, e in vad_tuples if lab == 'speech']
+
+
+def is_mid_speech(start, stop, speech):
+    """vbx_segmenter.py:28-37: midpoint strictly inside a speech segment."""
+    m = (start + stop) / 2
+    return any(s < m < e for s, e in speech)
+
+
+def overlap_ratio(start, stop, speech):
+    """Timeline([Segment(start, stop)]).crop(vad.get_timeline()).duration() / (stop - start)  (:138-140)."""
+    ov = sum(max(0.0, min(stop, e) - max(start, s)) for s, e in speech)
+    return ov / (stop - start)
+
+
+def add_needed_vectors(xvectors, t_mid):
+    """vbx_segmenter.py:40-52: keep at least round(50 %) of the mid-in-speech predictions, best overlap first."""
+    min_pred = round(0.5 * len(t_mid))
+    if len(xvectors) < min_pred:
+        order = np.argsort(np.asarray([t[0] for t in t_mid], dtype=np.float64))[::-1]
+        ranked = [t_mid[i] for i in order]
+        diff = min_pred - len(xvectors)
+        for _, k, (s, e), x in ranked[len(xvectors):len(xvectors) + diff]:
+            xvectors.append((k, (s, e), x))
+    return xvectors
+
+
+def apply_vad(xvectors, speech, vad_thresh):
+    """vbx_segmenter.py:129-145."""
+    midpoint_seg, kept = [], []
+    for key, (start, stop), x in xvectors:
+        if is_mid_speech(start, stop, speech):
+            r = overlap_ratio(start, stop, speech)
+            if r >= vad_thresh:
+                kept.append((key, (start, stop), x))
+            midpoint_seg.append((r, key, (start, stop), x))
+    return add_needed_vectors(kept, midpoint_seg)
+
+
+def get_femininity_score(g_preds):
+    """vbx_segmenter.py:55-61: an Annotation keyed by Segment(start, stop) keeps ONE entry per distinct segment
+    (a later prediction on the same segment replaces the earlier one); score = #(p >= 0.5) / #segments."""
+    seen = {}
+    for start, stop, p in g_preds:
+        seen[(float(start), float(stop))] = bool(p >= 0.5)
+    return sum(seen.values()) / len(seen)
+
+
+def _load_resnet_params(path):
+    """raw_81.pth (the torch checkpoint behind the reference's commented TorchBackendExtractor, :268-288)."""
+    import torch
+    ck = torch.load(path, map_location='cpu')
+    sd = ck.get('state_dict', ck)
+    return {k: v.numpy() for k, v in sd.items() if hasattr(v, 'numpy')}
+
+
+class VoiceFemininityScoring:
+    def __init__(self, gd_model_criteria='bgc', backend='onnx', ffmpeg='ffmpeg', device=0, models=None):
+        """gd_model_criteria / backend: as vbx_segmenter.py:97-127.  models: None -> files from the
+        remote_utils search path (raw_81.pth for the x-vector net: the ONNX graph itself is not parsed here);
+        'synthetic' -> seeded stand-ins; or a dict {'resnet': state_dict-like, 'mlp': (layers, in_shape)}."""
+        assert backend in ['onnx'], "Backend should be 'onnx' (or 'pytorch' if uncommented)."
+        assert gd_model_criteria in ['bgc', 'vfp'], "Gender detection model Criteria must be 'bgc' (default) or 'vfp'"
+        gd_model, self.vad_thresh = ('interspeech2023_all.hdf5', 0.7) if gd_model_criteria == 'bgc' else ('interspeech2023_cvfr.hdf5', 0.62)
+        self.ffmpeg = ffmpeg
+        self.vad = Segmenter(vad_engine='smn', detect_gender=False, ffmpeg=ffmpeg, device=device,
+                             models='synthetic' if models == 'synthetic' else None)
+        self.ctx = self.vad.ctx
+        if models == 'synthetic':
+            rng = np.random.default_rng(23)
+            resnet = _synthetic_resnet()
+            mlp = ([dict(type='dense', W=rng.normal(0, 0.1, (256, 64)).astype(np.float32), b=np.zeros(64, np.float32), activation='relu'),
+                    dict(type='dense', W=rng.normal(0, 0.3, (64, 1)).astype(np.float32), b=np.zeros(1, np.float32), activation='sigmoid')],
+                   (1, 1, 256))
+        elif isinstance(models, dict):
+            resnet, mlp = models['resnet'], models['mlp']
+        else:
+            resnet = _load_resnet_params(locate_model('raw_81.pth'))
+            mlp = keras_model.load_model_file(locate_model(gd_model))
+        self.features = FeatureExtractor(self.ctx)
+        self.xvector_model = VBxExtractor(self.ctx, resnet)
+        layers, in_shape = mlp
+        if len(in_shape) == 1:
+            in_shape = (1, 1, in_shape[0])
+        self.ctx.cnn_load(_MLP_NET, keras_model.compile_layers(layers, in_shape, patch_input=False))
+
+    def gender_predict(self, x):
+        x = np.asarray(x, dtype=np.float32)
+        return self.ctx.cnn_forward(_MLP_NET, x.reshape(len(x), 1, 1, -1))
+
+    def __call__(self, fpath):
+        """-> (score, speech_duration, nb_vectors)  (vbx_segmenter.py:147-202)."""
+        basename = os.path.splitext(os.path.basename(fpath))[0]
+        signal = media2sig16kmono(fpath, ffmpeg=self.ffmpeg, dtype='float64')
+        duration = len(signal) / SR
+        speech = speech_intervals(self.vad(fpath))
+        speech_duration = sum(e - s for s, e in speech)
+        if not speech_duration:
+            return None, speech_duration, 0
+        feats = self.features(signal)
+        x_vectors = self.xvector_model(basename, feats, duration)
+        x_vectors = apply_vad(x_vectors, speech, self.vad_thresh)
+        pred = self.gender_predict(np.asarray([x for _, _, x in x_vectors])).reshape(len(x_vectors), -1)[:, 0]
+        g = [(seg[0], seg[1], p) for (_, seg, _), p in zip(x_vectors, pred)]
+        return get_femininity_score(g), speech_duration, len(g)
+
+
+def _synthetic_resnet(seed=0):
+    """Seeded, numerically tame ResNet-101 parameters keyed like resnet.py's state_dict (test / bench stand-in)."""
+    rng = np.random.default_rng(seed)
+    params = {}
+
+    def conv(name, cout, cin, k):
+        params[name + '.weight'] = rng.normal(0, np.sqrt(1.0 / (cin * k * k)), (cout, cin, k, k)).astype(np.float32)
+
+    def bn(name, c):
+        params[name + '.weight'] = rng.uniform(0.8, 1.2, c).astype(np.float32)
+        params[name + '.bias'] = rng.normal(0, 0.1, c).astype(np.float32)
+        params[name + '.running_mean'] = rng.normal(0, 0.1, c).astype(np.float32)
+        params[name + '.running_var'] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+
+    m = 32
+    conv('conv1', m, 1, 3); bn('bn1', m)
+    inp = m
+    for li, (planes, nblocks, stride) in enumerate(zip((m, 2 * m, 4 * m, 8 * m), (3, 4, 23, 3), (1, 2, 2, 2)), 1):
+        for bi in range(nblocks):
+            p = f'layer{li}.{bi}'
+            conv(p + '.conv1', planes, inp, 1); bn(p + '.bn1', planes)
+            conv(p + '.conv2', planes, planes, 3); bn(p + '.bn2', planes)
+            conv(p + '.conv3', 4 * planes, planes, 1); bn(p + '.bn3', 4 * planes)
+            if (stride if bi == 0 else 1) != 1 or inp != 4 * planes:
+                conv(p + '.shortcut.0', 4 * planes, inp, 1); bn(p + '.shortcut.1', 4 * planes)
+            inp = 4 * planes
+    params['embedding.weight'] = rng.normal(0, np.sqrt(1.0 / 16384), (256, 16384)).astype(np.float32)
+    params['embedding.bias'] = rng.normal(0, 0.05, 256).astype(np.float32)
+    return params

@@ -92,3 +92,20 @@ def test_cli_flags_match_reference():
     d = cli.build_parser().parse_args(['-i', 'x', '-o', 'y'])
     assert (d.vad_engine, d.detect_gender, d.ffmpeg_binary, d.export_format, d.energy_ratio, d.batch_size) == \
         ('smn', True, 'ffmpeg', 'csv', 0.03, 32)
+
+
+def test_joblist_matches_reference_server_semantics():
+    """run_test.py:166-172 test_pyroserver on the reference's own fixture (media/pyroserver_test.csv)."""
+    from conftest import GOLDEN
+    gs = archive.JobList(os.path.join(GOLDEN, 'pyroserver_test.csv'))
+    assert gs.has_more_jobs()
+    lsrc, ldst = gs.get_njobs('')
+    assert len(lsrc) == 7 and len(ldst) == 7
+    assert sorted(lsrc) == ['/my_/source_4', 'my_source_1', 'my_source_2', 'my_source_3', 'my_source_5', 'my_source_6', 'my_source_7']
+    assert sorted(ldst) == ['my_dest_1', 'my_dest_2', 'my_dest_3', 'my_dest_4', 'my_dest_5', 'my_dest_6', 'my_dest_7@@@!!']
+    assert not gs.has_more_jobs() and gs.get_njobs('') == ([], [])
+    a = archive.JobList(os.path.join(GOLDEN, 'pyroserver_test.csv'), seed=1)
+    b = archive.JobList(os.path.join(GOLDEN, 'pyroserver_test.csv'), seed=1)
+    assert a.lsource == b.lsource and a.get_njobs('', 3)[0] == b.lsource[:3] and a.has_more_jobs()
+    pairs = dict(zip(*archive.JobList(os.path.join(GOLDEN, 'pyroserver_test.csv'), shuffle=False).get_njobs('')))
+    assert pairs['my_source_1'] == 'my_dest_1' and pairs['/my_/source_4'] == 'my_dest_4'
