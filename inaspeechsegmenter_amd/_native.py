@@ -71,6 +71,9 @@ def lib():
         'iss_set_precision': (C.c_int, [vp, C.c_int]),
         'iss_vbx_tables': (C.c_int, [vp, pd, pd]),
         'iss_vbx_features': (C.c_int, [vp, pi32, pd, i64, pf, pi32]),
+        'iss_vbx_set_dither': (C.c_int, [vp, pd, i64]),
+        'iss_vbx_features_pcm16': (C.c_int, [vp, pi16, i64, pf, pi32]),
+        'iss_vbx_embed': (C.c_int, [vp, C.c_int, pi32, i32, pf]),
         'iss_prof_enable': (C.c_int, [vp, C.c_int]),
         'iss_prof_get': (C.c_int, [vp, C.c_int, pd, pi64, pd]),
         'iss_prof_reset': (C.c_int, [vp]),
@@ -123,6 +126,7 @@ class Context:
         self.device = device
         self.T = 0
         self._net_out = {}
+        self._dither_n = 0          # length of the dither stream cached on the device (vbx)
 
     def close(self):
         if getattr(self, '_h', None):
@@ -241,7 +245,29 @@ class Context:
         t = C.c_int32()
         self._ck(self._L.iss_vbx_features(self._h, _ptr(s, C.c_int32), _ptr(u, C.c_double), s.size,
                                           _ptr(out, C.c_float), C.byref(t)), 'iss_vbx_features')
+        self._dither_n = 0          # this entry uploads its own stream over the cached one
         assert t.value == T
+        return out
+
+    def vbx_set_dither(self, dither_u):
+        u = np.ascontiguousarray(dither_u, dtype=np.float64)
+        self._ck(self._L.iss_vbx_set_dither(self._h, _ptr(u, C.c_double), u.size), 'iss_vbx_set_dither')
+        self._dither_n = u.size
+
+    def vbx_features_pcm16(self, pcm):
+        s = np.ascontiguousarray(pcm, dtype=np.int16)
+        T = (s.size + 320 - 400) // 160 + 1
+        out = np.empty((T, 64), dtype=np.float32)
+        t = C.c_int32()
+        self._ck(self._L.iss_vbx_features_pcm16(self._h, _ptr(s, C.c_int16), s.size, _ptr(out, C.c_float), C.byref(t)),
+                 'iss_vbx_features_pcm16')
+        assert t.value == T
+        return out
+
+    def vbx_embed(self, net_id, starts):
+        st = np.ascontiguousarray(starts, dtype=np.int32)
+        out = np.empty((st.size, self._net_out[net_id]), dtype=np.float32)
+        self._ck(self._L.iss_vbx_embed(self._h, net_id, _ptr(st, C.c_int32), st.size, _ptr(out, C.c_float)), 'iss_vbx_embed')
         return out
 
     # ---- profiling

@@ -178,6 +178,8 @@ __device__ __forceinline__ RowSrc row_source(const ConvArgs& p, long long m) {
         r.mean = p.stats[2 * b];
         r.sd = p.stats[2 * b + 1];
         r.ok = r.ok && p.finite[b];
+    } else if (MODE == 1 && p.win_row) {             // window of the resident vbx features: frame (start + ix), feature iy
+        r.base = ((long long)p.win_row[b] + r.ix0) * p.pix_stride + (long long)r.iy0 * p.row_stride;
     } else {
         r.base = (long long)b * p.img_stride + (long long)r.iy0 * p.row_stride + (long long)r.ix0 * p.pix_stride;
     }
@@ -924,8 +926,11 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
             if (fph * fpw > 1 && (R[ISS_C_RES] >= 0 || R[ISS_C_HO] / fph < 1 || R[ISS_C_WO] / fpw < 1))
                 return bad("fused pool with residual / empty pooled output");
             const bool patch = R[ISS_C_INMODE] == 1;
+            const bool window = R[ISS_C_INMODE] == 2;      // (H = features, W = frames) view of the resident (T, H) vbx features
             if (patch && (R[ISS_C_CIN] != 1 || R[ISS_C_H] != 68 || R[ISS_C_W] > 24)) return bad("patch-mode conv must read (68, <=24, 1)");
-            const int rs = patch ? 24 : R[ISS_C_W] * R[ISS_C_CIN], ps = patch ? 1 : R[ISS_C_CIN];
+            if (window && (R[ISS_C_CIN] != 1 || R[ISS_C_H] != 64)) return bad("window-mode conv must read (64, frames, 1)");
+            const int rs = patch ? 24 : (window ? 1 : R[ISS_C_W] * R[ISS_C_CIN]);
+            const int ps = patch ? 1 : (window ? R[ISS_C_H] : R[ISS_C_CIN]);
             n.kpad[r] = Kpad; n.ktab_off[r] = (int64_t)ktab.size();
             for (int k = 0; k < Kpad; ++k) {
                 if (k < K) {
@@ -1054,10 +1059,16 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const bool patch = R[ISS_C_INMODE] == 1;
             const bool x3 = c->precision == ISS_PREC_BF16X3;
             a.mode = patch ? 2 : ((a.Cin % (x3 ? XBK : 4) == 0) ? 0 : 1);
+            const bool window = R[ISS_C_INMODE] == 2;
             if (patch) {
                 if (!d_winrow) return iss_fail(c, ISS_ESTATE, "patch-mode network run without a window list");
                 a.in = (const float*)c->mspec.p; a.win_row = d_winrow; a.stats = d_stats; a.finite = d_fin;
                 a.row_stride = 24; a.pix_stride = 1; a.img_stride = 0;
+            } else if (window) {
+                if (!d_winrow || !c->vbx_out.p) return iss_fail(c, ISS_ESTATE, "window-mode network run without resident vbx features");
+                a.in = (const float*)c->vbx_out.p; a.win_row = d_winrow;
+                a.row_stride = 1; a.pix_stride = a.H; a.img_stride = 0;
+                a.mode = 1;
             } else {
                 if (!in) return iss_fail(c, ISS_ESTATE, "network input missing");
                 a.row_stride = a.W * a.Cin; a.pix_stride = a.Cin; a.img_stride = (long long)a.H * a.W * a.Cin;
@@ -1217,6 +1228,40 @@ extern "C" int iss_cnn_forward(iss_ctx* c, int id, const float* x, int32_t nsamp
                                   hipMemcpyDeviceToDevice, c->stream));
     }
     ISS_HIP(c, hipMemcpyAsync(out, c->d_out.p, (size_t)nsamp * n.out_dim * 4, hipMemcpyDeviceToHost, c->stream));
+    ISS_HIP(c, hipStreamSynchronize(c->stream));
+    iss_prof_collect(c);
+    return ISS_OK;
+}
+
+extern "C" int iss_vbx_embed(iss_ctx* c, int id, const int32_t* starts, int32_t nwin, float* out) {
+    if (!c) return ISS_EINVAL;
+    if (id < 0 || id >= ISS_MAX_NETS || nwin < 0 || (nwin > 0 && (!starts || !out)))
+        return iss_fail(c, ISS_EINVAL, "iss_vbx_embed: bad argument");
+    IssNet& n = c->nets[id];
+    if (!n.loaded) return iss_fail(c, ISS_ESTATE, "iss_vbx_embed: net %d not loaded", id);
+    if (n.prog[ISS_C_OP] != ISS_OP_CONV || n.prog[ISS_C_INMODE] != 2)
+        return iss_fail(c, ISS_EINVAL, "iss_vbx_embed: net %d does not start with a window-mode conv", id);
+    if (c->vbx_T <= 0) return iss_fail(c, ISS_ESTATE, "iss_vbx_embed: no vbx features resident (iss_vbx_features*)");
+    if (nwin == 0) return ISS_OK;
+    for (int i = 0; i < nwin; ++i)
+        if (starts[i] < 0 || starts[i] + n.in_w > c->vbx_T)
+            return iss_fail(c, ISS_EINVAL, "iss_vbx_embed: window %d (frames %d..%d) outside the %d resident frames", i, starts[i],
+                            starts[i] + n.in_w, c->vbx_T);
+    ISS_HIP(c, hipSetDevice(c->device));
+    int rc, bc = 0;
+    if ((rc = iss_reserve(c, c->d_winrow, (size_t)nwin * 4))) return rc;
+    if ((rc = iss_reserve(c, c->d_out, (size_t)nwin * n.out_dim * 4))) return rc;
+    if ((rc = plan_chunk(c, n, nwin, &bc))) return rc;
+    ISS_HIP(c, hipMemcpyAsync(c->d_winrow.p, starts, (size_t)nwin * 4, hipMemcpyHostToDevice, c->stream));
+    for (int s0 = 0; s0 < nwin; s0 += bc) {
+        const int cur = std::min(bc, nwin - s0);
+        float* res = nullptr;
+        rc = run_program(c, n, cur, (const int32_t*)c->d_winrow.p + s0, nullptr, nullptr, nullptr, &res);
+        if (rc) return rc;
+        ISS_HIP(c, hipMemcpyAsync((float*)c->d_out.p + (size_t)s0 * n.out_dim, res, (size_t)cur * n.out_dim * 4,
+                                  hipMemcpyDeviceToDevice, c->stream));
+    }
+    ISS_HIP(c, hipMemcpyAsync(out, c->d_out.p, (size_t)nwin * n.out_dim * 4, hipMemcpyDeviceToHost, c->stream));
     ISS_HIP(c, hipStreamSynchronize(c->stream));
     iss_prof_collect(c);
     return ISS_OK;

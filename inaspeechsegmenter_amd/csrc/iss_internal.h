@@ -72,6 +72,7 @@ struct iss_ctx {
     int32_t* d_vbx_mellim = nullptr;
     DevBuf vbx_sig, vbx_dither, vbx_fb, vbx_out;
     int32_t vbx_T = 0;
+    int64_t vbx_dither_n = 0;              // length of the dither stream cached in vbx_dither (0 = none)
 
     // profiling
     bool prof = false;

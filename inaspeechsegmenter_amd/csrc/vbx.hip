@@ -26,7 +26,8 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ double seg_at(const int32_t* __restrict__ sig, const double* __restrict__ u, int64_t n,
+template <typename SampleT>
+__device__ __forceinline__ double seg_at(const SampleT* __restrict__ sig, const double* __restrict__ u, int64_t n,
                                          int64_t j) {
     // seg = r_[x[119::-1], x, x[-1:-201:-1]]  with x = sig + 8*(u*2-1)
     int64_t i = j < 120 ? 119 - j : (j < 120 + n ? j - 120 : n - 1 - (j - 120 - n));
@@ -34,7 +35,8 @@ __device__ __forceinline__ double seg_at(const int32_t* __restrict__ sig, const 
     return __dadd_rn((double)sig[i], d);
 }
 
-__global__ __launch_bounds__(256) void vbx_fbank_kernel(const int32_t* __restrict__ sig, const double* __restrict__ u,
+template <typename SampleT>
+__global__ __launch_bounds__(256) void vbx_fbank_kernel(const SampleT* __restrict__ sig, const double* __restrict__ u,
                                                         int64_t n, int T, const double* __restrict__ window,
                                                         const double* __restrict__ tw, const double* __restrict__ melw,
                                                         const int32_t* __restrict__ mellim, double* __restrict__ fb) {
@@ -191,27 +193,23 @@ extern "C" int iss_vbx_tables(iss_ctx* c, const double* window400, const double*
     return ISS_OK;
 }
 
-extern "C" int iss_vbx_features(iss_ctx* c, const int32_t* sig, const double* u, int64_t n, float* out, int32_t* T_out) {
-    if (!c || !sig || !u || n < 200) return iss_fail(c, ISS_EINVAL, "iss_vbx_features: bad argument (need n >= 200)");
-    if (!c->vbx_tables) return iss_fail(c, ISS_ESTATE, "iss_vbx_features: call iss_vbx_tables first");
-    ISS_HIP(c, hipSetDevice(c->device));
+namespace {
+// common tail: signal (int32 or int16, already on the device) + dither stream (device) -> resident (T,64) float32
+template <typename SampleT>
+int vbx_run(iss_ctx* c, const SampleT* d_sig, const double* d_u, int64_t n, float* out, int32_t* T_out) {
     const int64_t T64 = (n + 320 - 400) / 160 + 1;
     if (T64 <= 0 || T64 > (1 << 26)) return iss_fail(c, ISS_EINVAL, "iss_vbx_features: unsupported length");
     const int T = (int)T64;
     int rc;
-    if ((rc = iss_reserve(c, c->vbx_sig, (size_t)n * 4))) return rc;
-    if ((rc = iss_reserve(c, c->vbx_dither, (size_t)n * 8))) return rc;
     if ((rc = iss_reserve(c, c->vbx_fb, (size_t)(2 * T + 1) * 64 * 8))) return rc;
     if ((rc = iss_reserve(c, c->vbx_out, (size_t)T * 64 * 4))) return rc;
-    ISS_HIP(c, hipMemcpyAsync(c->vbx_sig.p, sig, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    ISS_HIP(c, hipMemcpyAsync(c->vbx_dither.p, u, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
     double* fb = (double*)c->vbx_fb.p;
     double* f = fb + (size_t)T * 64;
     int blocks = (T + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     iss_prof_begin(c, 1, 0.0);
-    hipLaunchKernelGGL(vbx_fbank_kernel, dim3(blocks), dim3(256), 0, c->stream, (const int32_t*)c->vbx_sig.p,
-                       (const double*)c->vbx_dither.p, n, T, c->d_vbx_window, c->d_tw, c->d_vbx_melw, c->d_vbx_mellim, fb);
+    hipLaunchKernelGGL(vbx_fbank_kernel<SampleT>, dim3(blocks), dim3(256), 0, c->stream, d_sig, d_u, n, T, c->d_vbx_window,
+                       c->d_tw, c->d_vbx_melw, c->d_vbx_mellim, fb);
     iss_prof_end(c);
     iss_prof_begin(c, 2, 0.0);
     hipLaunchKernelGGL(vbx_cumsum_kernel, dim3(1), dim3(64), 0, c->stream, fb, T, f);
@@ -226,4 +224,42 @@ extern "C" int iss_vbx_features(iss_ctx* c, const int32_t* sig, const double* u,
     c->vbx_T = T;
     if (T_out) *T_out = T;
     return ISS_OK;
+}
+}  // namespace
+
+extern "C" int iss_vbx_features(iss_ctx* c, const int32_t* sig, const double* u, int64_t n, float* out, int32_t* T_out) {
+    if (!c || !sig || !u || n < 200) return iss_fail(c, ISS_EINVAL, "iss_vbx_features: bad argument (need n >= 200)");
+    if (!c->vbx_tables) return iss_fail(c, ISS_ESTATE, "iss_vbx_features: call iss_vbx_tables first");
+    ISS_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = iss_reserve(c, c->vbx_sig, (size_t)n * 4))) return rc;
+    if ((rc = iss_reserve(c, c->vbx_dither, (size_t)n * 8))) return rc;
+    ISS_HIP(c, hipMemcpyAsync(c->vbx_sig.p, sig, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    ISS_HIP(c, hipMemcpyAsync(c->vbx_dither.p, u, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    c->vbx_dither_n = 0;                              // the cached stream (iss_vbx_set_dither) was overwritten
+    return vbx_run<int32_t>(c, (const int32_t*)c->vbx_sig.p, (const double*)c->vbx_dither.p, n, out, T_out);
+}
+
+extern "C" int iss_vbx_set_dither(iss_ctx* c, const double* u, int64_t n) {
+    if (!c || !u || n <= 0) return iss_fail(c, ISS_EINVAL, "iss_vbx_set_dither: bad argument");
+    ISS_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = iss_reserve(c, c->vbx_dither, (size_t)n * 8))) return rc;
+    ISS_HIP(c, hipMemcpyAsync(c->vbx_dither.p, u, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    ISS_HIP(c, hipStreamSynchronize(c->stream));
+    c->vbx_dither_n = n;
+    return ISS_OK;
+}
+
+extern "C" int iss_vbx_features_pcm16(iss_ctx* c, const int16_t* pcm, int64_t n, float* out, int32_t* T_out) {
+    if (!c || !pcm || n < 200) return iss_fail(c, ISS_EINVAL, "iss_vbx_features_pcm16: bad argument (need n >= 200)");
+    if (!c->vbx_tables) return iss_fail(c, ISS_ESTATE, "iss_vbx_features_pcm16: call iss_vbx_tables first");
+    if (c->vbx_dither_n < n)
+        return iss_fail(c, ISS_ESTATE, "iss_vbx_features_pcm16: cached dither stream holds %lld values, need %lld (iss_vbx_set_dither)",
+                        (long long)c->vbx_dither_n, (long long)n);
+    ISS_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = iss_reserve(c, c->vbx_sig, (size_t)n * 2))) return rc;
+    ISS_HIP(c, hipMemcpyAsync(c->vbx_sig.p, pcm, (size_t)n * 2, hipMemcpyHostToDevice, c->stream));
+    return vbx_run<int16_t>(c, (const int16_t*)c->vbx_sig.p, (const double*)c->vbx_dither.p, n, out, T_out);
 }

@@ -434,10 +434,11 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True):
 
 
 # ------------------------------------------------------------------------------ ResNet-101
-def compile_resnet101(params, feat_dim=64, frames=144, eps=1e-5):
+def compile_resnet101(params, feat_dim=64, frames=144, eps=1e-5, window_input=False):
     """params: dict keyed like resnet.py's state_dict (conv OIHW, BN weight/bias/running_*).
     Lowers resnet.py:78-130 (Bottleneck [3,4,23,3], m_channels 32) for a fixed number of
-    frames; BatchNorm (eval mode) is folded into the preceding conv."""
+    frames; BatchNorm (eval mode) is folded into the preceding conv.  window_input=True makes the first conv read
+    its (feat_dim, frames) image straight from the resident (T, feat_dim) vbx features (iss_vbx_embed)."""
     B = _Builder()
 
     def fold(conv, bn):
@@ -447,15 +448,15 @@ def compile_resnet101(params, feat_dim=64, frames=144, eps=1e-5):
         Wm = (W * sc[:, None, None, None]).transpose(0, 2, 3, 1).reshape(W.shape[0], -1)
         return Wm.astype(np.float32), sft.astype(np.float32), W.shape[2], W.shape[3]
 
-    def conv(src, dst, shape, cname, bname, stride, pad, act, res=-1):
+    def conv(src, dst, shape, cname, bname, stride, pad, act, res=-1, inmode=0):
         Wm, b, kh, kw = fold(cname, bname)
         h, w, _ = shape
         ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
-        return B.conv(src, dst, shape, Wm, kh, kw, stride, stride, pad, pad, ho, wo, bias=b, act=act, res=res)
+        return B.conv(src, dst, shape, Wm, kh, kw, stride, stride, pad, pad, ho, wo, bias=b, act=act, res=res, inmode=inmode)
 
     shape = (feat_dim, frames, 1)                     # NHWC view of torch's (B,1,F,T)
     A, Bb, Cc, D = 0, 1, 2, 3
-    shape = conv(N.BUF_INPUT, A, shape, 'conv1', 'bn1', 1, 1, 1)
+    shape = conv(N.BUF_INPUT, A, shape, 'conv1', 'bn1', 1, 1, 1, inmode=2 if window_input else 0)
     cur = A
     spare = D
     for li, (planes, nblocks, stride) in enumerate(zip((32, 64, 128, 256), (3, 4, 23, 3), (1, 2, 2, 2)), 1):

@@ -7,7 +7,7 @@ Mirrors, for the hot path only:
                                                                    op program run by iss_cnn_forward, many
                                                                    windows per launch sequence instead of
                                                                    one onnxruntime call per window.
-The VAD filtering / MLP scoring tail of VoiceFemininityScoring (:129-202) is SURVEY 8(f) "next".
+The VAD filtering / MLP scoring tail of VoiceFemininityScoring (:129-202) lives in vfs.py.
 """
 import logging
 import os
@@ -34,16 +34,34 @@ def dither_stream(n, seed=3):
 
 
 class FeatureExtractor:
-    """get_features (vbx_segmenter.py:72-89) bound to one device context."""
+    """get_features (vbx_segmenter.py:72-89) bound to one device context.  The features also stay resident on
+    the device; `VBxExtractor` recognises the array it is handed back and gathers its windows there."""
 
     def __init__(self, ctx):
         self.ctx = ctx
         ctx.vbx_tables(tables.vbx_window(), tables.vbx_melbank())
 
+    def _ensure_dither(self, n):
+        """np.random.seed(3) restarts the stream for every file (vbx_segmenter.py:84): all files share one stream,
+        so its longest prefix lives on the device."""
+        if n > self.ctx._dither_n:
+            self.ctx.vbx_set_dither(dither_stream(max(n, 2 * self.ctx._dither_n)))
+
     def __call__(self, signal):
-        signal = np.asarray(signal, dtype=np.float64)
-        sig_i = (signal * 2 ** 15).astype(int)                       # :85 truncation toward zero
-        return self.ctx.vbx_features(sig_i.astype(np.int32), dither_stream(len(signal)))
+        signal = np.asarray(signal)
+        if signal.dtype == np.int16:                                  # PCM16 source: (signal/32768 * 2**15).astype(int) == pcm
+            pcm = signal
+        else:
+            sig_i = (np.asarray(signal, dtype=np.float64) * 2 ** 15).astype(int)      # :85 truncation toward zero
+            pcm = sig_i.astype(np.int16) if sig_i.size and -32768 <= sig_i.min() and sig_i.max() <= 32767 else None
+            if pcm is None:                                           # out-of-range float input: the general int32 path
+                fea = self.ctx.vbx_features(sig_i.astype(np.int32), dither_stream(len(sig_i)))
+                self.ctx._vbx_resident = fea
+                return fea
+        self._ensure_dither(len(pcm))
+        fea = self.ctx.vbx_features_pcm16(pcm)
+        self.ctx._vbx_resident = fea                                  # identity token for VBxExtractor
+        return fea
 
 
 class VBxExtractor:
@@ -57,19 +75,36 @@ class VBxExtractor:
         self.ctx = ctx
         self.params = params
         self.batch_windows = batch_windows
-        self._nets = {}      # frames -> net_id
+        self._nets = {}      # (frames, device-window input) -> net_id
+        self._lru = []       # keys of the two tail-length slots, oldest first
 
-    def _net_for(self, frames):
-        if frames not in self._nets:
-            if len(self._nets) >= _native.MAX_NETS - self._NET_BASE:
-                raise _native.NativeError("too many distinct window lengths loaded")
-            nid = self._NET_BASE + len(self._nets)
-            self.ctx.cnn_load(nid, keras_model.compile_resnet101(self.params, FEAT_DIM, frames))
-            self._nets[frames] = nid
-        return self._nets[frames]
+    def _net_for(self, frames, window=False):
+        """Engine program for this window length.  The full-length programs keep fixed slots (4: host input, 5: device
+        windows); the shorter last-window programs share slots 6-7, least recently used one reloaded on demand."""
+        key = (frames, window)
+        if key in self._nets:
+            if frames != WINLEN:
+                self._lru.remove(key)
+                self._lru.append(key)
+            return self._nets[key]
+        if frames == WINLEN:
+            nid = self._NET_BASE + (1 if window else 0)
+        elif len(self._lru) < 2:
+            nid = self._NET_BASE + 2 + len(self._lru)
+        else:
+            old = self._lru.pop(0)
+            nid = self._nets.pop(old)
+        if frames != WINLEN:
+            self._lru.append(key)
+        self.ctx.cnn_load(nid, keras_model.compile_resnet101(self.params, FEAT_DIM, frames, window_input=window))
+        self._nets[key] = nid
+        return nid
 
     def get_embeddings(self, fea, starts, frames):
-        """(len(starts), 256) embeddings of fea[s:s+frames] (feature-major input like :265)."""
+        """(len(starts), 256) embeddings of fea[s:s+frames] (feature-major input like :265).  When `fea` is the
+        array FeatureExtractor just produced on this context, the windows are gathered on the device."""
+        if getattr(self.ctx, '_vbx_resident', None) is fea:
+            return self.ctx.vbx_embed(self._net_for(frames, window=True), starts)
         nid = self._net_for(frames)
         out = np.empty((len(starts), EMBED_DIM), dtype=np.float32)
         for i in range(0, len(starts), self.batch_windows):

@@ -99,7 +99,8 @@ enum {
     ISS_C_ACT,                                          /* 0 none 1 relu 2 sigmoid 3 tanh   */
     ISS_C_WOFF, ISS_C_BOFF,                             /* blob offsets: W [Cout][roundup32(kh*kw*Cin)] (WOFF % 8 == 0), bias */
     ISS_C_PSOFF, ISS_C_PTOFF,                           /* post-activation scale / shift   */
-    ISS_C_INMODE,                                       /* 0 NHWC buffer, 1 z-normed mspec patch */
+    ISS_C_INMODE,                                       /* 0 NHWC buffer, 1 z-normed mspec patch,
+                                                           2 window of the resident vbx features (iss_vbx_embed) */
     ISS_C_POOLKIND,                                     /* POOL: 0 max 1 avg               */
     ISS_C_ORDER,                                        /* STATPOOL out order: 0 = (c,h) torch flatten */
     ISS_C_FPOOLH, ISS_C_FPOOLW,                         /* CONV: fused non-overlapping pool window applied after
@@ -152,6 +153,16 @@ int iss_cnn_flops(iss_ctx* ctx, int net_id, double* flops_per_sample);
 int iss_vbx_tables(iss_ctx* ctx, const double* window400, const double* melbank_257x64);
 int iss_vbx_features(iss_ctx* ctx, const int32_t* sig_i32, const double* dither_u, int64_t n,
                      float* fea_out /* T*64, may be NULL to keep on device */, int32_t* T_out);
+/* Same for PCM16 sources (what io.py's ffmpeg hop yields: (signal * 2**15).astype(int) is then the PCM itself) with a
+ * dither stream cached on the device: np.random.seed(3) gives every file the same stream, so upload its longest prefix
+ * once (iss_vbx_set_dither) and send 2 bytes per sample afterwards.                                                    */
+int iss_vbx_set_dither(iss_ctx* ctx, const double* dither_u, int64_t n);
+int iss_vbx_features_pcm16(iss_ctx* ctx, const int16_t* pcm, int64_t n,
+                           float* fea_out /* T*64 or NULL */, int32_t* T_out);
+/* x-vectors of n windows [starts[i], starts[i] + frames) of the RESIDENT features (frames = the loaded network's input
+ * width; its first conv must be a window-mode conv, ISS_C_INMODE 2): replaces the window loop of
+ * vbx_segmenter.py:222-231 + get_embedding (:262-266) without copying windows through the host.                        */
+int iss_vbx_embed(iss_ctx* ctx, int net_id, const int32_t* starts, int32_t n, float* out /* n*out_dim */);
 
 /* ------------------------------------------------------------ profiling hooks */
 /* Accumulated device time (ms, hipEvent-timed on the context's stream) and launch

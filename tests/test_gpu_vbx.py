@@ -81,3 +81,24 @@ def test_batched_equals_single(extractor):
     a = extractor.get_embeddings(fea, starts, 144)
     b = np.stack([extractor.get_embedding(fea[s:s + 144]) for s in starts])
     assert np.array_equal(a, b)
+
+
+def test_pcm16_path_and_device_window_gather(ctx, extractor, golden_vbx):
+    """PCM16 entry + cached dither == the int32 + per-call dither entry (bit-identical); x-vectors from the
+    device-side window gather (iss_vbx_embed) == the host-stacked windows through iss_cnn_forward."""
+    pcm = golden_vbx['lamartine_pcm16'][:16000 * 6]
+    fe = V.FeatureExtractor(ctx)
+    a = fe(pcm)                                                        # int16 -> iss_vbx_features_pcm16
+    b = ctx.vbx_features(pcm.astype(np.int32), V.dither_stream(len(pcm)))
+    assert np.array_equal(a, b)
+    assert np.array_equal(fe(pcm.astype(np.float64) / 32768.0), a)     # float input that is PCM16-exact takes the same path
+    assert np.array_equal(fe(pcm[:16000 * 2]), ctx.vbx_features(pcm[:32000].astype(np.int32), V.dither_stream(32000)))   # cached prefix
+    fea = fe(pcm)
+    got = extractor('utt', fea, len(pcm) / 16000.0)                    # resident features -> device windows
+    want = extractor('utt', fea.copy(), len(pcm) / 16000.0)            # a copy is not the resident array -> host path
+    assert [g[0] for g in got] == [w[0] for w in want] and len(got) > 15
+    for (k, seg, x), (_, seg2, y) in zip(got, want):
+        assert seg == seg2 and np.abs(x - y).max() <= 1e-5 * max(1.0, np.abs(y).max()), k
+    for n in (16000 * 3 + 777, 16000 * 4 + 99, 16000 * 5 + 1234):     # three more tail lengths: the two tail slots recycle
+        f2 = fe(pcm[:n])
+        assert len(extractor('u', f2, n / 16000.0)) == len(ovbx.window_list(len(f2)))
