@@ -105,11 +105,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5): every lane holds 4 groups of 4 CONSECUTIVE rows, so a
 // fused pool over 2 or 4 consecutive GEMM rows (rows are enumerated pool-window-major, see
 // map_row) is a max/mean over registers of one lane -- no shuffles, no LDS.
-__device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
+// ACT: 0 none, 1 relu, -1 = read p.act at run time (sigmoid / tanh); PP: fused pool window size (1, 2, 4);
+// HAS_PS: post-activation scale/shift; HAS_RES: residual add.  The common combinations are compiled without any
+// per-element branch (the fully generic form, inlined 32 times per tile, was ~6000 ISA lines of mostly skipped code).
+template <int ACT, int PP, bool HAS_PS, bool HAS_RES>
+__device__ __forceinline__ void epilogue_impl(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
     if (n >= p.Cout) return;
     const float bias = p.bias ? p.bias[n] : 0.f;
-    const float s = p.ps ? p.ps[n] : 1.f;
-    const float sh = p.pt ? p.pt[n] : 0.f;
+    const float s = HAS_PS ? p.ps[n] : 1.f;
+    const float sh = HAS_PS ? p.pt[n] : 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const long long mb = mrow0 + 8 * g + 4 * lh;        // first of this lane's 4 consecutive rows
@@ -117,28 +121,86 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const floatx16&
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float x = acc[4 * g + i] + bias;
-            if (p.res && mb + i < p.M) x += p.res[(size_t)(mb + i) * p.Cout + n];
-            x = apply_act(x, p.act);
-            if (p.ps) x = x * s + sh;
+            if (HAS_RES) { if (mb + i < p.M) x += p.res[(size_t)(mb + i) * p.Cout + n]; }
+            if (ACT == 1) x = fmaxf(x, 0.f);
+            else if (ACT == -1) x = apply_act(x, p.act);
+            if (HAS_PS) x = x * s + sh;
             v[i] = x;
         }
-        if (p.pp == 1) {
+        if (PP == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (mb + i < p.M && (!(p.dbg & 16) || v[i] == 1234.5678f)) p.out[(size_t)(mb + i) * p.Cout + n] = v[i];
-        } else if (p.pp == 4) {
+                if (mb + i < p.M) p.out[(size_t)(mb + i) * p.Cout + n] = v[i];
+        } else if (PP == 4) {
             if (mb < p.M) {
                 const float r = p.poolkind == 0 ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]))
                                                 : (v[0] + v[1] + v[2] + v[3]) * 0.25f;
-                if (!(p.dbg & 16) || r == 1234.5678f) p.out[(size_t)(mb >> 2) * p.Cout + n] = r;
+                p.out[(size_t)(mb >> 2) * p.Cout + n] = r;
             }
-        } else {                                             // pp == 2
+        } else {                                             // PP == 2
 #pragma unroll
             for (int i = 0; i < 4; i += 2)
                 if (mb + i < p.M) {
                     const float r = p.poolkind == 0 ? fmaxf(v[i], v[i + 1]) : (v[i] + v[i + 1]) * 0.5f;
                     p.out[(size_t)((mb + i) >> 1) * p.Cout + n] = r;
                 }
+        }
+    }
+}
+
+template <int PP>
+__device__ __forceinline__ void epilogue_pp(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
+    const bool ps = p.ps != nullptr;
+    if (p.res) {                                             // residual add (ResNet): run-time activation
+        if (ps) epilogue_impl<-1, PP, true, true>(p, acc, mrow0, n, lh);
+        else epilogue_impl<-1, PP, false, true>(p, acc, mrow0, n, lh);
+    } else if (p.act > 1) {                                  // sigmoid / tanh
+        if (ps) epilogue_impl<-1, PP, true, false>(p, acc, mrow0, n, lh);
+        else epilogue_impl<-1, PP, false, false>(p, acc, mrow0, n, lh);
+    } else if (p.act == 1) {
+        if (ps) epilogue_impl<1, PP, true, false>(p, acc, mrow0, n, lh);
+        else epilogue_impl<1, PP, false, false>(p, acc, mrow0, n, lh);
+    } else {
+        if (ps) epilogue_impl<0, PP, true, false>(p, acc, mrow0, n, lh);
+        else epilogue_impl<0, PP, false, false>(p, acc, mrow0, n, lh);
+    }
+}
+
+__device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
+    if (p.pp == 1) epilogue_pp<1>(p, acc, mrow0, n, lh);
+    else if (p.pp == 4) epilogue_pp<4>(p, acc, mrow0, n, lh);
+    else epilogue_pp<2>(p, acc, mrow0, n, lh);
+}
+
+// Epilogue of TRANSPOSED accumulators (the MFMAs were issued as W-fragment x A-fragment, i.e. C^T): lane = GEMM row
+// (pixel) m, register group g of tile t = output channels n0 + 32 t + 8 g + 4 lh + {0..3}.  Every access is a float4:
+// bias / scale / shift, the residual, and the store (8 x 16 B per lane and tile pair instead of 32 x 4 B).  Needs
+// pp == 1 and Cout % 4 == 0 (parameter offsets in the blob are multiples of 8 floats).
+__device__ __forceinline__ void epilogue_tr(const ConvArgs& p, const floatx16& acc0, const floatx16& acc1, long long m,
+                                            int n0, int lh) {
+    if (m >= p.M) return;
+    float* orow = p.out + (size_t)m * p.Cout;
+    const float* rrow = p.res ? p.res + (size_t)m * p.Cout : nullptr;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = n0 + 32 * t + 8 * g + 4 * lh;
+            if (c >= p.Cout) continue;
+            float4 v;
+            v.x = t == 0 ? acc0[4 * g + 0] : acc1[4 * g + 0];
+            v.y = t == 0 ? acc0[4 * g + 1] : acc1[4 * g + 1];
+            v.z = t == 0 ? acc0[4 * g + 2] : acc1[4 * g + 2];
+            v.w = t == 0 ? acc0[4 * g + 3] : acc1[4 * g + 3];
+            if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + c); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+            if (rrow) { const float4 r4 = *reinterpret_cast<const float4*>(rrow + c); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+            if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else if (p.act > 1) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
+            if (p.ps) {
+                const float4 s4 = *reinterpret_cast<const float4*>(p.ps + c), t4 = *reinterpret_cast<const float4*>(p.pt + c);
+                v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
+            }
+            *reinterpret_cast<float4*>(orow + c) = v;
         }
     }
 }
@@ -300,7 +362,7 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& l) {
     l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
 }
 
-template <int MODE>
+template <int MODE, bool TR>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs p) {
     __shared__ __attribute__((aligned(16))) uint16_t sAh[2][BM * XLD];
     __shared__ __attribute__((aligned(16))) uint16_t sAl[2][BM * XLD];
@@ -381,18 +443,31 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs p) {
             const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + ks * 16]);
             const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + 32 * XLD + ks * 16]);
             const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + 32 * XLD + ks * 16]);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
+            if (TR) {                                    // C^T: rows = channels, columns = pixels (see epilogue_tr)
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0h, al, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1h, al, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0l, ah, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1l, ah, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0h, ah, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1h, ah, acc1, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
+            }
         }
         if (kt + 1 < nk) stage(cur ^ 1);
         __syncthreads();
     }
-    epilogue_tile(p, acc0, m0 + wv * 32, n0 + li, lh);
-    epilogue_tile(p, acc1, m0 + wv * 32, n0 + 32 + li, lh);
+    if (TR) {
+        epilogue_tr(p, acc0, acc1, m0 + wv * 32 + li, n0, lh);
+    } else {
+        epilogue_tile(p, acc0, m0 + wv * 32, n0 + li, lh);
+        epilogue_tile(p, acc1, m0 + wv * 32, n0 + 32 + li, lh);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -456,7 +531,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // chunk of 16 rows with distinct (r mod 16) hit 16 different 16-byte bank groups.
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
 
-template <int KH, int KW, bool PADDED>
+template <int KH, int KW, bool PADDED, bool TR>
 __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     constexpr int NT = KH * KW;
     static_assert(NT >= 2, "1x1 convolutions use conv_x3_kernel");
@@ -564,12 +639,21 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         f.b1l = *reinterpret_cast<const bf16x8*>(&sB[so + BSTAGE / 2 + (b1s - (0 ^ bx) + c) * 8]);
     };
     auto mfma6 = [&](const Frags& f) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b0h, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b1h, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0l, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1l, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0h, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1h, acc1, 0, 0, 0);
+        if (TR) {                                        // C^T: rows = channels, columns = pixels (see epilogue_tr)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0h, f.al, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1h, f.al, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0l, f.ah, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1l, f.ah, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0h, f.ah, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1h, f.ah, acc1, 0, 0, 0);
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b1h, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0l, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1l, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0h, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1h, acc1, 0, 0, 0);
+        }
     };
 
     // ---- software pipeline over the (tile, chunk, tap) sequence.  LDS: three weight stages (B(t), B(t+1), and
@@ -655,8 +739,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
                 st[0] = r[NT % 4]; st[1] = r[(NT + 1) % 4]; st[2] = r[(NT + 2) % 4]; st[3] = r[(NT + 3) % 4];
             }
         }
-        epilogue_tile(p, acc0, (long long)tile * BM + wv * 32, n0 + li, lh);
-        epilogue_tile(p, acc1, (long long)tile * BM + wv * 32, n0 + 32 + li, lh);
+        if (TR) {
+            epilogue_tr(p, acc0, acc1, (long long)tile * BM + wv * 32 + li, n0, lh);
+        } else {
+            epilogue_tile(p, acc0, (long long)tile * BM + wv * 32, n0 + li, lh);
+            epilogue_tile(p, acc1, (long long)tile * BM + wv * 32, n0 + 32 + li, lh);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
         g = gn;
@@ -674,6 +762,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
 //     bf16 hi/lo split -- no LDS A tile, no barrier at all;
 //   * the workgroup's 64 x 32 weight block (hi + lo) is loaded once into 32 VGPRs and stays there while
 //     the persistent workgroup walks its range of tiles: 12 MFMAs + the fused epilogue per tile.
+// TR: operands swapped (C^T = W . A^T): a lane then holds 4 CONSECUTIVE channels of one pixel per register group and
+// the epilogue stores float4 (8 x 16-byte stores per lane and tile instead of 32 x 4-byte ones); needs pp == 1.
+template <bool TR>
 __global__ __launch_bounds__(256, 2) void conv1_patch_x3_kernel(const ConvArgs p) {
     __shared__ int s_delta[XBK];                     // k -> ty * 24 + tx  (or -1 for the K padding)
     __shared__ int s_tap[XBK];                       // k -> (ty << 16) | tx
@@ -740,17 +831,30 @@ __global__ __launch_bounds__(256, 2) void conv1_patch_x3_kernel(const ConvArgs p
         floatx16 acc0, acc1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        if (!TR) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], b0h[ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], b1h[ks], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b0l[ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b1l[ks], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b0h[ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b1h[ks], acc1, 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], b0h[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], b1h[ks], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b0l[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b1l[ks], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b0h[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], b1h[ks], acc1, 0, 0, 0);
+            }
+            epilogue_tile(p, acc0, (long long)tile * BM + wv * 32, n0 + li, lh);
+            epilogue_tile(p, acc1, (long long)tile * BM + wv * 32, n0 + 32 + li, lh);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {             // rows = channels (weight fragment), columns = pixels
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0h[ks], al[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1h[ks], al[ks], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0l[ks], ah[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1l[ks], ah[ks], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0h[ks], ah[ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1h[ks], ah[ks], acc1, 0, 0, 0);
+            }
+            epilogue_tr(p, acc0, acc1, m, n0, lh);
         }
-        epilogue_tile(p, acc0, (long long)tile * BM + wv * 32, n0 + li, lh);
-        epilogue_tile(p, acc1, (long long)tile * BM + wv * 32, n0 + 32 + li, lh);
     }
 }
 
@@ -1091,19 +1195,27 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                                     (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
 #define ISS_FP_CASE(KH_, KW_)                                                                              \
     if (a.H_k == KH_ && a.kw == KW_) {                                                                     \
-        if (padded) hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, true>), pgrid, dim3(256), 0, c->stream, a);  \
-        else hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, false>), pgrid, dim3(256), 0, c->stream, a);        \
+        if (padded && tr) hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, true, true>), pgrid, dim3(256), 0, c->stream, a);       \
+        else if (padded) hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, true, false>), pgrid, dim3(256), 0, c->stream, a);       \
+        else if (tr) hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, false, true>), pgrid, dim3(256), 0, c->stream, a);           \
+        else hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, false, false>), pgrid, dim3(256), 0, c->stream, a);                  \
     } else
                 const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent: 2 workgroups per CU
+                const bool tr = a.pp == 1 && a.Cout % 4 == 0;                   // float4 epilogue on transposed accumulators
                 ISS_FP_SHAPES(ISS_FP_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no footprint kernel for %dx%d", a.H_k, a.kw); }
 #undef ISS_FP_CASE
             } else if (x3 && patch && a.H_k * a.kw <= XBK && a.M < (1ll << 31)) {
                 const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent, no barriers: 2 workgroups per CU
-                hipLaunchKernelGGL(conv1_patch_x3_kernel, pgrid, dim3(256), 0, c->stream, a);
+                // blob offsets are multiples of 8 floats, so the float4 loads of bias / scale / shift are aligned
+                if (a.pp == 1 && a.Cout % 4 == 0 && !a.res) hipLaunchKernelGGL(conv1_patch_x3_kernel<true>, pgrid, dim3(256), 0, c->stream, a);
+                else hipLaunchKernelGGL(conv1_patch_x3_kernel<false>, pgrid, dim3(256), 0, c->stream, a);
             } else if (x3) {
-                if (a.mode == 0) hipLaunchKernelGGL(conv_x3_kernel<0>, grid, dim3(256), 0, c->stream, a);
-                else if (a.mode == 1) hipLaunchKernelGGL(conv_x3_kernel<1>, grid, dim3(256), 0, c->stream, a);
-                else hipLaunchKernelGGL(conv_x3_kernel<2>, grid, dim3(256), 0, c->stream, a);
+                const bool tr = a.pp == 1 && a.Cout % 4 == 0;     // float4 epilogue on transposed accumulators
+                if (a.mode == 0 && tr) hipLaunchKernelGGL((conv_x3_kernel<0, true>), grid, dim3(256), 0, c->stream, a);
+                else if (a.mode == 0) hipLaunchKernelGGL((conv_x3_kernel<0, false>), grid, dim3(256), 0, c->stream, a);
+                else if (a.mode == 1 && tr) hipLaunchKernelGGL((conv_x3_kernel<1, true>), grid, dim3(256), 0, c->stream, a);
+                else if (a.mode == 1) hipLaunchKernelGGL((conv_x3_kernel<1, false>), grid, dim3(256), 0, c->stream, a);
+                else hipLaunchKernelGGL((conv_x3_kernel<2, false>), grid, dim3(256), 0, c->stream, a);
             } else {
                 if (a.mode == 0) hipLaunchKernelGGL(conv_igemm_kernel<0>, grid, dim3(256), 0, c->stream, a);
                 else if (a.mode == 1) hipLaunchKernelGGL(conv_igemm_kernel<1>, grid, dim3(256), 0, c->stream, a);
