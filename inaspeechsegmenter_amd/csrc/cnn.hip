@@ -20,244 +20,12 @@
 //   pool_kernel          max / average pooling, NHWC (pools that cannot be fused)
 //   softmax_kernel       softmax over channels
 //   statpool_kernel      mean || std over time                           (resnet.py:123-127)
-#include "iss_internal.h"
-#include <cmath>
-#include <cstring>
-#include <algorithm>
-#include <cstdlib>
+#include "conv_common.h"
+#include "conv_fp.h"
+
+using namespace issk;
 
 namespace {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BM = 128;      // GEMM rows (output pixels) per workgroup
-constexpr int BN = 64;       // GEMM cols (output channels) per workgroup
-constexpr int BK = 16;       // k-tile of the f32 kernel
-constexpr int LDK = BK + 4;  // padded LDS row (floats): conflict-free ds_read_b128
-constexpr int XBK = 32;      // k-tile of the bf16x3 kernel (two k16 MFMA steps)
-constexpr int XLD = XBK + 8; // padded LDS row (bf16): 80 B, conflict-free ds_read_b128
-constexpr int KALIGN = 32;   // weight rows are padded to this many k
-
-struct ConvArgs {
-    const float* in;
-    const float* w;          // [Cout][Kpad] f32
-    const uint16_t* wh;      // [Cout][Kpad] bf16 hi part
-    const uint16_t* wl;      // [Cout][Kpad] bf16 lo part
-    const float* bias;       // [Cout] or null
-    const float* ps;         // post-activation scale [Cout] or null
-    const float* pt;         // post-activation shift
-    const float* res;        // residual, same shape as out, or null
-    float* out;
-    const int32_t* ktab;     // [Kpad] x {delta, (ky<<16)|kx}
-    const int32_t* win_row;  // PATCH mode
-    const float* stats;      // PATCH mode: {mean, std} per sample
-    const uint8_t* finite;   // PATCH mode
-    long long M;             // samples * Hq * Wq * pp   (GEMM rows)
-    long long img_stride;    // floats per input sample
-    int H, W, Cin, Cout;
-    int Hq, Wq;              // output grid the GEMM rows enumerate: pooled grid when pp > 1, else (Ho, Wo)
-    int ph, pw, pp;          // fused pool window (1,1,1 = none); rows m = q*pp + (dy*pw + dx)
-    int poolkind;            // 0 max, 1 avg
-    int H_k, kw;             // kernel height / width (vectorised loaders walk taps)
-    int sh, sw, pt_, pl_;
-    int row_stride, pix_stride;
-    int act, Kpad, mode;
-    unsigned nblk;           // M tiles (grid.x)
-    int dbg;                 // ISS_DBG experiment bits (0 in production)
-};
-
-// GEMM row -> (sample, oy, ox) of the convolution output it stands for
-__device__ __forceinline__ void map_row(const ConvArgs& p, long long m, int& b, int& oy, int& ox) {
-    long long q = m;
-    int dy = 0, dx = 0;
-    if (p.pp > 1) {
-        q = m / p.pp;
-        const int j = (int)(m - q * p.pp);
-        dy = j / p.pw; dx = j - dy * p.pw;
-    }
-    const int hw = p.Hq * p.Wq;
-    b = (int)(q / hw);
-    const int rem = (int)(q - (long long)b * hw);
-    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-    oy = qy * p.ph + dy;
-    ox = qx * p.pw + dx;
-}
-
-// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed); give every XCD one contiguous
-// range of M tiles so that neighbouring tiles (which share im2col halos) hit the same L2.
-__device__ __forceinline__ unsigned tile_of_block(unsigned bid, unsigned nblk) {
-    const unsigned per = nblk >> 3;
-    if (per == 0 || bid >= per * 8) return bid;
-    return (bid & 7) * per + (bid >> 3);
-}
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == 1) return fmaxf(v, 0.f);
-    if (act == 2) return 1.f / (1.f + expf(-v));
-    if (act == 3) return tanhf(v);
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------
-// Shared epilogue.  C/D layout of the 32x32 MFMAs (f32 and bf16 alike): col = lane&31,
-// row = (r&3) + 8*(r>>2) + 4*(lane>>5): every lane holds 4 groups of 4 CONSECUTIVE rows, so a
-// fused pool over 2 or 4 consecutive GEMM rows (rows are enumerated pool-window-major, see
-// map_row) is a max/mean over registers of one lane -- no shuffles, no LDS.
-// ACT: 0 none, 1 relu, -1 = read p.act at run time (sigmoid / tanh); PP: fused pool window size (1, 2, 4);
-// HAS_PS: post-activation scale/shift; HAS_RES: residual add.  The common combinations are compiled without any
-// per-element branch (the fully generic form, inlined 32 times per tile, was ~6000 ISA lines of mostly skipped code).
-template <int ACT, int PP, bool HAS_PS, bool HAS_RES>
-__device__ __forceinline__ void epilogue_impl(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
-    if (n >= p.Cout) return;
-    const float bias = p.bias ? p.bias[n] : 0.f;
-    const float s = HAS_PS ? p.ps[n] : 1.f;
-    const float sh = HAS_PS ? p.pt[n] : 0.f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const long long mb = mrow0 + 8 * g + 4 * lh;        // first of this lane's 4 consecutive rows
-        float v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float x = acc[4 * g + i] + bias;
-            if (HAS_RES) { if (mb + i < p.M) x += p.res[(size_t)(mb + i) * p.Cout + n]; }
-            if (ACT == 1) x = fmaxf(x, 0.f);
-            else if (ACT == -1) x = apply_act(x, p.act);
-            if (HAS_PS) x = x * s + sh;
-            v[i] = x;
-        }
-        if (PP == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (mb + i < p.M) p.out[(size_t)(mb + i) * p.Cout + n] = v[i];
-        } else if (PP == 4) {
-            if (mb < p.M) {
-                const float r = p.poolkind == 0 ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]))
-                                                : (v[0] + v[1] + v[2] + v[3]) * 0.25f;
-                p.out[(size_t)(mb >> 2) * p.Cout + n] = r;
-            }
-        } else {                                             // PP == 2
-#pragma unroll
-            for (int i = 0; i < 4; i += 2)
-                if (mb + i < p.M) {
-                    const float r = p.poolkind == 0 ? fmaxf(v[i], v[i + 1]) : (v[i] + v[i + 1]) * 0.5f;
-                    p.out[(size_t)((mb + i) >> 1) * p.Cout + n] = r;
-                }
-        }
-    }
-}
-
-template <int PP>
-__device__ __forceinline__ void epilogue_pp(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
-    const bool ps = p.ps != nullptr;
-    if (p.res) {                                             // residual add (ResNet): run-time activation
-        if (ps) epilogue_impl<-1, PP, true, true>(p, acc, mrow0, n, lh);
-        else epilogue_impl<-1, PP, false, true>(p, acc, mrow0, n, lh);
-    } else if (p.act > 1) {                                  // sigmoid / tanh
-        if (ps) epilogue_impl<-1, PP, true, false>(p, acc, mrow0, n, lh);
-        else epilogue_impl<-1, PP, false, false>(p, acc, mrow0, n, lh);
-    } else if (p.act == 1) {
-        if (ps) epilogue_impl<1, PP, true, false>(p, acc, mrow0, n, lh);
-        else epilogue_impl<1, PP, false, false>(p, acc, mrow0, n, lh);
-    } else {
-        if (ps) epilogue_impl<0, PP, true, false>(p, acc, mrow0, n, lh);
-        else epilogue_impl<0, PP, false, false>(p, acc, mrow0, n, lh);
-    }
-}
-
-__device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
-    if (p.pp == 1) epilogue_pp<1>(p, acc, mrow0, n, lh);
-    else if (p.pp == 4) epilogue_pp<4>(p, acc, mrow0, n, lh);
-    else epilogue_pp<2>(p, acc, mrow0, n, lh);
-}
-
-// Epilogue of TRANSPOSED accumulators (the MFMAs were issued as W-fragment x A-fragment, i.e. C^T): lane = GEMM row
-// (pixel) m, register group g of tile t = output channels n0 + 32 t + 8 g + 4 lh + {0..3}.  Every access is a float4:
-// bias / scale / shift, the residual, and the store (8 x 16 B per lane and tile pair instead of 32 x 4 B).  Needs
-// pp == 1 and Cout % 4 == 0 (parameter offsets in the blob are multiples of 8 floats).
-__device__ __forceinline__ void epilogue_tr(const ConvArgs& p, const floatx16& acc0, const floatx16& acc1, long long m,
-                                            int n0, int lh) {
-    if (m >= p.M) return;
-    float* orow = p.out + (size_t)m * p.Cout;
-    const float* rrow = p.res ? p.res + (size_t)m * p.Cout : nullptr;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c = n0 + 32 * t + 8 * g + 4 * lh;
-            if (c >= p.Cout) continue;
-            float4 v;
-            v.x = t == 0 ? acc0[4 * g + 0] : acc1[4 * g + 0];
-            v.y = t == 0 ? acc0[4 * g + 1] : acc1[4 * g + 1];
-            v.z = t == 0 ? acc0[4 * g + 2] : acc1[4 * g + 2];
-            v.w = t == 0 ? acc0[4 * g + 3] : acc1[4 * g + 3];
-            if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + c); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
-            if (rrow) { const float4 r4 = *reinterpret_cast<const float4*>(rrow + c); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
-            if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            else if (p.act > 1) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
-            if (p.ps) {
-                const float4 s4 = *reinterpret_cast<const float4*>(p.ps + c), t4 = *reinterpret_cast<const float4*>(p.pt + c);
-                v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
-            }
-            *reinterpret_cast<float4*>(orow + c) = v;
-        }
-    }
-}
-
-// Unconditional loads: a load inside a divergent `if` makes hipcc put an `s_waitcnt vmcnt(0)` at the
-// join, right behind the load, which exposes the full memory latency in every k iteration.  So:
-// always load from a valid address (the tensor base when the element is out of bounds) and
-// select afterwards.
-__device__ __forceinline__ float4 ld4_or_zero(const float* base, long long off, bool ok) {
-    const float4 v = *reinterpret_cast<const float4*>(base + (ok ? off : 0));
-    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-__device__ __forceinline__ uint4 ldu4_or_zero(const uint16_t* base, size_t off, bool ok) {
-    const uint4 v = *reinterpret_cast<const uint4*>(base + (ok ? off : 0));
-    return ok ? v : make_uint4(0, 0, 0, 0);
-}
-
-// per-thread gather bookkeeping of one A row
-struct RowSrc {
-    long long base;
-    int iy0, ix0;
-    float mean, sd;
-    bool ok;
-};
-
-template <int MODE>
-__device__ __forceinline__ RowSrc row_source(const ConvArgs& p, long long m) {
-    RowSrc r;
-    r.ok = m < p.M;
-    int b, oy, ox;
-    map_row(p, r.ok ? m : 0, b, oy, ox);
-    r.iy0 = oy * p.sh - p.pt_;
-    r.ix0 = ox * p.sw - p.pl_;
-    r.mean = 0.f; r.sd = 1.f;
-    if (MODE == 2) {
-        r.base = (long long)p.win_row[b] * 24 + (long long)r.iy0 * 24 + r.ix0;
-        r.mean = p.stats[2 * b];
-        r.sd = p.stats[2 * b + 1];
-        r.ok = r.ok && p.finite[b];
-    } else if (MODE == 1 && p.win_row) {             // window of the resident vbx features: frame (start + ix), feature iy
-        r.base = ((long long)p.win_row[b] + r.ix0) * p.pix_stride + (long long)r.iy0 * p.row_stride;
-    } else {
-        r.base = (long long)b * p.img_stride + (long long)r.iy0 * p.row_stride + (long long)r.ix0 * p.pix_stride;
-    }
-    return r;
-}
-
-// one A element through the im2col table (scalar path: any Cin, and the z-normalised PATCH input)
-template <int MODE>
-__device__ __forceinline__ float gather_scalar(const ConvArgs& p, const RowSrc& r, int k) {
-    const int2 e = reinterpret_cast<const int2*>(p.ktab)[k];
-    const int iy = r.iy0 + (e.y >> 16), ix = r.ix0 + (e.y & 0xffff);
-    const bool ok = r.ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    float x = p.in[ok ? r.base + e.x : 0];
-    if (MODE == 2) x = (x - r.mean) / r.sd;
-    return ok ? x : 0.f;
-}
 
 // ------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution, exact f32.  C[m][n] = sum_k A[m][k] * Wt[n][k],
@@ -356,11 +124,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 // -> two workgroups per CU, one staging while the other is on the matrix pipe.
 // MODE: 0 = NHWC with Cin % 32 == 0 (a k-tile is 32 consecutive channels of ONE tap: float4
 //           gathers, no table), 1 = NHWC scalar gathers, 2 = z-normed patch.
-__device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& l) {
-    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-    l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
-    l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
-}
 
 template <int MODE, bool TR>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs p) {
@@ -467,287 +230,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs p) {
     } else {
         epilogue_tile(p, acc0, m0 + wv * 32, n0 + li, lh);
         epilogue_tile(p, acc1, m0 + wv * 32, n0 + 32 + li, lh);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// bf16x3 implicit GEMM with an LDS-resident input footprint (kh*kw > 1, Cin % 32 == 0).
-//
-// conv_x3_kernel re-gathers every A element once per tap: 16 KB of f32 activations per 384 MFMA
-// cycles and workgroup, which saturates the per-CU L1/L2 path (~56 B/clk) long before the matrix
-// pipe.  Here the k loop is re-ordered to (channel chunk of 32) x (ky, kx): the input pixels a
-// 128-row M tile touches form ONE contiguous range [p_lo, p_hi] of the flattened (sample, iy, ix)
-// pixel index (NHWC), so per chunk that range is loaded from global memory ONCE, split into
-// bf16 hi/lo and kept in LDS; every tap then reads its MFMA A fragments straight from that
-// footprint at a per-lane pixel offset (+ ky*W + kx).  Global A traffic drops by ~kh*kw; only
-// the 8 KB weight tile per tap still streams (double-buffered) from L2.
-constexpr int FPIX = 360;    // footprint capacity in pixels (host-validated per launch): 56 KB of LDS as bf16 hi+lo
-
-// MFMA operand fragments of one k16 step of one tap (A rows hi/lo, two 32-column B tiles hi/lo)
-struct Frags { bf16x8 ah, al, b0h, b0l, b1h, b1l; };
-
-// KH x KW are compile-time so that the tap loop unrolls completely: tap coordinates, LDS offsets,
-// B-stage parity and the footprint-slice schedule become constants.  (With a run-time tap loop the
-// scalar bookkeeping alone was ~80 SALU instructions + a dozen taken branches per 12 MFMAs, more
-// than the five issue slots a wave has between two back-to-back MFMAs.)
-// 32-bit replica of map_row (the launch guarantees M < 2^31): 64-bit integer division is ~100 scalar
-// instructions on gfx950 and this runs once per lane per tile.
-__device__ __forceinline__ void map_row32(const ConvArgs& p, int m, int& b, int& oy, int& ox) {
-    int q = m, dy = 0, dx = 0;
-    if (p.pp > 1) {
-        q = m / p.pp;
-        const int j = m - q * p.pp;
-        dy = j / p.pw; dx = j - dy * p.pw;
-    }
-    const int hw = p.Hq * p.Wq;
-    b = q / hw;
-    const int rem = q - b * hw;
-    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-    oy = qy * p.ph + dy;
-    ox = qx * p.pw + dx;
-}
-
-// Persistent workgroups: a 128-row tile is only 7-14 k cycles of MFMA work, while filling the
-// pipeline (footprint + weight loads from HBM/L2, geometry) and draining it (32 stores per lane)
-// cost several thousand cycles -- one-tile-per-workgroup launches measured 33 % matrix-pipe
-// utilisation.  Here 2 x 256 workgroups each walk a contiguous range of M tiles and the software
-// pipeline runs ACROSS tiles: the next tile's first footprint and weight tiles are fetched during
-// the current tile's last taps, exactly like the next channel chunk's.
-// LDS-DMA: 16 bytes per lane from global memory straight into LDS at (wave-uniform base + lane * 16); no VGPR
-// destination, no ds_write.  hipcc does not count this instruction in its s_waitcnt bookkeeping: the kernel
-// below waits for it with explicit vmcnt(N) statements.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
-}
-
-// 16-byte chunk swizzle of the unpadded LDS tiles (rows of 4 chunks = 32 bf16): logical chunk c of row r
-// lives at physical chunk c ^ ((r >> 2) & 3).  16 lanes of a ds_read_b128 group that read the same logical
-// chunk of 16 rows with distinct (r mod 16) hit 16 different 16-byte bank groups.
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
-
-template <int KH, int KW, bool PADDED, bool TR>
-__global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
-    constexpr int NT = KH * KW;
-    static_assert(NT >= 2, "1x1 convolutions use conv_x3_kernel");
-    constexpr int BSTAGE = BN * 64;                  // bytes of one plane of one weight stage (64 rows x 32 bf16)
-    __shared__ __attribute__((aligned(16))) uint16_t sFh[FPIX * 32];
-    __shared__ __attribute__((aligned(16))) uint16_t sFl[FPIX * 32];
-    __shared__ __attribute__((aligned(1024))) uint16_t sB[4 * 2 * BSTAGE / 2];      // [stage][hi | lo][row][32]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.y * BN;
-    const int li = lane & 31, lh = lane >> 5;
-    const int M = (int)p.M;
-    const int totpix = (int)(p.img_stride / p.Cin) * (M / (p.Hq * p.Wq * p.pp));     // samples * H * W
-
-    // contiguous tile range of this workgroup (neighbouring tiles share im2col halos -> same L2 / L1)
-    const int per = ((int)p.nblk + (int)gridDim.x - 1) / (int)gridDim.x;
-    int tile = (int)blockIdx.x * per;
-    const int tile_end = tile + per < (int)p.nblk ? tile + per : (int)p.nblk;
-    if (tile >= tile_end) return;
-
-    // ---- per-tile geometry: first pixel of the tile (uniform) and this lane's A row
-    struct Geom { int p_lo, lanepix, iy0, ix0; };
-    auto geometry = [&](int t) {
-        Geom g;
-        const int m0 = t * BM;
-        int b, oy, ox;
-        map_row32(p, m0, b, oy, ox);
-        g.p_lo = (b * p.H + (oy * p.sh - p.pt_)) * p.W + (ox * p.sw - p.pl_);
-        const int m = m0 + wv * 32 + li;
-        map_row32(p, m < M ? m : m0, b, oy, ox);
-        g.iy0 = oy * p.sh - p.pt_;
-        g.ix0 = ox * p.sw - p.pl_;
-        int lanepix = (b * p.H + g.iy0) * p.W + g.ix0 - g.p_lo;
-        const int hi = FPIX - 1 - ((KH - 1) * p.W + (KW - 1));   // keeps every tap of a row >= M inside the buffer
-        g.lanepix = lanepix < 0 ? 0 : (lanepix > hi ? hi : lanepix);
-        return g;
-    };
-    Geom g = geometry(tile), gn = g;
-
-    // ---- weight tiles by LDS-DMA.  Wave wv moves slots [64 wv, 64 wv + 64) of the 256-slot tile: slot = row * 4 +
-    // physical chunk; lane reads the LOGICAL chunk that belongs there (swizzle on the source side, LDS linear).
-    // Rows >= Cout read row 0 instead: their output columns are never stored.
-    const int brow = wv * 16 + (lane >> 2);
-    const size_t boff = (size_t)(n0 + brow < p.Cout ? n0 + brow : 0) * p.Kpad + (size_t)(((lane & 3) ^ ((brow >> 2) & 3)) * 8);
-    const unsigned sB_base = (unsigned)(size_t)(&sB[0]);
-    auto dma_b = [&](int stage_off, int tap, int c0) {       // stage_off: byte offset of the stage inside sB
-        const size_t src = boff + (size_t)tap * p.Cin + c0;
-        glds16(p.wh + src, sB_base + stage_off + wv * 1024);
-        glds16(p.wl + src, sB_base + stage_off + BSTAGE + wv * 1024);
-    };
-
-    floatx16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-
-    // ---- footprint prefetch registers: pixel prow + 32 q, channels [c0 + 4 k8, +4).  Pixels outside
-    // [0, totpix) are clamped to a valid address: only rows >= M or zero-padded taps ever read them
-    // (the latter are zeroed after the LDS read), so the loads need no mask.
-    const int k8 = tid & 7, prow = tid >> 3;
-    constexpr int NFV = (FPIX + 31) / 32;
-    float4 fv[NFV];
-    auto fetch_fp_part = [&](int q, int p_lo, int c0) {
-        int gp = p_lo + prow + 32 * q;
-        gp = gp < 0 ? 0 : (gp > totpix - 1 ? totpix - 1 : gp);
-        fv[q] = *reinterpret_cast<const float4*>(p.in + ((unsigned)gp * (unsigned)p.Cin + (unsigned)(c0 + k8 * 4)));
-    };
-    auto stage_fp = [&]() {
-#pragma unroll
-        for (int q = 0; q < NFV; ++q) {
-            const int pix = prow + 32 * q;
-            if (pix >= FPIX) continue;
-            bf16x4 h, l;
-            split4(fv[q], h, l);
-            const int o = swz(pix, k8 >> 1) * 8 + (k8 & 1) * 4;          // bf16 units
-            *reinterpret_cast<bf16x4*>(&sFh[o]) = h;
-            *reinterpret_cast<bf16x4*>(&sFl[o]) = l;
-        }
-    };
-
-    const int b0s = swz(li, 0), b1s = swz(li + 32, 0);                   // chunk-0 slots of this lane's two weight rows
-    const int bx = (li >> 2) & 3;                                        // their swizzle key (same for li and li + 32)
-    auto read_frags = [&](Frags& f, const Geom& gg, int ky, int kx, int ks, int stage_off) {
-        // opaque copy: without it hipcc hoists the 2 x KH x KW swizzled A addresses (they only depend on the tile)
-        // out of the chunk loop and keeps them live in 18-30 VGPRs; recomputing costs ~5 VALU per address
-        int lp = gg.lanepix;
-        asm volatile("" : "+v"(lp));
-        const int pix = lp + ky * p.W + kx;
-        const int lc = ks * 2 + lh;
-        const int aoff = swz(pix, lc) * 8;                               // bf16 units
-        f.ah = *reinterpret_cast<const bf16x8*>(&sFh[aoff]);
-        f.al = *reinterpret_cast<const bf16x8*>(&sFl[aoff]);
-        if (PADDED) {
-            const bool ok = (unsigned)(gg.iy0 + ky) < (unsigned)p.H && (unsigned)(gg.ix0 + kx) < (unsigned)p.W;
-            if (!ok) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { f.ah[q] = (__bf16)0.f; f.al[q] = (__bf16)0.f; }
-            }
-        }
-        const int so = stage_off / 2;                                    // bf16 units
-        const int c = lc ^ bx;
-        f.b0h = *reinterpret_cast<const bf16x8*>(&sB[so + (b0s - (0 ^ bx) + c) * 8]);
-        f.b0l = *reinterpret_cast<const bf16x8*>(&sB[so + BSTAGE / 2 + (b0s - (0 ^ bx) + c) * 8]);
-        f.b1h = *reinterpret_cast<const bf16x8*>(&sB[so + (b1s - (0 ^ bx) + c) * 8]);
-        f.b1l = *reinterpret_cast<const bf16x8*>(&sB[so + BSTAGE / 2 + (b1s - (0 ^ bx) + c) * 8]);
-    };
-    auto mfma6 = [&](const Frags& f) {
-        if (TR) {                                        // C^T: rows = channels, columns = pixels (see epilogue_tr)
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0h, f.al, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1h, f.al, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0l, f.ah, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1l, f.ah, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0h, f.ah, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1h, f.ah, acc1, 0, 0, 0);
-        } else {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b1h, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0l, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1l, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1h, acc1, 0, 0, 0);
-        }
-    };
-
-    // ---- software pipeline over the (tile, chunk, tap) sequence.  LDS: three weight stages (B(t), B(t+1), and
-    //   the one B(t+2) is being DMA'd into) and the footprint of tap t's chunk.  Tap t:
-    //     global: a slice of the next chunk's (or next tile's first) footprint -> registers; DMA B(t+3) -> LDS
-    //     LDS   : read the fragments of t's second k16 step          (covered by the 6 MFMAs below)
-    //     6 MFMAs on the first k16 step (fragments read during tap t-1)
-    //     LDS   : read the fragments of (t+1)'s first k16 step       (covered by the 6 MFMAs below)
-    //     6 MFMAs on the second k16 step
-    //     wait for this wave's share of B(t+2) (vmcnt counts in order: everything but this tap's own loads), barrier:
-    //     the next tap reads B(t+2) in its second half
-    //   The last tap of a chunk swaps the footprint between its two MFMA groups (two extra barriers); the last tap
-    //   of a tile is followed by the epilogue, whose stores drain behind the next tile's taps.
-    constexpr int FPT = (NFV + NT - 2) / (NT - 1);   // footprint slices per tap (taps 0 .. NT-2 of a chunk)
-    const int nchunk = p.Cin / XBK;
-#pragma unroll
-    for (int q = 0; q < NFV; ++q) fetch_fp_part(q, g.p_lo, 0);
-    static_assert(NT >= 3 || NT == 2, "");
-    dma_b(0, 0, 0);
-    dma_b(2 * BSTAGE, 1 % NT, (1 / NT) * XBK);
-    dma_b(4 * BSTAGE, 2 % NT, (2 / NT) * XBK);       // (a 2-tap kernel in a 1-chunk layer re-reads tap 0: harmless, never used)
-    stage_fp();
-    wait_vmcnt<0>();
-    __syncthreads();
-    Frags fa, fb;                                    // fa: first k16 step of the current tap, fb: second
-    read_frags(fa, g, 0, 0, 0, 0);
-    int st[4] = {0, 2 * BSTAGE, 4 * BSTAGE, 6 * BSTAGE};   // byte offsets of the stages of B(t), B(t+1), B(t+2), B(t+3) at tap j = 0
-
-    for (; tile < tile_end; ++tile) {
-        const bool last_tile = tile + 1 == tile_end;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const int c0 = ch * XBK;
-            const bool last_chunk = ch + 1 == nchunk;
-            const bool fin = last_chunk && last_tile;            // nothing follows this chunk
-            if (last_chunk && !last_tile) gn = geometry(tile + 1);
-            const int nx_plo = last_chunk ? gn.p_lo : g.p_lo;    // where the next chunk's footprint comes from
-            const int nx_c0 = last_chunk ? 0 : c0 + XBK;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const bool has1 = j + 1 < NT || !fin;
-                const bool has3 = j + 3 < NT || !fin;
-                const int st0 = st[j % 4], st1 = st[(j + 1) % 4], st3 = st[(j + 3) % 4];   // stages of B(t), B(t+1), B(t+3)
-                // footprint slices of this tap (compile-time count: the wait below must know it exactly)
-                const int q_lo = j < NT - 1 ? (j * FPT < NFV ? j * FPT : NFV) : NFV;
-                const int q_hi = j < NT - 1 ? ((j + 1) * FPT < NFV ? (j + 1) * FPT : NFV) : NFV;
-                if (!fin) {
-#pragma unroll
-                    for (int q = q_lo; q < q_hi; ++q) fetch_fp_part(q, nx_plo, nx_c0);
-                }
-                if (has3) dma_b(st3, (j + 3) % NT, (j + 3) >= NT ? ((j + 3) >= 2 * NT ? nx_c0 + XBK : nx_c0) : c0);
-                read_frags(fb, g, j / KW, j % KW, 1, st0);
-                mfma6(fa);
-                if (has1) {
-                    if (j == NT - 1) {               // tap t+1 opens the next chunk: swap the footprint.  Every wave
-                        __syncthreads();             // must have its fb reads back before anyone overwrites it
-                        stage_fp();
-                        __syncthreads();
-                    }
-                    read_frags(fa, (j == NT - 1 && last_chunk) ? gn : g, ((j + 1) % NT) / KW, ((j + 1) % NT) % KW, 0, st1);
-                }
-                mfma6(fb);
-                // B(t+1) was DMA'd during tap t-1; vmcnt counts in order, so allow exactly this tap's own VMEM
-                // operations (its footprint loads + 2 DMAs) to stay in flight.  hipcc's own waits for the footprint
-                // loads do not know about the DMAs, which only makes them stricter.
-                if (!fin) {
-                    if (q_hi - q_lo == 0) wait_vmcnt<2>();
-                    else if (q_hi - q_lo == 1) wait_vmcnt<3>();
-                    else if (q_hi - q_lo == 2) wait_vmcnt<4>();
-                    else if (q_hi - q_lo == 3) wait_vmcnt<5>();
-                    else if (q_hi - q_lo == 4) wait_vmcnt<6>();
-                    else wait_vmcnt<0>();
-                } else if (has3) {
-                    wait_vmcnt<2>();
-                } else {
-                    wait_vmcnt<0>();
-                }
-                __builtin_amdgcn_s_barrier();
-            }
-            // rotate the stage roles by NT taps
-            if (NT % 4 != 0) {
-                const int t0 = st[0], t1 = st[1], t2 = st[2], t3 = st[3];
-                const int r[4] = {t0, t1, t2, t3};
-                st[0] = r[NT % 4]; st[1] = r[(NT + 1) % 4]; st[2] = r[(NT + 2) % 4]; st[3] = r[(NT + 3) % 4];
-            }
-        }
-        if (TR) {
-            epilogue_tr(p, acc0, acc1, (long long)tile * BM + wv * 32 + li, n0, lh);
-        } else {
-            epilogue_tile(p, acc0, (long long)tile * BM + wv * 32, n0 + li, lh);
-            epilogue_tile(p, acc1, (long long)tile * BM + wv * 32, n0 + 32 + li, lh);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-        g = gn;
     }
 }
 
@@ -1092,7 +574,6 @@ namespace {
 
 // Kernel shapes conv_x3_fp_kernel is instantiated for (the tap loop is unrolled at compile time);
 // other shapes run on conv_x3_kernel.
-#define ISS_FP_SHAPES(X) X(3, 3) X(5, 3) X(3, 5) X(5, 5) X(2, 2) X(4, 4) X(1, 3) X(3, 1)
 inline bool fp_shape_compiled(int kh, int kw) {
 #define ISS_FP_HAS(KH_, KW_) if (kh == KH_ && kw == KW_) return true;
     ISS_FP_SHAPES(ISS_FP_HAS)
@@ -1193,13 +674,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             if (fp) {
                 const bool padded = a.pt_ != 0 || a.pl_ != 0 ||
                                     (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
-#define ISS_FP_CASE(KH_, KW_)                                                                              \
-    if (a.H_k == KH_ && a.kw == KW_) {                                                                     \
-        if (padded && tr) hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, true, true>), pgrid, dim3(256), 0, c->stream, a);       \
-        else if (padded) hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, true, false>), pgrid, dim3(256), 0, c->stream, a);       \
-        else if (tr) hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, false, true>), pgrid, dim3(256), 0, c->stream, a);           \
-        else hipLaunchKernelGGL((conv_x3_fp_kernel<KH_, KW_, false, false>), pgrid, dim3(256), 0, c->stream, a);                  \
-    } else
+#define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr); else
                 const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent: 2 workgroups per CU
                 const bool tr = a.pp == 1 && a.Cout % 4 == 0;                   // float4 epilogue on transposed accumulators
                 ISS_FP_SHAPES(ISS_FP_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no footprint kernel for %dx%d", a.H_k, a.kw); }

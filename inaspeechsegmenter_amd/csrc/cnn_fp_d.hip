@@ -1,0 +1,7 @@
+// Instantiation unit of conv_x3_fp_kernel (conv_fp.h) for a subset of the filter shapes.
+#include "conv_fp.h"
+
+ISS_FP_DEFINE(2, 2)
+ISS_FP_DEFINE(4, 4)
+ISS_FP_DEFINE(1, 3)
+ISS_FP_DEFINE(3, 1)

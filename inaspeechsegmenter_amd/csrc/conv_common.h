@@ -1,0 +1,252 @@
+// Shared device code of the conv/dense GEMM kernels of libiss_hip.so: argument block, GEMM-row mapping, the fused
+// epilogues and the operand loaders.  Included by cnn.hip and by the cnn_fp_*.hip units that instantiate the
+// LDS-footprint kernel per filter shape (split so that `make -j` compiles them in parallel).
+#pragma once
+#include "iss_internal.h"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include <cstdlib>
+
+namespace issk {
+
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128;      // GEMM rows (output pixels) per workgroup
+constexpr int BN = 64;       // GEMM cols (output channels) per workgroup
+constexpr int BK = 16;       // k-tile of the f32 kernel
+constexpr int LDK = BK + 4;  // padded LDS row (floats): conflict-free ds_read_b128
+constexpr int XBK = 32;      // k-tile of the bf16x3 kernel (two k16 MFMA steps)
+constexpr int XLD = XBK + 8; // padded LDS row (bf16): 80 B, conflict-free ds_read_b128
+constexpr int KALIGN = 32;   // weight rows are padded to this many k
+
+struct ConvArgs {
+    const float* in;
+    const float* w;          // [Cout][Kpad] f32
+    const uint16_t* wh;      // [Cout][Kpad] bf16 hi part
+    const uint16_t* wl;      // [Cout][Kpad] bf16 lo part
+    const float* bias;       // [Cout] or null
+    const float* ps;         // post-activation scale [Cout] or null
+    const float* pt;         // post-activation shift
+    const float* res;        // residual, same shape as out, or null
+    float* out;
+    const int32_t* ktab;     // [Kpad] x {delta, (ky<<16)|kx}
+    const int32_t* win_row;  // PATCH mode
+    const float* stats;      // PATCH mode: {mean, std} per sample
+    const uint8_t* finite;   // PATCH mode
+    long long M;             // samples * Hq * Wq * pp   (GEMM rows)
+    long long img_stride;    // floats per input sample
+    int H, W, Cin, Cout;
+    int Hq, Wq;              // output grid the GEMM rows enumerate: pooled grid when pp > 1, else (Ho, Wo)
+    int ph, pw, pp;          // fused pool window (1,1,1 = none); rows m = q*pp + (dy*pw + dx)
+    int poolkind;            // 0 max, 1 avg
+    int H_k, kw;             // kernel height / width (vectorised loaders walk taps)
+    int sh, sw, pt_, pl_;
+    int row_stride, pix_stride;
+    int act, Kpad, mode;
+    unsigned nblk;           // M tiles (grid.x)
+    int dbg;                 // ISS_DBG experiment bits (0 in production)
+};
+
+// GEMM row -> (sample, oy, ox) of the convolution output it stands for
+__device__ __forceinline__ void map_row(const ConvArgs& p, long long m, int& b, int& oy, int& ox) {
+    long long q = m;
+    int dy = 0, dx = 0;
+    if (p.pp > 1) {
+        q = m / p.pp;
+        const int j = (int)(m - q * p.pp);
+        dy = j / p.pw; dx = j - dy * p.pw;
+    }
+    const int hw = p.Hq * p.Wq;
+    b = (int)(q / hw);
+    const int rem = (int)(q - (long long)b * hw);
+    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    oy = qy * p.ph + dy;
+    ox = qx * p.pw + dx;
+}
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed); give every XCD one contiguous
+// range of M tiles so that neighbouring tiles (which share im2col halos) hit the same L2.
+__device__ __forceinline__ unsigned tile_of_block(unsigned bid, unsigned nblk) {
+    const unsigned per = nblk >> 3;
+    if (per == 0 || bid >= per * 8) return bid;
+    return (bid & 7) * per + (bid >> 3);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return 1.f / (1.f + expf(-v));
+    if (act == 3) return tanhf(v);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Shared epilogue.  C/D layout of the 32x32 MFMAs (f32 and bf16 alike): col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5): every lane holds 4 groups of 4 CONSECUTIVE rows, so a
+// fused pool over 2 or 4 consecutive GEMM rows (rows are enumerated pool-window-major, see
+// map_row) is a max/mean over registers of one lane -- no shuffles, no LDS.
+// ACT: 0 none, 1 relu, -1 = read p.act at run time (sigmoid / tanh); PP: fused pool window size (1, 2, 4);
+// HAS_PS: post-activation scale/shift; HAS_RES: residual add.  The common combinations are compiled without any
+// per-element branch (the fully generic form, inlined 32 times per tile, was ~6000 ISA lines of mostly skipped code).
+template <int ACT, int PP, bool HAS_PS, bool HAS_RES>
+__device__ __forceinline__ void epilogue_impl(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
+    if (n >= p.Cout) return;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const float s = HAS_PS ? p.ps[n] : 1.f;
+    const float sh = HAS_PS ? p.pt[n] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const long long mb = mrow0 + 8 * g + 4 * lh;        // first of this lane's 4 consecutive rows
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x = acc[4 * g + i] + bias;
+            if (HAS_RES) { if (mb + i < p.M) x += p.res[(size_t)(mb + i) * p.Cout + n]; }
+            if (ACT == 1) x = fmaxf(x, 0.f);
+            else if (ACT == -1) x = apply_act(x, p.act);
+            if (HAS_PS) x = x * s + sh;
+            v[i] = x;
+        }
+        if (PP == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (mb + i < p.M) p.out[(size_t)(mb + i) * p.Cout + n] = v[i];
+        } else if (PP == 4) {
+            if (mb < p.M) {
+                const float r = p.poolkind == 0 ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]))
+                                                : (v[0] + v[1] + v[2] + v[3]) * 0.25f;
+                p.out[(size_t)(mb >> 2) * p.Cout + n] = r;
+            }
+        } else {                                             // PP == 2
+#pragma unroll
+            for (int i = 0; i < 4; i += 2)
+                if (mb + i < p.M) {
+                    const float r = p.poolkind == 0 ? fmaxf(v[i], v[i + 1]) : (v[i] + v[i + 1]) * 0.5f;
+                    p.out[(size_t)((mb + i) >> 1) * p.Cout + n] = r;
+                }
+        }
+    }
+}
+
+template <int PP>
+__device__ __forceinline__ void epilogue_pp(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
+    const bool ps = p.ps != nullptr;
+    if (p.res) {                                             // residual add (ResNet): run-time activation
+        if (ps) epilogue_impl<-1, PP, true, true>(p, acc, mrow0, n, lh);
+        else epilogue_impl<-1, PP, false, true>(p, acc, mrow0, n, lh);
+    } else if (p.act > 1) {                                  // sigmoid / tanh
+        if (ps) epilogue_impl<-1, PP, true, false>(p, acc, mrow0, n, lh);
+        else epilogue_impl<-1, PP, false, false>(p, acc, mrow0, n, lh);
+    } else if (p.act == 1) {
+        if (ps) epilogue_impl<1, PP, true, false>(p, acc, mrow0, n, lh);
+        else epilogue_impl<1, PP, false, false>(p, acc, mrow0, n, lh);
+    } else {
+        if (ps) epilogue_impl<0, PP, true, false>(p, acc, mrow0, n, lh);
+        else epilogue_impl<0, PP, false, false>(p, acc, mrow0, n, lh);
+    }
+}
+
+__device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
+    if (p.pp == 1) epilogue_pp<1>(p, acc, mrow0, n, lh);
+    else if (p.pp == 4) epilogue_pp<4>(p, acc, mrow0, n, lh);
+    else epilogue_pp<2>(p, acc, mrow0, n, lh);
+}
+
+// Epilogue of TRANSPOSED accumulators (the MFMAs were issued as W-fragment x A-fragment, i.e. C^T): lane = GEMM row
+// (pixel) m, register group g of tile t = output channels n0 + 32 t + 8 g + 4 lh + {0..3}.  Every access is a float4:
+// bias / scale / shift, the residual, and the store (8 x 16 B per lane and tile pair instead of 32 x 4 B).  Needs
+// pp == 1 and Cout % 4 == 0 (parameter offsets in the blob are multiples of 8 floats).
+__device__ __forceinline__ void epilogue_tr(const ConvArgs& p, const floatx16& acc0, const floatx16& acc1, long long m,
+                                            int n0, int lh) {
+    if (m >= p.M) return;
+    float* orow = p.out + (size_t)m * p.Cout;
+    const float* rrow = p.res ? p.res + (size_t)m * p.Cout : nullptr;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = n0 + 32 * t + 8 * g + 4 * lh;
+            if (c >= p.Cout) continue;
+            float4 v;
+            v.x = t == 0 ? acc0[4 * g + 0] : acc1[4 * g + 0];
+            v.y = t == 0 ? acc0[4 * g + 1] : acc1[4 * g + 1];
+            v.z = t == 0 ? acc0[4 * g + 2] : acc1[4 * g + 2];
+            v.w = t == 0 ? acc0[4 * g + 3] : acc1[4 * g + 3];
+            if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + c); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+            if (rrow) { const float4 r4 = *reinterpret_cast<const float4*>(rrow + c); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+            if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else if (p.act > 1) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
+            if (p.ps) {
+                const float4 s4 = *reinterpret_cast<const float4*>(p.ps + c), t4 = *reinterpret_cast<const float4*>(p.pt + c);
+                v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
+            }
+            *reinterpret_cast<float4*>(orow + c) = v;
+        }
+    }
+}
+
+// Unconditional loads: a load inside a divergent `if` makes hipcc put an `s_waitcnt vmcnt(0)` at the
+// join, right behind the load, which exposes the full memory latency in every k iteration.  So:
+// always load from a valid address (the tensor base when the element is out of bounds) and
+// select afterwards.
+__device__ __forceinline__ float4 ld4_or_zero(const float* base, long long off, bool ok) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (ok ? off : 0));
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ uint4 ldu4_or_zero(const uint16_t* base, size_t off, bool ok) {
+    const uint4 v = *reinterpret_cast<const uint4*>(base + (ok ? off : 0));
+    return ok ? v : make_uint4(0, 0, 0, 0);
+}
+
+// per-thread gather bookkeeping of one A row
+struct RowSrc {
+    long long base;
+    int iy0, ix0;
+    float mean, sd;
+    bool ok;
+};
+
+template <int MODE>
+__device__ __forceinline__ RowSrc row_source(const ConvArgs& p, long long m) {
+    RowSrc r;
+    r.ok = m < p.M;
+    int b, oy, ox;
+    map_row(p, r.ok ? m : 0, b, oy, ox);
+    r.iy0 = oy * p.sh - p.pt_;
+    r.ix0 = ox * p.sw - p.pl_;
+    r.mean = 0.f; r.sd = 1.f;
+    if (MODE == 2) {
+        r.base = (long long)p.win_row[b] * 24 + (long long)r.iy0 * 24 + r.ix0;
+        r.mean = p.stats[2 * b];
+        r.sd = p.stats[2 * b + 1];
+        r.ok = r.ok && p.finite[b];
+    } else if (MODE == 1 && p.win_row) {             // window of the resident vbx features: frame (start + ix), feature iy
+        r.base = ((long long)p.win_row[b] + r.ix0) * p.pix_stride + (long long)r.iy0 * p.row_stride;
+    } else {
+        r.base = (long long)b * p.img_stride + (long long)r.iy0 * p.row_stride + (long long)r.ix0 * p.pix_stride;
+    }
+    return r;
+}
+
+// one A element through the im2col table (scalar path: any Cin, and the z-normalised PATCH input)
+template <int MODE>
+__device__ __forceinline__ float gather_scalar(const ConvArgs& p, const RowSrc& r, int k) {
+    const int2 e = reinterpret_cast<const int2*>(p.ktab)[k];
+    const int iy = r.iy0 + (e.y >> 16), ix = r.ix0 + (e.y & 0xffff);
+    const bool ok = r.ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    float x = p.in[ok ? r.base + e.x : 0];
+    if (MODE == 2) x = (x - r.mean) / r.sd;
+    return ok ? x : 0.f;
+}
+
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi)  (v_cvt_pk_bf16_f32, round to nearest even)
+__device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& l) {
+    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+    l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+}
+
+}  // namespace issk
