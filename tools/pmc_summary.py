@@ -19,7 +19,7 @@ def short(name):
 
 def main():
     db = sys.argv[1]
-    filt = sys.argv[2:] or ['conv_', 'sidekit_kernel', 'pool_kernel', 'patch_stats', 'softmax_kernel', 'vbx_', 'statpool']
+    filt = sys.argv[2:] or ['conv_', 'conv1_', 'sidekit_kernel', 'pool_kernel', 'patch_stats', 'softmax_kernel', 'vbx_', 'statpool']
     c = sqlite3.connect(db)
     out = {}
     q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration), avg(grid_size), avg(vgpr_count), "
