@@ -38,8 +38,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float sB[2][BN * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long m0 = (long long)tile_of_block(blockIdx.x, p.nblk) * BM;
-    const int n0 = blockIdx.y * BN;
+    unsigned mt, nt;
+    gemm_tile_of_block(blockIdx.x, p.nblk, p.nblk_n, mt, nt);
+    const long long m0 = (long long)mt * BM;
+    const int n0 = (int)nt * BN;
 
     // this thread fills (row lr, k4) and (row lr+64, k4) of sA
     const int k4 = tid & 3;
@@ -125,16 +127,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 // MODE: 0 = NHWC with Cin % 32 == 0 (a k-tile is 32 consecutive channels of ONE tap: float4
 //           gathers, no table), 1 = NHWC scalar gathers, 2 = z-normed patch.
 
-template <int MODE, bool TR>
-__global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs p) {
+// NTN = 32-column accumulator tiles per wavefront: the workgroup covers 128 rows x 32*NTN output channels.  NTN = 2 is
+// the 128 x 64 tile of the other kernels; NTN = 4 / 8 (Cout >= 128 / 256) stage and split the A tile once for 128 / 256
+// channels -- the ResNet 1x1 expansions (K = 32..256, N up to 1024) were bound by re-reading A once per 64 channels.
+template <int MODE, bool TR, int NTN>
+__global__ __launch_bounds__(256, NTN <= 4 ? 2 : 1) void conv_x3_kernel(const ConvArgs p) {
+    constexpr int BNX = 32 * NTN;                    // output channels per workgroup
+    constexpr int NBR = BNX / 64;                    // weight rows per thread and k-tile (rows br + 64 j)
     __shared__ __attribute__((aligned(16))) uint16_t sAh[2][BM * XLD];
     __shared__ __attribute__((aligned(16))) uint16_t sAl[2][BM * XLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sBh[2][BN * XLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sBl[2][BN * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBh[2][BNX * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBl[2][BNX * XLD];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long long m0 = (long long)tile_of_block(blockIdx.x, p.nblk) * BM;
-    const int n0 = blockIdx.y * BN;
+    unsigned mt, nt;
+    gemm_tile_of_block(blockIdx.x, p.nblk, p.nblk_n, mt, nt);
+    const long long m0 = (long long)mt * BM;
+    const int n0 = (int)nt * BNX;
 
     // A staging: thread fills k columns [4*k8, 4*k8+4) of rows lr, lr+32, lr+64, lr+96
     const int k8 = tid & 7;
@@ -142,13 +151,15 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs p) {
     RowSrc rs[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rs[j] = row_source<MODE>(p, m0 + lr + 32 * j);
-    // B staging: thread fills 8 bf16 (16 B) of weight row br, for hi and lo
+    // B staging: thread fills 8 bf16 (16 B) of weight rows br + 64 j, for hi and lo.  Rows >= Cout read row 0:
+    // their output columns are never stored.
     const int br = tid >> 2, bseg = tid & 3;
-    const bool bok = n0 + br < p.Cout;
-    const size_t boff = (size_t)(bok ? n0 + br : 0) * p.Kpad + bseg * 8;
+    size_t boff[NBR];
+#pragma unroll
+    for (int j = 0; j < NBR; ++j) boff[j] = (size_t)(n0 + br + 64 * j < p.Cout ? n0 + br + 64 * j : 0) * p.Kpad + bseg * 8;
 
     float4 ra[4];
-    uint4 rbh, rbl;
+    uint4 rbh[NBR], rbl[NBR];
     int tap_ky = 0, tap_kx = 0, tap_c = 0;          // MODE 0: tap walked by the NEXT gather
     auto gather = [&](int kt) {
         if (MODE == 0) {
@@ -168,8 +179,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs p) {
                 ra[j] = make_float4(gather_scalar<MODE>(p, rs[j], kbase), gather_scalar<MODE>(p, rs[j], kbase + 1),
                                     gather_scalar<MODE>(p, rs[j], kbase + 2), gather_scalar<MODE>(p, rs[j], kbase + 3));
         }
-        rbh = *reinterpret_cast<const uint4*>(p.wh + boff + (size_t)kt * XBK);   // rows >= Cout read row 0: never stored
-        rbl = *reinterpret_cast<const uint4*>(p.wl + boff + (size_t)kt * XBK);
+#pragma unroll
+        for (int j = 0; j < NBR; ++j) {
+            rbh[j] = *reinterpret_cast<const uint4*>(p.wh + boff[j] + (size_t)kt * XBK);
+            rbl[j] = *reinterpret_cast<const uint4*>(p.wl + boff[j] + (size_t)kt * XBK);
+        }
     };
     auto stage = [&](int buf) {
 #pragma unroll
@@ -179,13 +193,18 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs p) {
             *reinterpret_cast<bf16x4*>(&sAh[buf][(lr + 32 * j) * XLD + k8 * 4]) = h;
             *reinterpret_cast<bf16x4*>(&sAl[buf][(lr + 32 * j) * XLD + k8 * 4]) = l;
         }
-        *reinterpret_cast<uint4*>(&sBh[buf][br * XLD + bseg * 8]) = rbh;
-        *reinterpret_cast<uint4*>(&sBl[buf][br * XLD + bseg * 8]) = rbl;
+#pragma unroll
+        for (int j = 0; j < NBR; ++j) {
+            *reinterpret_cast<uint4*>(&sBh[buf][(br + 64 * j) * XLD + bseg * 8]) = rbh[j];
+            *reinterpret_cast<uint4*>(&sBl[buf][(br + 64 * j) * XLD + bseg * 8]) = rbl[j];
+        }
     };
 
-    floatx16 acc0, acc1;
+    floatx16 acc[NTN];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int t = 0; t < NTN; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     const int nk = p.Kpad / XBK;
     gather(0);
@@ -202,34 +221,30 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs p) {
         for (int ks = 0; ks < 2; ++ks) {
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sAh[cur][aoff + ks * 16]);
             const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sAl[cur][aoff + ks * 16]);
-            const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + ks * 16]);
-            const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + ks * 16]);
-            const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + 32 * XLD + ks * 16]);
-            const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + 32 * XLD + ks * 16]);
-            if (TR) {                                    // C^T: rows = channels, columns = pixels (see epilogue_tr)
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0h, al, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1h, al, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0l, ah, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1l, ah, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0h, ah, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1h, ah, acc1, 0, 0, 0);
-            } else {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NTN; ++t) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + t * 32 * XLD + ks * 16]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + t * 32 * XLD + ks * 16]);
+                if (TR) {                                // C^T: rows = channels, columns = pixels (see epilogue_tr)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[t], 0, 0, 0);
+                } else {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                }
             }
         }
         if (kt + 1 < nk) stage(cur ^ 1);
         __syncthreads();
     }
     if (TR) {
-        epilogue_tr(p, acc0, acc1, m0 + wv * 32 + li, n0, lh);
+#pragma unroll
+        for (int t = 0; t < NTN; t += 2) epilogue_tr(p, acc[t], acc[t + 1], m0 + wv * 32 + li, n0 + 32 * t, lh);
     } else {
-        epilogue_tile(p, acc0, m0 + wv * 32, n0 + li, lh);
-        epilogue_tile(p, acc1, m0 + wv * 32, n0 + 32 + li, lh);
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) epilogue_tile(p, acc[t], m0 + wv * 32, n0 + 32 * t + li, lh);
     }
 }
 
@@ -660,7 +675,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             }
             a.nblk = (unsigned)((a.M + BM - 1) / BM);
             { static const int dbg = getenv("ISS_DBG") ? atoi(getenv("ISS_DBG")) : 0; a.dbg = dbg; }
-            dim3 grid(a.nblk, (unsigned)((a.Cout + BN - 1) / BN));
+            a.nblk_n = (unsigned)((a.Cout + BN - 1) / BN);
+            dim3 grid(a.nblk, a.nblk_n);
+            const dim3 grid1(a.nblk * a.nblk_n);          // generic kernels: 1-D, XCD-aware (gemm_tile_of_block)
             const double fl = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * a.Cin * (double)a.Cout * (double)a.M;
             iss_prof_begin(c, 0, fl);
             bool fp = false;
@@ -686,15 +703,22 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 else hipLaunchKernelGGL(conv1_patch_x3_kernel<false>, pgrid, dim3(256), 0, c->stream, a);
             } else if (x3) {
                 const bool tr = a.pp == 1 && a.Cout % 4 == 0;     // float4 epilogue on transposed accumulators
-                if (a.mode == 0 && tr) hipLaunchKernelGGL((conv_x3_kernel<0, true>), grid, dim3(256), 0, c->stream, a);
-                else if (a.mode == 0) hipLaunchKernelGGL((conv_x3_kernel<0, false>), grid, dim3(256), 0, c->stream, a);
-                else if (a.mode == 1 && tr) hipLaunchKernelGGL((conv_x3_kernel<1, true>), grid, dim3(256), 0, c->stream, a);
-                else if (a.mode == 1) hipLaunchKernelGGL((conv_x3_kernel<1, false>), grid, dim3(256), 0, c->stream, a);
-                else hipLaunchKernelGGL((conv_x3_kernel<2, false>), grid, dim3(256), 0, c->stream, a);
+                // wider N tiles for wide layers (A staged once per 128 / 256 output channels); 1-D XCD-aware grid
+                // NTN = 4 (128 x 128 tiles) is compiled but not selected: with the XCD-aware order the A tile is re-read from
+                // L2, not from HBM, and the wider tiles (fewer, fatter workgroups) measured 6 % SLOWER on ResNet-101
+                const int ntn = 2;
+                a.nblk_n = (unsigned)((a.Cout + 32 * ntn - 1) / (32 * ntn));
+                const dim3 gridw(a.nblk * a.nblk_n);
+                if (ntn == 4) hipLaunchKernelGGL((conv_x3_kernel<0, true, 4>), gridw, dim3(256), 0, c->stream, a);
+                else if (a.mode == 0 && tr) hipLaunchKernelGGL((conv_x3_kernel<0, true, 2>), gridw, dim3(256), 0, c->stream, a);
+                else if (a.mode == 0) hipLaunchKernelGGL((conv_x3_kernel<0, false, 2>), gridw, dim3(256), 0, c->stream, a);
+                else if (a.mode == 1 && tr) hipLaunchKernelGGL((conv_x3_kernel<1, true, 2>), gridw, dim3(256), 0, c->stream, a);
+                else if (a.mode == 1) hipLaunchKernelGGL((conv_x3_kernel<1, false, 2>), gridw, dim3(256), 0, c->stream, a);
+                else hipLaunchKernelGGL((conv_x3_kernel<2, false, 2>), gridw, dim3(256), 0, c->stream, a);
             } else {
-                if (a.mode == 0) hipLaunchKernelGGL(conv_igemm_kernel<0>, grid, dim3(256), 0, c->stream, a);
-                else if (a.mode == 1) hipLaunchKernelGGL(conv_igemm_kernel<1>, grid, dim3(256), 0, c->stream, a);
-                else hipLaunchKernelGGL(conv_igemm_kernel<2>, grid, dim3(256), 0, c->stream, a);
+                if (a.mode == 0) hipLaunchKernelGGL(conv_igemm_kernel<0>, grid1, dim3(256), 0, c->stream, a);
+                else if (a.mode == 1) hipLaunchKernelGGL(conv_igemm_kernel<1>, grid1, dim3(256), 0, c->stream, a);
+                else hipLaunchKernelGGL(conv_igemm_kernel<2>, grid1, dim3(256), 0, c->stream, a);
             }
             iss_prof_end(c);
         } else if (op == ISS_OP_POOL) {

@@ -47,7 +47,8 @@ struct ConvArgs {
     int sh, sw, pt_, pl_;
     int row_stride, pix_stride;
     int act, Kpad, mode;
-    unsigned nblk;           // M tiles (grid.x)
+    unsigned nblk;           // M tiles
+    unsigned nblk_n;         // N tiles (generic kernels are launched 1-D: nblk * nblk_n workgroups)
     int dbg;                 // ISS_DBG experiment bits (0 in production)
 };
 
@@ -240,6 +241,24 @@ __device__ __forceinline__ float gather_scalar(const ConvArgs& p, const RowSrc& 
     float x = p.in[ok ? r.base + e.x : 0];
     if (MODE == 2) x = (x - r.mean) / r.sd;
     return ok ? x : 0.f;
+}
+
+// 1-D launch of an (M tiles x N tiles) GEMM grid with the N tiles of one M tile placed on ONE XCD, back to back:
+// workgroup id runs on XCD id % 8 (observed), so XCD x takes the M tiles congruent to x (mod 8) and walks their N tiles
+// fastest.  The A tile of an M tile is then fetched from HBM once and re-read from that XCD's L2 by the other N tiles
+// (with a 2-D grid the 8 N tiles of a 512-channel layer landed on 8 different XCDs and re-fetched A 8 times).
+__device__ __forceinline__ void gemm_tile_of_block(unsigned bid, unsigned nblk_m, unsigned nblk_n, unsigned& mtile, unsigned& ntile) {
+    const unsigned groups = nblk_m >> 3;                  // complete groups of 8 M tiles
+    const unsigned cut = groups * 8 * nblk_n;             // workgroups covered by the XCD-aware mapping
+    if (bid < cut) {
+        const unsigned x = bid & 7, l = bid >> 3;
+        mtile = x + 8 * (l / nblk_n);
+        ntile = l % nblk_n;
+    } else {                                              // the last < 8 M tiles: plain order
+        const unsigned r = bid - cut;
+        mtile = groups * 8 + r / nblk_n;
+        ntile = r % nblk_n;
+    }
 }
 
 // x = hi + lo with hi = bf16(x), lo = bf16(x - hi)  (v_cvt_pk_bf16_f32, round to nearest even)
