@@ -357,6 +357,43 @@ __global__ __launch_bounds__(256, 2) void conv1_patch_x3_kernel(const ConvArgs p
 
 // ------------------------------------------------------------------------------------------
 // Per-slot statistics of the 68 x h log-mel window: mean, population std, finite flag.
+// Shared first layer (ConvArgs::f_*): the PATCH conv without its per-window normalisation, once per log-mel row:
+//   R[t][x][c] = sum_{ky,kx} w[c][ky * kw + kx] * mspec[(row0 + t + ky) * 24 + x + kx]       (f32, FMA chain in k order)
+// One thread per (t, x, 4 channels).  Non-finite results are stored as 0: they only ever reach windows whose finite
+// flag is 0, and those are scaled by 0 (their normalised input is all zeros in the reference, segmenter.py:86-88).
+__global__ __launch_bounds__(256) void first_layer_raw_kernel(const float* __restrict__ mspec, int row0, long long total,
+                                                              int Wout, int Cout, int kh, int kw,
+                                                              const float* __restrict__ w, int Kpad, float* __restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];     // [K][Cout]: a lane's 4 channels of tap k are one ds_read_b128
+    const int K = kh * kw;
+    for (int e = threadIdx.x; e < K * Cout; e += 256) {
+        const int co = e / K, k = e - co * K;
+        sW[k * Cout + co] = w[(size_t)co * Kpad + k];
+    }
+    __syncthreads();
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cg = Cout >> 2;
+    const int c4 = (int)(idx % cg) * 4;
+    const long long pix = idx / cg;
+    const int x = (int)(pix % Wout);
+    const long long t = pix / Wout;
+    const float* src = mspec + (size_t)(row0 + t) * 24 + x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < kw; ++kx) {
+            const float v = src[ky * 24 + kx];
+            const float4 wk = *reinterpret_cast<const float4*>(&sW[(ky * kw + kx) * Cout + c4]);
+            a0 = fmaf(v, wk.x, a0);
+            a1 = fmaf(v, wk.y, a1);
+            a2 = fmaf(v, wk.z, a2);
+            a3 = fmaf(v, wk.w, a3);
+        }
+    float4 o;
+    o.x = isfinite(a0) ? a0 : 0.f; o.y = isfinite(a1) ? a1 : 0.f; o.z = isfinite(a2) ? a2 : 0.f; o.w = isfinite(a3) ? a3 : 0.f;
+    *reinterpret_cast<float4*>(R + idx * 4) = o;
+}
+
 // One wavefront per slot.  segmenter.py:82 (np.mean / np.std over the flattened window) and
 // :86 (finite = all(isfinite(normalised))).
 __global__ __launch_bounds__(256) void patch_stats_kernel(const float* __restrict__ mspec,
@@ -488,6 +525,7 @@ int iss_cnn_free(iss_ctx* c, int id) {
     if (n.d_blob) (void)hipFree(n.d_blob);
     if (n.d_wh) (void)hipFree(n.d_wh);
     if (n.d_wl) (void)hipFree(n.d_wl);
+    if (n.d_wsum) (void)hipFree(n.d_wsum);
     if (n.d_ktab) (void)hipFree(n.d_ktab);
     n = IssNet();
     return ISS_OK;
@@ -563,6 +601,26 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
         ISS_HIP(c, hipMemcpy(n.d_wh, hi.data(), (size_t)blob_floats * 2, hipMemcpyHostToDevice));
         ISS_HIP(c, hipMemcpy(n.d_wl, lo.data(), (size_t)blob_floats * 2, hipMemcpyHostToDevice));
     }
+    {   // per-channel weight sums of the patch-mode first layers (ConvArgs::f_wsum)
+        std::vector<float> wsum;
+        n.wsum_off.assign(nrows, -1);
+        for (int r = 0; r < nrows; ++r) {
+            const int32_t* R = &n.prog[(size_t)r * ISS_PROG_COLS];
+            if (R[ISS_C_OP] != ISS_OP_CONV || R[ISS_C_INMODE] != 1) continue;
+            const int K = R[ISS_C_KH] * R[ISS_C_KW] * R[ISS_C_CIN];
+            n.wsum_off[r] = (int64_t)wsum.size();
+            for (int co = 0; co < R[ISS_C_COUT]; ++co) {
+                double acc = 0.0;
+                for (int k = 0; k < K; ++k) acc += (double)blob[R[ISS_C_WOFF] + (int64_t)co * n.kpad[r] + k];
+                wsum.push_back((float)acc);
+            }
+            while (wsum.size() % 8) wsum.push_back(0.f);         // float4-aligned rows
+        }
+        if (!wsum.empty()) {
+            ISS_HIP(c, hipMalloc((void**)&n.d_wsum, wsum.size() * sizeof(float)));
+            ISS_HIP(c, hipMemcpy(n.d_wsum, wsum.data(), wsum.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
     if (!ktab.empty()) {
         ISS_HIP(c, hipMalloc((void**)&n.d_ktab, ktab.size() * sizeof(int32_t)));
         ISS_HIP(c, hipMemcpy(n.d_ktab, ktab.data(), ktab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -626,101 +684,171 @@ bool footprint_fits(const ConvArgs& a) {
 }
 
 // Run the op program on `bc` samples.  src: PATCH mode uses (d_winrow + s0, stats, finite),
-// otherwise `d_input` is an NHWC batch.  The result is left in act[last OUT].
+// otherwise `d_input` is an NHWC batch.  The result is left in act[last OUT].  [rmin, rmax] = range of the window rows
+// of this call; share_first: the caller's (chunking-independent) decision to use the shared first layer.
 int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const float* d_stats,
-                const uint8_t* d_fin, const float* d_input, float** result) {
+                const uint8_t* d_fin, const float* d_input, float** result, int rmin = 0, int rmax = -1,
+                bool share_first = false) {
+    const bool x3mode = c->precision == ISS_PREC_BF16X3;
+    // A PATCH first layer directly in front of a footprint-kernel conv is not launched per window: it is computed once
+    // per log-mel row and the second conv normalises it per window while staging its LDS footprint (ConvArgs::f_*,
+    // conv_fp.h FUSED).  Static part of the test; the footprint-capacity part is decided when the second row is reached
+    // (the first layer is then launched per window after all).
+    auto can_defer = [&](int r) {
+        if (!x3mode || r + 1 >= n.nrows || !share_first || rmax < rmin) return false;
+        const int32_t* R1 = &n.prog[(size_t)r * ISS_PROG_COLS];
+        const int32_t* R2 = &n.prog[(size_t)(r + 1) * ISS_PROG_COLS];
+        int ph, pw;
+        fused_pool_of(R1, ph, pw);
+        if (R1[ISS_C_OP] != ISS_OP_CONV || R1[ISS_C_INMODE] != 1 || ph * pw != 1 || R1[ISS_C_RES] >= 0 || R1[ISS_C_ACT] > 1) return false;
+        if (R1[ISS_C_CIN] != 1 || R1[ISS_C_SH] != 1 || R1[ISS_C_SW] != 1 || R1[ISS_C_PT] != 0 || R1[ISS_C_PL] != 0) return false;
+        if (R1[ISS_C_HO] != R1[ISS_C_H] - R1[ISS_C_KH] + 1 || R1[ISS_C_WO] != R1[ISS_C_W] - R1[ISS_C_KW] + 1) return false;   // 'valid'
+        if (R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4 > 48 * 1024) return false;        // first_layer_raw_kernel's LDS weights
+        if (R1[ISS_C_BOFF] < 0 || R1[ISS_C_PSOFF] >= 0 || R1[ISS_C_PTOFF] >= 0 || R1[ISS_C_COUT] % 4 != 0 || n.wsum_off[r] < 0) return false;
+        if (R2[ISS_C_OP] != ISS_OP_CONV || R2[ISS_C_INMODE] != 0 || R2[ISS_C_IN] != R1[ISS_C_OUT] || R2[ISS_C_RES] >= 0) return false;
+        if (R2[ISS_C_CIN] != R1[ISS_C_COUT] || R2[ISS_C_CIN] % XBK != 0 || R2[ISS_C_H] != R1[ISS_C_HO] || R2[ISS_C_W] != R1[ISS_C_WO]) return false;
+        if (R2[ISS_C_KH] * R2[ISS_C_KW] < 12 || !fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW])) return false;
+        if (R2[ISS_C_PT] != 0 || R2[ISS_C_PL] != 0 || (R2[ISS_C_HO] - 1) * R2[ISS_C_SH] + R2[ISS_C_KH] > R2[ISS_C_H] ||
+            (R2[ISS_C_WO] - 1) * R2[ISS_C_SW] + R2[ISS_C_KW] > R2[ISS_C_W]) return false;
+        // the footprint may touch two windows at most, and the x / W trick of the kernel needs a small W
+        if (R2[ISS_C_H] * R2[ISS_C_W] < FPIX + 32 || R2[ISS_C_W] > 128) return false;
+        for (int q = r + 2; q < n.nrows; ++q) {                  // nobody else may read the first layer's output
+            const int32_t* Q = &n.prog[(size_t)q * ISS_PROG_COLS];
+            if (Q[ISS_C_IN] == R1[ISS_C_OUT] || Q[ISS_C_RES] == R1[ISS_C_OUT]) return false;
+            if (Q[ISS_C_OUT] == R1[ISS_C_OUT]) break;
+        }
+        return true;
+    };
+    std::function<int(int, int)> conv_row = [&](int r, int pend) -> int {
+        const int32_t* R = &n.prog[(size_t)r * ISS_PROG_COLS];
+        const float* in = R[ISS_C_IN] == ISS_BUF_INPUT ? d_input : (const float*)c->act[R[ISS_C_IN]].p;
+        float* out = (float*)c->act[R[ISS_C_OUT]].p;
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = in;
+        a.w = n.d_blob + R[ISS_C_WOFF];
+        a.bias = R[ISS_C_BOFF] >= 0 ? n.d_blob + R[ISS_C_BOFF] : nullptr;
+        a.ps = R[ISS_C_PSOFF] >= 0 ? n.d_blob + R[ISS_C_PSOFF] : nullptr;
+        a.pt = R[ISS_C_PTOFF] >= 0 ? n.d_blob + R[ISS_C_PTOFF] : nullptr;
+        a.res = R[ISS_C_RES] >= 0 ? (const float*)c->act[R[ISS_C_RES]].p : nullptr;
+        a.out = out;
+        a.ktab = n.d_ktab + n.ktab_off[r];
+        a.wh = n.d_wh + R[ISS_C_WOFF];
+        a.wl = n.d_wl + R[ISS_C_WOFF];
+        a.H = R[ISS_C_H]; a.W = R[ISS_C_W]; a.Cin = R[ISS_C_CIN]; a.Cout = R[ISS_C_COUT];
+        fused_pool_of(R, a.ph, a.pw);
+        a.pp = a.ph * a.pw;
+        a.poolkind = R[ISS_C_POOLKIND];
+        a.Hq = R[ISS_C_HO] / a.ph; a.Wq = R[ISS_C_WO] / a.pw;
+        a.H_k = R[ISS_C_KH]; a.kw = R[ISS_C_KW];
+        a.sh = R[ISS_C_SH]; a.sw = R[ISS_C_SW]; a.pt_ = R[ISS_C_PT]; a.pl_ = R[ISS_C_PL];
+        a.act = R[ISS_C_ACT]; a.Kpad = n.kpad[r];
+        a.M = (long long)bc * a.Hq * a.Wq * a.pp;
+        const bool patch = R[ISS_C_INMODE] == 1;
+        const bool x3 = c->precision == ISS_PREC_BF16X3;
+        a.mode = patch ? 2 : ((a.Cin % (x3 ? XBK : 4) == 0) ? 0 : 1);
+        const bool window = R[ISS_C_INMODE] == 2;
+        if (patch) {
+            if (!d_winrow) return iss_fail(c, ISS_ESTATE, "patch-mode network run without a window list");
+            a.in = (const float*)c->mspec.p; a.win_row = d_winrow; a.stats = d_stats; a.finite = d_fin;
+            a.row_stride = 24; a.pix_stride = 1; a.img_stride = 0;
+        } else if (window) {
+            if (!d_winrow || !c->vbx_out.p) return iss_fail(c, ISS_ESTATE, "window-mode network run without resident vbx features");
+            a.in = (const float*)c->vbx_out.p; a.win_row = d_winrow;
+            a.row_stride = 1; a.pix_stride = a.H; a.img_stride = 0;
+            a.mode = 1;
+        } else {
+            if (!in) return iss_fail(c, ISS_ESTATE, "network input missing");
+            a.row_stride = a.W * a.Cin; a.pix_stride = a.Cin; a.img_stride = (long long)a.H * a.W * a.Cin;
+        }
+        a.nblk = (unsigned)((a.M + BM - 1) / BM);
+        { static const int dbg = getenv("ISS_DBG") ? atoi(getenv("ISS_DBG")) : 0; a.dbg = dbg; }
+        a.nblk_n = (unsigned)((a.Cout + BN - 1) / BN);
+        dim3 grid(a.nblk, a.nblk_n);
+        const dim3 grid1(a.nblk * a.nblk_n);          // generic kernels: 1-D, XCD-aware (gemm_tile_of_block)
+        double fl = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * a.Cin * (double)a.Cout * (double)a.M;
+        bool fp = false;
+        if (x3 && a.mode == 0 && fp_shape_compiled(a.H_k, a.kw) && a.M < (1ll << 31) &&
+            (long long)bc * a.img_stride < (1ll << 32)) {
+            const long long key = ((long long)r << 32) | (unsigned)bc;
+            auto it = n.fp_ok.find(key);
+            if (it == n.fp_ok.end()) it = n.fp_ok.emplace(key, footprint_fits(a)).first;
+            fp = it->second;
+        }
+        const bool padded = a.pt_ != 0 || a.pl_ != 0 ||
+                            (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
+        bool fused = false;
+        if (pend >= 0) {
+            const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
+            fused = fp && !padded && a.H_k * a.kw >= 12 && d_winrow != nullptr &&
+                    ((long long)(rmax - rmin) + Rp[ISS_C_HO]) * Rp[ISS_C_WO] * Rp[ISS_C_COUT] < (1ll << 32);   // 32-bit offsets into R
+            if (!fused) {                                    // the deferred first layer runs on its own after all
+                const int rc = conv_row(pend, -1);
+                if (rc) return rc;
+            } else {
+                const int32_t* R1 = &n.prog[(size_t)pend * ISS_PROG_COLS];
+                const long long rrows = (long long)(rmax - rmin) + R1[ISS_C_HO];     // R: rows rmin .. rmax + H1 - 1
+                const long long rtot = rrows * R1[ISS_C_WO] * (R1[ISS_C_COUT] / 4);
+                { const int rc = iss_reserve(c, c->raw1, (size_t)rtot * 16); if (rc) return rc; }
+                float* Rraw = (float*)c->raw1.p;
+                iss_prof_begin(c, 2, 0);
+                hipLaunchKernelGGL(first_layer_raw_kernel, dim3((unsigned)((rtot + 255) / 256)), dim3(256),
+                                   (size_t)R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4, c->stream,
+                                   (const float*)c->mspec.p, rmin, rtot, R1[ISS_C_WO], R1[ISS_C_COUT], R1[ISS_C_KH], R1[ISS_C_KW],
+                                   (const float*)(n.d_blob + R1[ISS_C_WOFF]), n.kpad[pend], Rraw);
+                iss_prof_end(c);
+                a.in = Rraw; a.win_row = d_winrow; a.stats = d_stats; a.finite = d_fin;
+                a.f_bias = n.d_blob + R1[ISS_C_BOFF];
+                a.f_wsum = n.d_wsum + n.wsum_off[pend];
+                a.f_act = R1[ISS_C_ACT]; a.f_rmin = rmin;
+                fl += 2.0 * R1[ISS_C_KH] * R1[ISS_C_KW] * (double)R1[ISS_C_COUT] * (double)bc * R1[ISS_C_HO] * R1[ISS_C_WO];
+            }
+        }
+        iss_prof_begin(c, 0, fl);
+        if (fp) {
+#define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr, fused); else
+            const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent: 2 workgroups per CU
+            const bool tr = a.pp == 1 && a.Cout % 4 == 0;                   // float4 epilogue on transposed accumulators
+            ISS_FP_SHAPES(ISS_FP_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no footprint kernel for %dx%d", a.H_k, a.kw); }
+#undef ISS_FP_CASE
+        } else if (x3 && patch && a.H_k * a.kw <= XBK && a.M < (1ll << 31)) {
+            const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent, no barriers: 2 workgroups per CU
+            // blob offsets are multiples of 8 floats, so the float4 loads of bias / scale / shift are aligned
+            if (a.pp == 1 && a.Cout % 4 == 0 && !a.res) hipLaunchKernelGGL(conv1_patch_x3_kernel<true>, pgrid, dim3(256), 0, c->stream, a);
+            else hipLaunchKernelGGL(conv1_patch_x3_kernel<false>, pgrid, dim3(256), 0, c->stream, a);
+        } else if (x3) {
+            const bool tr = a.pp == 1 && a.Cout % 4 == 0;     // float4 epilogue on transposed accumulators
+            // wider N tiles for wide layers (A staged once per 128 / 256 output channels); 1-D XCD-aware grid
+            // NTN = 4 (128 x 128 tiles) is compiled but not selected: with the XCD-aware order the A tile is re-read from
+            // L2, not from HBM, and the wider tiles (fewer, fatter workgroups) measured 6 % SLOWER on ResNet-101
+            const int ntn = 2;
+            a.nblk_n = (unsigned)((a.Cout + 32 * ntn - 1) / (32 * ntn));
+            const dim3 gridw(a.nblk * a.nblk_n);
+            if (ntn == 4) hipLaunchKernelGGL((conv_x3_kernel<0, true, 4>), gridw, dim3(256), 0, c->stream, a);
+            else if (a.mode == 0 && tr) hipLaunchKernelGGL((conv_x3_kernel<0, true, 2>), gridw, dim3(256), 0, c->stream, a);
+            else if (a.mode == 0) hipLaunchKernelGGL((conv_x3_kernel<0, false, 2>), gridw, dim3(256), 0, c->stream, a);
+            else if (a.mode == 1 && tr) hipLaunchKernelGGL((conv_x3_kernel<1, true, 2>), gridw, dim3(256), 0, c->stream, a);
+            else if (a.mode == 1) hipLaunchKernelGGL((conv_x3_kernel<1, false, 2>), gridw, dim3(256), 0, c->stream, a);
+            else hipLaunchKernelGGL((conv_x3_kernel<2, false, 2>), gridw, dim3(256), 0, c->stream, a);
+        } else {
+            if (a.mode == 0) hipLaunchKernelGGL(conv_igemm_kernel<0>, grid1, dim3(256), 0, c->stream, a);
+            else if (a.mode == 1) hipLaunchKernelGGL(conv_igemm_kernel<1>, grid1, dim3(256), 0, c->stream, a);
+            else hipLaunchKernelGGL(conv_igemm_kernel<2>, grid1, dim3(256), 0, c->stream, a);
+        }
+        iss_prof_end(c);
+        return ISS_OK;
+    };
+    int pending = -1;                                            // deferred PATCH first layer (see can_defer)
     for (int r = 0; r < n.nrows; ++r) {
         const int32_t* R = &n.prog[(size_t)r * ISS_PROG_COLS];
         const float* in = R[ISS_C_IN] == ISS_BUF_INPUT ? d_input : (const float*)c->act[R[ISS_C_IN]].p;
         float* out = (float*)c->act[R[ISS_C_OUT]].p;
         const int op = R[ISS_C_OP];
         if (op == ISS_OP_CONV) {
-            ConvArgs a;
-            memset(&a, 0, sizeof(a));
-            a.in = in;
-            a.w = n.d_blob + R[ISS_C_WOFF];
-            a.bias = R[ISS_C_BOFF] >= 0 ? n.d_blob + R[ISS_C_BOFF] : nullptr;
-            a.ps = R[ISS_C_PSOFF] >= 0 ? n.d_blob + R[ISS_C_PSOFF] : nullptr;
-            a.pt = R[ISS_C_PTOFF] >= 0 ? n.d_blob + R[ISS_C_PTOFF] : nullptr;
-            a.res = R[ISS_C_RES] >= 0 ? (const float*)c->act[R[ISS_C_RES]].p : nullptr;
-            a.out = out;
-            a.ktab = n.d_ktab + n.ktab_off[r];
-            a.wh = n.d_wh + R[ISS_C_WOFF];
-            a.wl = n.d_wl + R[ISS_C_WOFF];
-            a.H = R[ISS_C_H]; a.W = R[ISS_C_W]; a.Cin = R[ISS_C_CIN]; a.Cout = R[ISS_C_COUT];
-            fused_pool_of(R, a.ph, a.pw);
-            a.pp = a.ph * a.pw;
-            a.poolkind = R[ISS_C_POOLKIND];
-            a.Hq = R[ISS_C_HO] / a.ph; a.Wq = R[ISS_C_WO] / a.pw;
-            a.H_k = R[ISS_C_KH]; a.kw = R[ISS_C_KW];
-            a.sh = R[ISS_C_SH]; a.sw = R[ISS_C_SW]; a.pt_ = R[ISS_C_PT]; a.pl_ = R[ISS_C_PL];
-            a.act = R[ISS_C_ACT]; a.Kpad = n.kpad[r];
-            a.M = (long long)bc * a.Hq * a.Wq * a.pp;
-            const bool patch = R[ISS_C_INMODE] == 1;
-            const bool x3 = c->precision == ISS_PREC_BF16X3;
-            a.mode = patch ? 2 : ((a.Cin % (x3 ? XBK : 4) == 0) ? 0 : 1);
-            const bool window = R[ISS_C_INMODE] == 2;
-            if (patch) {
-                if (!d_winrow) return iss_fail(c, ISS_ESTATE, "patch-mode network run without a window list");
-                a.in = (const float*)c->mspec.p; a.win_row = d_winrow; a.stats = d_stats; a.finite = d_fin;
-                a.row_stride = 24; a.pix_stride = 1; a.img_stride = 0;
-            } else if (window) {
-                if (!d_winrow || !c->vbx_out.p) return iss_fail(c, ISS_ESTATE, "window-mode network run without resident vbx features");
-                a.in = (const float*)c->vbx_out.p; a.win_row = d_winrow;
-                a.row_stride = 1; a.pix_stride = a.H; a.img_stride = 0;
-                a.mode = 1;
-            } else {
-                if (!in) return iss_fail(c, ISS_ESTATE, "network input missing");
-                a.row_stride = a.W * a.Cin; a.pix_stride = a.Cin; a.img_stride = (long long)a.H * a.W * a.Cin;
-            }
-            a.nblk = (unsigned)((a.M + BM - 1) / BM);
-            { static const int dbg = getenv("ISS_DBG") ? atoi(getenv("ISS_DBG")) : 0; a.dbg = dbg; }
-            a.nblk_n = (unsigned)((a.Cout + BN - 1) / BN);
-            dim3 grid(a.nblk, a.nblk_n);
-            const dim3 grid1(a.nblk * a.nblk_n);          // generic kernels: 1-D, XCD-aware (gemm_tile_of_block)
-            const double fl = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * a.Cin * (double)a.Cout * (double)a.M;
-            iss_prof_begin(c, 0, fl);
-            bool fp = false;
-            if (x3 && a.mode == 0 && fp_shape_compiled(a.H_k, a.kw) && a.M < (1ll << 31) &&
-                (long long)bc * a.img_stride < (1ll << 32)) {
-                const long long key = ((long long)r << 32) | (unsigned)bc;
-                auto it = n.fp_ok.find(key);
-                if (it == n.fp_ok.end()) it = n.fp_ok.emplace(key, footprint_fits(a)).first;
-                fp = it->second;
-            }
-            if (fp) {
-                const bool padded = a.pt_ != 0 || a.pl_ != 0 ||
-                                    (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
-#define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr); else
-                const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent: 2 workgroups per CU
-                const bool tr = a.pp == 1 && a.Cout % 4 == 0;                   // float4 epilogue on transposed accumulators
-                ISS_FP_SHAPES(ISS_FP_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no footprint kernel for %dx%d", a.H_k, a.kw); }
-#undef ISS_FP_CASE
-            } else if (x3 && patch && a.H_k * a.kw <= XBK && a.M < (1ll << 31)) {
-                const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent, no barriers: 2 workgroups per CU
-                // blob offsets are multiples of 8 floats, so the float4 loads of bias / scale / shift are aligned
-                if (a.pp == 1 && a.Cout % 4 == 0 && !a.res) hipLaunchKernelGGL(conv1_patch_x3_kernel<true>, pgrid, dim3(256), 0, c->stream, a);
-                else hipLaunchKernelGGL(conv1_patch_x3_kernel<false>, pgrid, dim3(256), 0, c->stream, a);
-            } else if (x3) {
-                const bool tr = a.pp == 1 && a.Cout % 4 == 0;     // float4 epilogue on transposed accumulators
-                // wider N tiles for wide layers (A staged once per 128 / 256 output channels); 1-D XCD-aware grid
-                // NTN = 4 (128 x 128 tiles) is compiled but not selected: with the XCD-aware order the A tile is re-read from
-                // L2, not from HBM, and the wider tiles (fewer, fatter workgroups) measured 6 % SLOWER on ResNet-101
-                const int ntn = 2;
-                a.nblk_n = (unsigned)((a.Cout + 32 * ntn - 1) / (32 * ntn));
-                const dim3 gridw(a.nblk * a.nblk_n);
-                if (ntn == 4) hipLaunchKernelGGL((conv_x3_kernel<0, true, 4>), gridw, dim3(256), 0, c->stream, a);
-                else if (a.mode == 0 && tr) hipLaunchKernelGGL((conv_x3_kernel<0, true, 2>), gridw, dim3(256), 0, c->stream, a);
-                else if (a.mode == 0) hipLaunchKernelGGL((conv_x3_kernel<0, false, 2>), gridw, dim3(256), 0, c->stream, a);
-                else if (a.mode == 1 && tr) hipLaunchKernelGGL((conv_x3_kernel<1, true, 2>), gridw, dim3(256), 0, c->stream, a);
-                else if (a.mode == 1) hipLaunchKernelGGL((conv_x3_kernel<1, false, 2>), gridw, dim3(256), 0, c->stream, a);
-                else hipLaunchKernelGGL((conv_x3_kernel<2, false, 2>), gridw, dim3(256), 0, c->stream, a);
-            } else {
-                if (a.mode == 0) hipLaunchKernelGGL(conv_igemm_kernel<0>, grid1, dim3(256), 0, c->stream, a);
-                else if (a.mode == 1) hipLaunchKernelGGL(conv_igemm_kernel<1>, grid1, dim3(256), 0, c->stream, a);
-                else hipLaunchKernelGGL(conv_igemm_kernel<2>, grid1, dim3(256), 0, c->stream, a);
-            }
-            iss_prof_end(c);
+            if (pending < 0 && can_defer(r)) { pending = r; *result = out; continue; }
+            const int rc = conv_row(r, pending);
+            pending = -1;
+            if (rc) return rc;
         } else if (op == ISS_OP_POOL) {
             const long long total = (long long)bc * R[ISS_C_HO] * R[ISS_C_WO] * R[ISS_C_CIN];
             iss_prof_begin(c, 2, 0);
@@ -793,11 +921,21 @@ extern "C" int iss_cnn_probs(iss_ctx* c, int id, const int32_t* win_row, int32_t
                        (const int32_t*)c->d_winrow.p, nslots, n.in_w, (float*)c->d_stats.p, (uint8_t*)c->d_finite.p);
     iss_prof_end(c);
     ISS_HIP(c, hipGetLastError());
+    // Shared first layer (ConvArgs::f_*): decided per call from the whole window list, not per chunk, so that the result
+    // does not depend on the workspace limit: on when the windows overlap at least 4-fold on average.
+    bool share = !getenv("ISS_NO_FUSE");
+    {
+        int gmin = win_row[0], gmax = win_row[0];
+        for (int i = 1; i < nslots; ++i) { gmin = std::min(gmin, win_row[i]); gmax = std::max(gmax, win_row[i]); }
+        if ((long long)(gmax - gmin + 68) * 4 > (long long)nslots * 68) share = false;
+    }
     for (int s0 = 0; s0 < nslots; s0 += bc) {
         const int cur = std::min(bc, nslots - s0);
         float* res = nullptr;
+        int rmin = win_row[s0], rmax = win_row[s0];
+        for (int i = s0 + 1; i < s0 + cur; ++i) { rmin = std::min(rmin, win_row[i]); rmax = std::max(rmax, win_row[i]); }
         rc = run_program(c, n, cur, (const int32_t*)c->d_winrow.p + s0, (const float*)c->d_stats.p + 2 * (size_t)s0,
-                         (const uint8_t*)c->d_finite.p + s0, nullptr, &res);
+                         (const uint8_t*)c->d_finite.p + s0, nullptr, &res, rmin, rmax, share);
         if (rc) return rc;
         ISS_HIP(c, hipMemcpyAsync((float*)c->d_out.p + (size_t)s0 * n.out_dim, res, (size_t)cur * n.out_dim * 4,
                                   hipMemcpyDeviceToDevice, c->stream));

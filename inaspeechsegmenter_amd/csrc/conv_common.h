@@ -7,6 +7,7 @@
 #include <cstring>
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
 
 namespace issk {
 
@@ -47,6 +48,16 @@ struct ConvArgs {
     int sh, sw, pt_, pl_;
     int row_stride, pix_stride;
     int act, Kpad, mode;
+    // ---- shared first layer (conv_x3_fp_kernel<..., FUSED>).  The PATCH conv in front of this conv is linear in its
+    // z-normalised window: conv((x - mean_b) / std_b)[c] = (conv(x)[c] - mean_b * sum_k w[c][k]) / std_b.  conv(x) on the RAW
+    // log-mel rows is the same for every window that contains the row, so it is computed ONCE per recording row
+    // (first_layer_raw_kernel -> `in`, [row - f_rmin][W][Cin], f32) instead of once per window (34 x fewer outputs for
+    // 68-row windows every 2 rows), and this kernel applies the per-window affine map, bias and activation while it
+    // stages its LDS footprint.  The first layer's per-window output (the largest tensor of the net) never exists.
+    const float* f_bias;     // [Cin] first layer bias
+    const float* f_wsum;     // [Cin] sum_k w[c][k] of the first layer
+    int f_act;               // first layer activation: 0 none, 1 relu
+    int f_rmin;              // log-mel row of `in`'s first row
     unsigned nblk;           // M tiles
     unsigned nblk_n;         // N tiles (generic kernels are launched 1-D: nblk * nblk_n workgroups)
     int dbg;                 // ISS_DBG experiment bits (0 in production)

@@ -51,10 +51,11 @@ __device__ __forceinline__ void map_row32(const ConvArgs& p, int m, int& b, int&
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS at (wave-uniform base + lane * 16); no VGPR
 // destination, no ds_write.  hipcc does not count this instruction in its s_waitcnt bookkeeping: the kernel
 // below waits for it with explicit vmcnt(N) statements.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+// Source = wave-uniform base (SGPR pair) + 32-bit unsigned per-lane byte offset: one address VGPR instead of two.
+__device__ __forceinline__ void glds16(const void* gbase, unsigned byte_off, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(byte_off), "s"(gbase), "s"(lds_dst) : "memory");
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
@@ -66,7 +67,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // chunk of 16 rows with distinct (r mod 16) hit 16 different 16-byte bank groups.
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
 
-template <int KH, int KW, bool PADDED, bool TR>
+template <int KH, int KW, bool PADDED, bool TR, bool FUSED = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     constexpr int NT = KH * KW;
     static_assert(NT >= 2, "1x1 convolutions use conv_x3_kernel");
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     if (tile >= tile_end) return;
 
     // ---- per-tile geometry: first pixel of the tile (uniform) and this lane's A row
-    struct Geom { int p_lo, lanepix, iy0, ix0; };
+    struct Geom { int p_lo, lanepix, iy0, ix0; int fy, fx, wr0, wr1; float mean0, mean1, sd0, sd1; bool live0, live1, two; };
     auto geometry = [&](int t) {
         Geom g;
         const int m0 = t * BM;
@@ -103,6 +104,19 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         int lanepix = (b * p.H + g.iy0) * p.W + g.ix0 - g.p_lo;
         const int hi = FPIX - 1 - ((KH - 1) * p.W + (KW - 1));   // keeps every tap of a row >= M inside the buffer
         g.lanepix = lanepix < 0 ? 0 : (lanepix > hi ? hi : lanepix);
+        if (FUSED) {
+            // first footprint pixel in the (window, y, x) grid of first-layer outputs, and the per-window scalars of the
+            // (at most two: H * W >= FPIX) windows the footprint touches: R row of the window's first row, mean, std,
+            // finite flag.  Only loaded here -- nothing below may USE them, or every tile would start with a full
+            // s_waitcnt vmcnt(0); stage_fp turns them into scale and shift one chunk later.
+            map_row32(p, m0, b, oy, ox);
+            g.fy = oy * p.sh; g.fx = ox * p.sw;
+            g.two = g.fy * p.W + g.fx + FPIX > p.H * p.W;            // footprint reaches into the next window
+            const int nb = M / (p.Hq * p.Wq * p.pp);
+            const unsigned b0 = (unsigned)(b < nb ? b : nb - 1), b1 = (unsigned)(b + 1 < nb ? b + 1 : nb - 1);
+            g.wr0 = p.win_row[b0]; g.mean0 = p.stats[2u * b0]; g.sd0 = p.stats[2u * b0 + 1u]; g.live0 = p.finite[b0] != 0;
+            g.wr1 = p.win_row[b1]; g.mean1 = p.stats[2u * b1]; g.sd1 = p.stats[2u * b1 + 1u]; g.live1 = p.finite[b1] != 0;
+        }
         return g;
     };
     Geom g = geometry(tile), gn = g;
@@ -111,12 +125,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     // physical chunk; lane reads the LOGICAL chunk that belongs there (swizzle on the source side, LDS linear).
     // Rows >= Cout read row 0 instead: their output columns are never stored.
     const int brow = wv * 16 + (lane >> 2);
-    const size_t boff = (size_t)(n0 + brow < p.Cout ? n0 + brow : 0) * p.Kpad + (size_t)(((lane & 3) ^ ((brow >> 2) & 3)) * 8);
+    const unsigned boff = 2u * ((unsigned)(n0 + brow < p.Cout ? n0 + brow : 0) * (unsigned)p.Kpad + (unsigned)(((lane & 3) ^ ((brow >> 2) & 3)) * 8));   // bytes
     const unsigned sB_base = (unsigned)(size_t)(&sB[0]);
     auto dma_b = [&](int stage_off, int tap, int c0) {       // stage_off: byte offset of the stage inside sB
-        const size_t src = boff + (size_t)tap * p.Cin + c0;
-        glds16(p.wh + src, sB_base + stage_off + wv * 1024);
-        glds16(p.wl + src, sB_base + stage_off + BSTAGE + wv * 1024);
+        const unsigned src = boff + 2u * (unsigned)(tap * p.Cin + c0);
+        glds16(p.wh, src, sB_base + stage_off + wv * 1024);
+        glds16(p.wl, src, sB_base + stage_off + BSTAGE + wv * 1024);
     };
 
     floatx16 acc0, acc1;
@@ -129,21 +143,73 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     const int k8 = tid & 7, prow = tid >> 3;
     constexpr int NFV = (FPIX + 31) / 32;
     float4 fv[NFV];
-    auto fetch_fp_part = [&](int q, int p_lo, int c0) {
-        int gp = p_lo + prow + 32 * q;
+    unsigned dbmask = 0;                             // FUSED: bit q = footprint pixel prow + 32 q belongs to the second window
+    float4 fsw = make_float4(0.f, 0.f, 0.f, 0.f), fbw = fsw;   // FUSED: weight sums / bias of this lane's 4 channels
+    const int magicW = (65536 + p.W - 1) / p.W;      // x / W == (x * magicW) >> 16 for x < 512, W <= 128
+    auto fetch_fp_part = [&](int q, const Geom& gg, int c0) {
+        if (FUSED) {
+            int x = gg.fx + prow + 32 * q;
+            const int dy = (x * magicW) >> 16;
+            x -= dy * p.W;
+            int y = gg.fy + dy;
+            const bool second = y >= p.H;
+            y -= second ? p.H : 0;
+            const int row = y + (second ? gg.wr1 : gg.wr0) - p.f_rmin;
+            dbmask = (q == 0 ? 0u : dbmask) | (second ? 1u << q : 0u);       // slice 0 is the first fetch of every chunk
+            fv[q] = *reinterpret_cast<const float4*>(p.in + ((unsigned)(row * p.W + x) * (unsigned)p.Cin + (unsigned)(c0 + k8 * 4)));
+            return;
+        }
+        int gp = gg.p_lo + prow + 32 * q;
         gp = gp < 0 ? 0 : (gp > totpix - 1 ? totpix - 1 : gp);
         fv[q] = *reinterpret_cast<const float4*>(p.in + ((unsigned)gp * (unsigned)p.Cin + (unsigned)(c0 + k8 * 4)));
     };
-    auto stage_fp = [&]() {
+    auto fetch_chan = [&](int c0) {                  // FUSED: two more loads in the first tap of a chunk
+        fsw = *reinterpret_cast<const float4*>(p.f_wsum + (unsigned)(c0 + k8 * 4));
+        fbw = *reinterpret_cast<const float4*>(p.f_bias + (unsigned)(c0 + k8 * 4));
+    };
+    auto stage_fp = [&](const Geom& gt) {            // gt: geometry of the tile the staged footprint belongs to
+        float t0[4], t1[4], rs0 = 0.f, rs1 = 0.f;
+        if (FUSED) {
+            // scale 1 / std and shift bias - mean / std * sum_k w of (window, channel).  A non-finite window is all zeros
+            // in the reference (segmenter.py:86-88): scale 0, shift = bias.
+            rs0 = gt.live0 ? 1.0f / gt.sd0 : 0.f;
+            rs1 = gt.live1 ? 1.0f / gt.sd1 : 0.f;
+            const float mr0 = gt.live0 ? -gt.mean0 * rs0 : 0.f, mr1 = gt.live1 ? -gt.mean1 * rs1 : 0.f;
+            const float sw[4] = {fsw.x, fsw.y, fsw.z, fsw.w}, bw[4] = {fbw.x, fbw.y, fbw.z, fbw.w};
 #pragma unroll
-        for (int q = 0; q < NFV; ++q) {
-            const int pix = prow + 32 * q;
-            if (pix >= FPIX) continue;
+            for (int i = 0; i < 4; ++i) { t0[i] = fmaf(sw[i], mr0, bw[i]); t1[i] = fmaf(sw[i], mr1, bw[i]); }
+        }
+        auto put = [&](int q, float4 v) {
             bf16x4 h, l;
-            split4(fv[q], h, l);
-            const int o = swz(pix, k8 >> 1) * 8 + (k8 & 1) * 4;          // bf16 units
+            split4(v, h, l);
+            const int o = swz(prow + 32 * q, k8 >> 1) * 8 + (k8 & 1) * 4;    // bf16 units
             *reinterpret_cast<bf16x4*>(&sFh[o]) = h;
             *reinterpret_cast<bf16x4*>(&sFl[o]) = l;
+        };
+        auto act4 = [&](float4 v) {
+            if (p.f_act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            return v;
+        };
+        if (FUSED && !gt.two) {                      // usual case: the whole footprint lies in one window (uniform branch)
+#pragma unroll
+            for (int q = 0; q < NFV; ++q) {
+                if (prow + 32 * q >= FPIX) continue;
+                const float4 r = fv[q];
+                put(q, act4(make_float4(fmaf(r.x, rs0, t0[0]), fmaf(r.y, rs0, t0[1]), fmaf(r.z, rs0, t0[2]), fmaf(r.w, rs0, t0[3]))));
+            }
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < NFV; ++q) {
+            if (prow + 32 * q >= FPIX) continue;
+            float4 v = fv[q];
+            if (FUSED) {
+                const bool second = (dbmask >> q) & 1u;
+                const float sc = second ? rs1 : rs0;
+                v = act4(make_float4(fmaf(v.x, sc, second ? t1[0] : t0[0]), fmaf(v.y, sc, second ? t1[1] : t0[1]),
+                                     fmaf(v.z, sc, second ? t1[2] : t0[2]), fmaf(v.w, sc, second ? t1[3] : t0[3])));
+            }
+            put(q, v);
         }
     };
 
@@ -204,13 +270,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     //   of a tile is followed by the epilogue, whose stores drain behind the next tile's taps.
     constexpr int FPT = (NFV + NT - 2) / (NT - 1);   // footprint slices per tap (taps 0 .. NT-2 of a chunk)
     const int nchunk = p.Cin / XBK;
+    if (FUSED) fetch_chan(0);
 #pragma unroll
-    for (int q = 0; q < NFV; ++q) fetch_fp_part(q, g.p_lo, 0);
+    for (int q = 0; q < NFV; ++q) fetch_fp_part(q, g, 0);
     static_assert(NT >= 3 || NT == 2, "");
     dma_b(0, 0, 0);
     dma_b(2 * BSTAGE, 1 % NT, (1 / NT) * XBK);
     dma_b(4 * BSTAGE, 2 % NT, (2 / NT) * XBK);       // (a 2-tap kernel in a 1-chunk layer re-reads tap 0: harmless, never used)
-    stage_fp();
+    stage_fp(g);
     wait_vmcnt<0>();
     __syncthreads();
     Frags fa, fb;                                    // fa: first k16 step of the current tap, fb: second
@@ -223,8 +290,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
             const int c0 = ch * XBK;
             const bool last_chunk = ch + 1 == nchunk;
             const bool fin = last_chunk && last_tile;            // nothing follows this chunk
-            if (last_chunk && !last_tile) gn = geometry(tile + 1);
-            const int nx_plo = last_chunk ? gn.p_lo : g.p_lo;    // where the next chunk's footprint comes from
+            // next tile's geometry one chunk early where possible: the fused variant loads per-window scalars in it
+            if (ch == (nchunk >= 2 ? nchunk - 2 : 0) && !last_tile) gn = geometry(tile + 1);
+            const Geom gx = last_chunk ? gn : g;                 // tile the next chunk's footprint belongs to (by value:
+                                                                 // a runtime choice of references would pin both structs in scratch)
             const int nx_c0 = last_chunk ? 0 : c0 + XBK;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -234,9 +303,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
                 // footprint slices of this tap (compile-time count: the wait below must know it exactly)
                 const int q_lo = j < NT - 1 ? (j * FPT < NFV ? j * FPT : NFV) : NFV;
                 const int q_hi = j < NT - 1 ? ((j + 1) * FPT < NFV ? (j + 1) * FPT : NFV) : NFV;
+                const int nld = (!fin ? q_hi - q_lo : 0) + (FUSED && !fin && j == 0 ? 2 : 0);   // this tap's own loads
                 if (!fin) {
+                    if (FUSED && j == 0) fetch_chan(nx_c0);
 #pragma unroll
-                    for (int q = q_lo; q < q_hi; ++q) fetch_fp_part(q, nx_plo, nx_c0);
+                    for (int q = q_lo; q < q_hi; ++q) fetch_fp_part(q, gx, nx_c0);
                 }
                 if (has3) dma_b(st3, (j + 3) % NT, (j + 3) >= NT ? ((j + 3) >= 2 * NT ? nx_c0 + XBK : nx_c0) : c0);
                 read_frags(fb, g, j / KW, j % KW, 1, st0);
@@ -244,27 +315,24 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
                 if (has1) {
                     if (j == NT - 1) {               // tap t+1 opens the next chunk: swap the footprint.  Every wave
                         __syncthreads();             // must have its fb reads back before anyone overwrites it
-                        stage_fp();
+                        stage_fp(gx);
                         __syncthreads();
                     }
-                    read_frags(fa, (j == NT - 1 && last_chunk) ? gn : g, ((j + 1) % NT) / KW, ((j + 1) % NT) % KW, 0, st1);
+                    read_frags(fa, j == NT - 1 ? gx : g, ((j + 1) % NT) / KW, ((j + 1) % NT) % KW, 0, st1);
                 }
                 mfma6(fb);
                 // B(t+1) was DMA'd during tap t-1; vmcnt counts in order, so allow exactly this tap's own VMEM
                 // operations (its footprint loads + 2 DMAs) to stay in flight.  hipcc's own waits for the footprint
                 // loads do not know about the DMAs, which only makes them stricter.
-                if (!fin) {
-                    if (q_hi - q_lo == 0) wait_vmcnt<2>();
-                    else if (q_hi - q_lo == 1) wait_vmcnt<3>();
-                    else if (q_hi - q_lo == 2) wait_vmcnt<4>();
-                    else if (q_hi - q_lo == 3) wait_vmcnt<5>();
-                    else if (q_hi - q_lo == 4) wait_vmcnt<6>();
-                    else wait_vmcnt<0>();
-                } else if (has3) {
-                    wait_vmcnt<2>();
-                } else {
-                    wait_vmcnt<0>();
-                }
+                if (!has3) wait_vmcnt<0>();
+                else if (nld == 0) wait_vmcnt<2>();
+                else if (nld == 1) wait_vmcnt<3>();
+                else if (nld == 2) wait_vmcnt<4>();
+                else if (nld == 3) wait_vmcnt<5>();
+                else if (nld == 4) wait_vmcnt<6>();
+                else if (nld == 5) wait_vmcnt<7>();
+                else if (nld == 6) wait_vmcnt<8>();
+                else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
             }
             // rotate the stage roles by NT taps
@@ -286,9 +354,17 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     }
 }
 
-// one filter shape, all (PADDED, TR) variants
+// one filter shape, all (PADDED, TR) variants; fused = shared first layer (ConvArgs::f_*), unpadded shapes with >= 12
+// taps only (one footprint slice per tap)
 template <int KH, int KW>
-void launch_fp_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr) {
+void launch_fp_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused) {
+    if constexpr (KH * KW >= 12) {
+        if (fused) {
+            if (tr) hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, false, true, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, false, false, true>), grid, dim3(256), 0, st, a);
+            return;
+        }
+    }
     if (padded && tr) hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, true, true>), grid, dim3(256), 0, st, a);
     else if (padded) hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, true, false>), grid, dim3(256), 0, st, a);
     else if (tr) hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, false, true>), grid, dim3(256), 0, st, a);
@@ -300,10 +376,10 @@ void launch_fp_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, 
 // Filter shapes the footprint kernel is instantiated for (the tap loop is unrolled at compile time); other shapes
 // run on conv_x3_kernel.  One extern launcher per shape, defined in the cnn_fp_*.hip units.
 #define ISS_FP_SHAPES(X) X(3, 3) X(5, 3) X(3, 5) X(5, 5) X(2, 2) X(4, 4) X(1, 3) X(3, 1)
-#define ISS_FP_DECL(KH_, KW_) void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr);
+#define ISS_FP_DECL(KH_, KW_) void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused);
 ISS_FP_SHAPES(ISS_FP_DECL)
 #undef ISS_FP_DECL
 #define ISS_FP_DEFINE(KH_, KW_)                                                                               \
-    void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr) { \
-        issk::launch_fp_shape<KH_, KW_>(a, grid, st, padded, tr);                                                 \
+    void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused) { \
+        issk::launch_fp_shape<KH_, KW_>(a, grid, st, padded, tr, fused);                                          \
     }

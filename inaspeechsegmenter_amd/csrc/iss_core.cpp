@@ -76,7 +76,7 @@ extern "C" void iss_destroy(iss_ctx* c) {
     for (int i = 0; i < ISS_MAX_NETS; ++i) iss_cnn_free(c, i);
     void* singles[] = {c->d_window, c->d_melw, c->d_mellim, c->d_tw, c->d_vbx_window, c->d_vbx_melw, c->d_vbx_mellim};
     for (void* p : singles) if (p) (void)hipFree(p);
-    DevBuf* bufs[] = {&c->sig, &c->mspec, &c->loge, &c->d_winrow, &c->d_stats, &c->d_finite, &c->d_out, &c->d_in,
+    DevBuf* bufs[] = {&c->sig, &c->mspec, &c->loge, &c->d_winrow, &c->d_stats, &c->d_finite, &c->d_out, &c->d_in, &c->raw1,
                       &c->vbx_sig, &c->vbx_dither, &c->vbx_fb, &c->vbx_out};
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& b : c->act) free_buf(b);

@@ -23,6 +23,8 @@ struct IssNet {
     float* d_blob = nullptr;              // parameters (conv weights [Cout][Kpad])
     uint16_t* d_wh = nullptr;             // bf16 hi part of every blob element (same offsets)
     uint16_t* d_wl = nullptr;             // bf16 lo part
+    float* d_wsum = nullptr;              // patch-mode first layers: sum_k w[c][k] per output channel (shared first layer)
+    std::vector<int64_t> wsum_off;        // per row: offset into d_wsum, -1 = none
     int64_t blob_floats = 0;
     std::vector<int64_t> w_dev_off;       // per row: offset of the padded weight matrix in d_blob
     std::vector<int32_t> kpad;            // per row: K padded to the GEMM k-tile
@@ -64,6 +66,7 @@ struct iss_ctx {
     int precision = ISS_PREC_BF16X3;
     std::vector<DevBuf> act;              // activation buffers (grown on demand)
     DevBuf d_winrow, d_stats, d_finite, d_out, d_in;
+    DevBuf raw1;                          // shared first layer: raw conv over the log-mel rows of the current chunk
 
     // vbx
     bool vbx_tables = false;
