@@ -768,8 +768,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         const dim3 grid1(a.nblk * a.nblk_n);          // generic kernels: 1-D, XCD-aware (gemm_tile_of_block)
         double fl = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * a.Cin * (double)a.Cout * (double)a.M;
         bool fp = false;
-        if (x3 && a.mode == 0 && fp_shape_compiled(a.H_k, a.kw) && a.M < (1ll << 31) &&
-            (long long)bc * a.img_stride < (1ll << 32)) {
+        if (x3 && a.mode == 0 && fp_shape_compiled(a.H_k, a.kw) && a.M < (1ll << 31)) {
             const long long key = ((long long)r << 32) | (unsigned)bc;
             auto it = n.fp_ok.find(key);
             if (it == n.fp_ok.end()) it = n.fp_ok.emplace(key, footprint_fits(a)).first;
@@ -782,6 +781,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
             fused = fp && !padded && a.H_k * a.kw >= 12 && d_winrow != nullptr &&
                     ((long long)(rmax - rmin) + Rp[ISS_C_HO]) * Rp[ISS_C_WO] * Rp[ISS_C_COUT] < (1ll << 32);   // 32-bit offsets into R
+        }
+        if (!fused && (long long)bc * a.img_stride >= (1ll << 32)) fp = false;        // 32-bit offsets into the input batch
+        if (pend >= 0) {
             if (!fused) {                                    // the deferred first layer runs on its own after all
                 const int rc = conv_row(pend, -1);
                 if (rc) return rc;

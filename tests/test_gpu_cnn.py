@@ -170,3 +170,60 @@ def test_generic_forward_nhwc(ctx, prec):
     out = ctx.cnn_forward(4, x)
     ref = ocnn.forward(layers, x)
     assert np.abs(out - ref).max() < 1e-4 * max(1, np.abs(ref).max())
+
+
+def _conv_launches(ctx, fn):
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    out = fn()
+    n = ctx.prof_get(0)[1]
+    ctx.prof_enable(False)
+    return out, n
+
+
+@pytest.mark.parametrize('nmel,nout', [(21, 3), (24, 2)])
+def test_shared_first_layer(ctx, nmel, nout):
+    """Overlapping windows (the segmenter's every-2nd-row list with edge replicas): the first conv runs once per
+    log-mel row and the second conv normalises per window (ConvArgs::f_*).  Must agree with the per-window
+    first layer (ISS_NO_FUSE=1) and with the oracle; windows straddled by one LDS footprint, non-finite and
+    constant windows included."""
+    rng = np.random.default_rng(21)
+    layers, shp = KM.synthetic_ina_like(nmel, nout, seed=9)
+    ctx.cnn_load(3, KM.compile_layers(layers, shp))
+    mspec = _mspec(rng, 700)
+    mspec[300:304, 2] = -np.inf
+    mspec[500:568, :] = -2.5
+    ctx.set_mspec(mspec)
+    rows = np.concatenate([np.zeros(17, np.int32), np.arange(0, 700 - 68 + 1, 2, dtype=np.int32),
+                           np.full(16, 632, np.int32)])
+    (probs, fin), n_shared = _conv_launches(ctx, lambda: ctx.cnn_probs(3, rows))
+    os.environ['ISS_NO_FUSE'] = '1'
+    try:
+        (probs_pw, fin_pw), n_pw = _conv_launches(ctx, lambda: ctx.cnn_probs(3, rows))
+    finally:
+        del os.environ['ISS_NO_FUSE']
+    assert n_shared < n_pw, 'the shared first layer did not run'      # one GEMM launch less per pass
+    ref, rfin = _oracle_probs(layers, mspec, nmel, rows)
+    assert np.array_equal(fin, rfin) and np.array_equal(fin_pw, rfin) and 30 < (~fin).sum() < len(rows) - 100
+    assert np.all(probs[~fin] == 0.5)
+    print(f'shared vs per-window {np.abs(probs - probs_pw).max():.2e}, shared vs oracle {np.abs(probs - ref).max():.2e}, '
+          f'per-window vs oracle {np.abs(probs_pw - ref).max():.2e}')
+    # the per-window path rounds the NORMALISED input to 2^-16 (split bf16); the shared path's first layer is exact f32
+    assert np.abs(probs - probs_pw).max() < 1e-4
+    assert np.abs(probs - ref).max() < 1e-4
+
+
+def test_shared_first_layer_needs_overlap(ctx):
+    """Few scattered windows: the per-call rule (4-fold average overlap) keeps the per-window first layer, bit for bit."""
+    rng = np.random.default_rng(22)
+    layers, shp = KM.synthetic_ina_like(21, 3, seed=9)
+    ctx.cnn_load(3, KM.compile_layers(layers, shp))
+    ctx.set_mspec(_mspec(rng, 3000))
+    rows = np.sort(rng.integers(0, 3000 - 68, 40)).astype(np.int32)
+    (a, _), n_a = _conv_launches(ctx, lambda: ctx.cnn_probs(3, rows))
+    os.environ['ISS_NO_FUSE'] = '1'
+    try:
+        (b, _), n_b = _conv_launches(ctx, lambda: ctx.cnn_probs(3, rows))
+    finally:
+        del os.environ['ISS_NO_FUSE']
+    assert n_a == n_b and np.array_equal(a, b)
