@@ -90,13 +90,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     if (tile >= tile_end) return;
 
     // ---- per-tile geometry: first pixel of the tile (uniform) and this lane's A row
-    struct Geom { int p_lo, lanepix, iy0, ix0; int fy, fx, wr0, wr1; float mean0, mean1, sd0, sd1; bool live0, live1, two; };
+    struct Geom { int p_lo, need, lanepix, iy0, ix0; int fy, fx, wr0, wr1; float mean0, mean1, sd0, sd1; bool live0, live1, two; };
     auto geometry = [&](int t) {
         Geom g;
         const int m0 = t * BM;
         int b, oy, ox;
         map_row32(p, m0, b, oy, ox);
         g.p_lo = (b * p.H + (oy * p.sh - p.pt_)) * p.W + (ox * p.sw - p.pl_);
+        {   // pixels the tile really needs (its last row's last tap is the highest, see footprint_fits): slices beyond
+            // them are neither converted nor written to LDS -- typically a quarter of the FPIX-pixel buffer
+            const int ml = m0 + BM - 1 < M - 1 ? m0 + BM - 1 : M - 1;
+            int b2, oy2, ox2;
+            map_row32(p, ml, b2, oy2, ox2);
+            g.need = (b2 * p.H + (oy2 * p.sh - p.pt_ + KH - 1)) * p.W + (ox2 * p.sw - p.pl_ + KW - 1) - g.p_lo + 1;
+        }
         const int m = m0 + wv * 32 + li;
         map_row32(p, m < M ? m : m0, b, oy, ox);
         g.iy0 = oy * p.sh - p.pt_;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
             // s_waitcnt vmcnt(0); stage_fp turns them into scale and shift one chunk later.
             map_row32(p, m0, b, oy, ox);
             g.fy = oy * p.sh; g.fx = ox * p.sw;
-            g.two = g.fy * p.W + g.fx + FPIX > p.H * p.W;            // footprint reaches into the next window
+            g.two = g.fy * p.W + g.fx + g.need > p.H * p.W;          // footprint reaches into the next window
             const int nb = M / (p.Hq * p.Wq * p.pp);
             const unsigned b0 = (unsigned)(b < nb ? b : nb - 1), b1 = (unsigned)(b + 1 < nb ? b + 1 : nb - 1);
             g.wr0 = p.win_row[b0]; g.mean0 = p.stats[2u * b0]; g.sd0 = p.stats[2u * b0 + 1u]; g.live0 = p.finite[b0] != 0;
@@ -147,8 +154,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     float4 fsw = make_float4(0.f, 0.f, 0.f, 0.f), fbw = fsw;   // FUSED: weight sums / bias of this lane's 4 channels
     const int magicW = (65536 + p.W - 1) / p.W;      // x / W == (x * magicW) >> 16 for x < 512, W <= 128
     auto fetch_fp_part = [&](int q, const Geom& gg, int c0) {
+        // slices the tile does not need re-load slice 0 (same cache lines; the load COUNT must not change, the vmcnt
+        // bookkeeping of the tap loop is exact)
+        const int qq = 32 * q < gg.need ? q : 0;
         if (FUSED) {
-            int x = gg.fx + prow + 32 * q;
+            int x = gg.fx + prow + 32 * qq;
             const int dy = (x * magicW) >> 16;
             x -= dy * p.W;
             int y = gg.fy + dy;
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
             fv[q] = *reinterpret_cast<const float4*>(p.in + ((unsigned)(row * p.W + x) * (unsigned)p.Cin + (unsigned)(c0 + k8 * 4)));
             return;
         }
-        int gp = gg.p_lo + prow + 32 * q;
+        int gp = gg.p_lo + prow + 32 * qq;
         gp = gp < 0 ? 0 : (gp > totpix - 1 ? totpix - 1 : gp);
         fv[q] = *reinterpret_cast<const float4*>(p.in + ((unsigned)gp * (unsigned)p.Cin + (unsigned)(c0 + k8 * 4)));
     };
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         if (FUSED && !gt.two) {                      // usual case: the whole footprint lies in one window (uniform branch)
 #pragma unroll
             for (int q = 0; q < NFV; ++q) {
-                if (prow + 32 * q >= FPIX) continue;
+                if (prow + 32 * q >= FPIX || 32 * q >= gt.need) continue;
                 const float4 r = fv[q];
                 put(q, act4(make_float4(fmaf(r.x, rs0, t0[0]), fmaf(r.y, rs0, t0[1]), fmaf(r.z, rs0, t0[2]), fmaf(r.w, rs0, t0[3]))));
             }
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         }
 #pragma unroll
         for (int q = 0; q < NFV; ++q) {
-            if (prow + 32 * q >= FPIX) continue;
+            if (prow + 32 * q >= FPIX || 32 * q >= gt.need) continue;
             float4 v = fv[q];
             if (FUSED) {
                 const bool second = (dbmask >> q) & 1u;
