@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Merge the three tools/pmc_summary.py outputs (FETCH_SIZE pass, WRITE_SIZE pass, SQ/GRBM pass) into
+profiles/pmc_latest.json (read by bench.py as roofline.traffic) and a markdown table on stdout.
+
+    python tools/pmc_report.py fetch.json write.json sq.json out.json
+Counter units as the guide prescribes: FETCH_SIZE / WRITE_SIZE count KB (x 1024 -> bytes, raw, no further correction);
+MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs)."""
+import json
+import sys
+
+
+def main():
+    fe, wr, sq = (json.load(open(p)) for p in sys.argv[1:4])
+    per = {}
+    for k in sorted(set(fe) | set(wr) | set(sq)):
+        d = {}
+        src = sq.get(k) or fe.get(k) or wr.get(k)
+        d['launches'] = src['launches']
+        d['avg_duration_us'] = src['avg_duration_us']
+        if k in fe and 'FETCH_SIZE' in fe[k]:
+            d['FETCH_SIZE_bytes'] = fe[k]['FETCH_SIZE'] * 1024
+        if k in wr and 'WRITE_SIZE' in wr[k]:
+            d['WRITE_SIZE_bytes'] = wr[k]['WRITE_SIZE'] * 1024
+        s = sq.get(k, {})
+        if 'GRBM_GUI_ACTIVE' in s and s['GRBM_GUI_ACTIVE'] > 0:
+            cyc = s['GRBM_GUI_ACTIVE'] / 8.0
+            d['clock_ghz'] = cyc / (s['avg_duration_us'] * 1e3)
+            d['mfma_busy_frac'] = s.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (cyc * 256 * 4)
+            if s.get('SQ_LDS_IDX_ACTIVE'):
+                d['lds_conflict_frac'] = s.get('SQ_LDS_BANK_CONFLICT', 0.0) / s['SQ_LDS_IDX_ACTIVE']
+            if s.get('SQ_WAVE_CYCLES'):
+                d['wait_inst_frac'] = s.get('SQ_WAIT_INST_ANY', 0.0) / s['SQ_WAVE_CYCLES']
+                d['active_inst_frac'] = s.get('SQ_ACTIVE_INST_ANY', 0.0) / s['SQ_WAVE_CYCLES']
+        per[k] = d
+    conv = [v for k, v in per.items() if k.startswith(('conv_x3', 'issk::conv_x3', 'conv1_patch', 'conv_igemm'))
+            and 'FETCH_SIZE_bytes' in v and 'WRITE_SIZE_bytes' in v]
+    n = sum(v['launches'] for v in conv)
+    traffic = sum(v['launches'] * (v['FETCH_SIZE_bytes'] + v['WRITE_SIZE_bytes']) for v in conv) / max(n, 1)
+    out = {'conv_hbm_bytes_per_launch_bf16x3': traffic,
+           'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --minutes 20 --steps 1 --warmup 0: '
+                   'launch-weighted mean of FETCH_SIZE+WRITE_SIZE over the conv GEMM launches, RAW counter bytes (KB x 1024)',
+           'per_kernel': per}
+    json.dump(out, open(sys.argv[4], 'w'), indent=1)
+    print('| kernel | launches | avg us | FETCH MB | WRITE MB | (F+W)/t TB/s | MFMA busy % | clock GHz | LDS conflict % |')
+    print('|---|---|---|---|---|---|---|---|---|')
+    for k, v in per.items():
+        f, w = v.get('FETCH_SIZE_bytes', 0.0), v.get('WRITE_SIZE_bytes', 0.0)
+        print(f"| `{k}` | {v['launches']} | {v['avg_duration_us']:.1f} | {f / 1e6:.1f} | {w / 1e6:.1f} | "
+              f"{(f + w) / (v['avg_duration_us'] * 1e-6) / 1e12:.2f} | {100 * v.get('mfma_busy_frac', 0):.1f} | "
+              f"{v.get('clock_ghz', 0):.2f} | {100 * v.get('lds_conflict_frac', 0):.0f} |")
+    print(f'\nlaunch-weighted mean HBM traffic per conv GEMM launch: {traffic / 1e9:.3f} GB')
+
+
+if __name__ == '__main__':
+    main()
