@@ -299,6 +299,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     read_frags(fa, g, 0, 0, 0, 0);
     int st[4] = {0, 2 * BSTAGE, 4 * BSTAGE, 6 * BSTAGE};   // byte offsets of the stages of B(t), B(t+1), B(t+2), B(t+3) at tap j = 0
 
+    // Wave priorities: the two workgroups of a CU run out of phase; MFMA groups (3) beat the tap's address / load
+    // bookkeeping (1-2), and that beats footprint staging and the epilogue (0) of the other workgroup -- 3 % of the step.
+    __builtin_amdgcn_s_setprio(2);
     for (; tile < tile_end; tile += tstep) {
         const bool last_tile = tile + tstep >= tile_end;
         for (int ch = 0; ch < nchunk; ++ch) {
@@ -326,16 +329,22 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
                 }
                 if (has3) dma_b(st3, (j + 3) % NT, (j + 3) >= NT ? ((j + 3) >= 2 * NT ? nx_c0 + XBK : nx_c0) : c0);
                 read_frags(fb, g, j / KW, j % KW, 1, st0);
+                __builtin_amdgcn_s_setprio(3);
                 mfma6(fa);
+                __builtin_amdgcn_s_setprio(1);
                 if (has1) {
                     if (j == NT - 1) {               // tap t+1 opens the next chunk: swap the footprint.  Every wave
                         __syncthreads();             // must have its fb reads back before anyone overwrites it
+                        __builtin_amdgcn_s_setprio(0);
                         stage_fp(gx);
+                        __builtin_amdgcn_s_setprio(2);
                         __syncthreads();
                     }
                     read_frags(fa, j == NT - 1 ? gx : g, ((j + 1) % NT) / KW, ((j + 1) % NT) % KW, 0, st1);
                 }
+                __builtin_amdgcn_s_setprio(3);
                 mfma6(fb);
+                __builtin_amdgcn_s_setprio(1);
                 // B(t+1) was DMA'd during tap t-1; vmcnt counts in order, so allow exactly this tap's own VMEM
                 // operations (its footprint loads + 2 DMAs) to stay in flight.  hipcc's own waits for the footprint
                 // loads do not know about the DMAs, which only makes them stricter.  (Issuing the loads AFTER the DMAs,
@@ -358,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
                 st[0] = r[NT % 4]; st[1] = r[(NT + 1) % 4]; st[2] = r[(NT + 2) % 4]; st[3] = r[(NT + 3) % 4];
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (TR) {
             epilogue_tr(p, acc0, acc1, (long long)tile * BM + wv * 32 + li, n0, lh);
         } else {
@@ -366,6 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        __builtin_amdgcn_s_setprio(2);
         g = gn;
     }
 }
