@@ -704,7 +704,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         if (R1[ISS_C_CIN] != 1 || R1[ISS_C_SH] != 1 || R1[ISS_C_SW] != 1 || R1[ISS_C_PT] != 0 || R1[ISS_C_PL] != 0) return false;
         if (R1[ISS_C_HO] != R1[ISS_C_H] - R1[ISS_C_KH] + 1 || R1[ISS_C_WO] != R1[ISS_C_W] - R1[ISS_C_KW] + 1) return false;   // 'valid'
         if (R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4 > 48 * 1024) return false;        // first_layer_raw_kernel's LDS weights
-        if (R1[ISS_C_BOFF] < 0 || R1[ISS_C_PSOFF] >= 0 || R1[ISS_C_PTOFF] >= 0 || R1[ISS_C_COUT] % 4 != 0 || n.wsum_off[r] < 0) return false;
+        if (R1[ISS_C_BOFF] < 0 || (R1[ISS_C_PSOFF] >= 0) != (R1[ISS_C_PTOFF] >= 0) || R1[ISS_C_COUT] % 4 != 0 || n.wsum_off[r] < 0) return false;
         if (R2[ISS_C_OP] != ISS_OP_CONV || R2[ISS_C_INMODE] != 0 || R2[ISS_C_IN] != R1[ISS_C_OUT] || R2[ISS_C_RES] >= 0) return false;
         if (R2[ISS_C_CIN] != R1[ISS_C_COUT] || R2[ISS_C_CIN] % XBK != 0 || R2[ISS_C_H] != R1[ISS_C_HO] || R2[ISS_C_W] != R1[ISS_C_WO]) return false;
         if (R2[ISS_C_KH] * R2[ISS_C_KW] < 12 || !fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW])) return false;
@@ -802,6 +802,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 a.in = Rraw; a.win_row = d_winrow; a.stats = d_stats; a.finite = d_fin;
                 a.f_bias = n.d_blob + R1[ISS_C_BOFF];
                 a.f_wsum = n.d_wsum + n.wsum_off[pend];
+                a.f_ps = R1[ISS_C_PSOFF] >= 0 ? n.d_blob + R1[ISS_C_PSOFF] : nullptr;
+                a.f_pt = R1[ISS_C_PTOFF] >= 0 ? n.d_blob + R1[ISS_C_PTOFF] : nullptr;
                 a.f_act = R1[ISS_C_ACT]; a.f_rmin = rmin;
                 fl += 2.0 * R1[ISS_C_KH] * R1[ISS_C_KW] * (double)R1[ISS_C_COUT] * (double)bc * R1[ISS_C_HO] * R1[ISS_C_WO];
             }

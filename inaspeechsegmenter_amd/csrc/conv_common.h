@@ -56,6 +56,8 @@ struct ConvArgs {
     // stages its LDS footprint.  The first layer's per-window output (the largest tensor of the net) never exists.
     const float* f_bias;     // [Cin] first layer bias
     const float* f_wsum;     // [Cin] sum_k w[c][k] of the first layer
+    const float* f_ps;       // [Cin] post-activation scale / shift of the first layer (conv -> relu -> BatchNorm), or null
+    const float* f_pt;
     int f_act;               // first layer activation: 0 none, 1 relu
     int f_rmin;              // log-mel row of `in`'s first row
     unsigned nblk;           // M tiles

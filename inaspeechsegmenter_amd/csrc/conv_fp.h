@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     constexpr int NFV = (FPIX + 31) / 32;
     float4 fv[NFV];
     unsigned dbmask = 0;                             // FUSED: bit q = footprint pixel prow + 32 q belongs to the second window
-    float4 fsw = make_float4(0.f, 0.f, 0.f, 0.f), fbw = fsw;   // FUSED: weight sums / bias of this lane's 4 channels
+    float4 fsw = make_float4(0.f, 0.f, 0.f, 0.f), fbw = fsw, fps = fsw, fpt = fsw;   // FUSED: weight sums, bias, post-activation
+                                                     // scale / shift of this lane's 4 channels
     const int magicW = (65536 + p.W - 1) / p.W;      // x / W == (x * magicW) >> 16 for x < 512, W <= 128
     auto fetch_fp_part = [&](int q, const Geom& gg, int c0) {
         // slices the tile does not need re-load slice 0 (same cache lines; the load COUNT must not change, the vmcnt
@@ -178,9 +179,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         gp = gp < 0 ? 0 : (gp > totpix - 1 ? totpix - 1 : gp);
         fv[q] = *reinterpret_cast<const float4*>(p.in + ((unsigned)gp * (unsigned)p.Cin + (unsigned)(c0 + k8 * 4)));
     };
-    auto fetch_chan = [&](int c0) {                  // FUSED: two more loads in the first tap of a chunk
-        fsw = *reinterpret_cast<const float4*>(p.f_wsum + (unsigned)(c0 + k8 * 4));
-        fbw = *reinterpret_cast<const float4*>(p.f_bias + (unsigned)(c0 + k8 * 4));
+    auto fetch_chan = [&](int c0) {                  // FUSED: four more loads in the first tap of a chunk (a CONSTANT count:
+        const unsigned o = (unsigned)(c0 + k8 * 4);  // without a post-activation affine the bias is loaded three times)
+        fsw = *reinterpret_cast<const float4*>(p.f_wsum + o);
+        fbw = *reinterpret_cast<const float4*>(p.f_bias + o);
+        fps = *reinterpret_cast<const float4*>((p.f_ps ? p.f_ps : p.f_bias) + o);
+        fpt = *reinterpret_cast<const float4*>((p.f_pt ? p.f_pt : p.f_bias) + o);
     };
     auto stage_fp = [&](const Geom& gt) {            // gt: geometry of the tile the staged footprint belongs to
         float t0[4], t1[4], rs0 = 0.f, rs1 = 0.f;
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         };
         auto act4 = [&](float4 v) {
             if (p.f_act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.f_ps) { v.x = v.x * fps.x + fpt.x; v.y = v.y * fps.y + fpt.y; v.z = v.z * fps.z + fpt.z; v.w = v.w * fps.w + fpt.w; }
             return v;
         };
         if (FUSED && !gt.two) {                      // usual case: the whole footprint lies in one window (uniform branch)
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
                 // footprint slices of this tap (compile-time count: the wait below must know it exactly)
                 const int q_lo = j < NT - 1 ? (j * FPT < NFV ? j * FPT : NFV) : NFV;
                 const int q_hi = j < NT - 1 ? ((j + 1) * FPT < NFV ? (j + 1) * FPT : NFV) : NFV;
-                const int nld = (!fin ? q_hi - q_lo : 0) + (FUSED && !fin && j == 0 ? 2 : 0);   // this tap's own loads
+                const int nld = (!fin ? q_hi - q_lo : 0) + (FUSED && !fin && j == 0 ? 4 : 0);   // this tap's own loads
                 if (!fin) {
                     if (FUSED && j == 0) fetch_chan(nx_c0);
 #pragma unroll

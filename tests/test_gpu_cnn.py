@@ -181,14 +181,22 @@ def _conv_launches(ctx, fn):
     return out, n
 
 
-@pytest.mark.parametrize('nmel,nout', [(21, 3), (24, 2)])
-def test_shared_first_layer(ctx, nmel, nout):
+def _post_affine_net(nmel, nout, seed):
+    """conv(relu) -> BatchNorm (a post-activation affine that cannot be folded into the conv) -> 5x3 conv."""
+    r = np.random.default_rng(seed)
+    return [_rand_conv(r, 4, 5, 1, 64, act='relu'), _rand_bn(r, 64), _rand_conv(r, 5, 3, 64, 64, act='relu'),
+            dict(type='maxpool', pool=(4, 4), strides=(4, 4), padding='valid'), dict(type='flatten'),
+            _rand_dense(r, 15 * ((nmel - 6) // 4) * 64, nout, 'softmax')], (68, nmel, 1)
+
+
+@pytest.mark.parametrize('nmel,nout,kind', [(21, 3, 'ina'), (24, 2, 'ina'), (21, 3, 'post_affine')])
+def test_shared_first_layer(ctx, nmel, nout, kind):
     """Overlapping windows (the segmenter's every-2nd-row list with edge replicas): the first conv runs once per
     log-mel row and the second conv normalises per window (ConvArgs::f_*).  Must agree with the per-window
     first layer (ISS_NO_FUSE=1) and with the oracle; windows straddled by one LDS footprint, non-finite and
     constant windows included."""
     rng = np.random.default_rng(21)
-    layers, shp = KM.synthetic_ina_like(nmel, nout, seed=9)
+    layers, shp = KM.synthetic_ina_like(nmel, nout, seed=9) if kind == 'ina' else _post_affine_net(nmel, nout, 9)
     ctx.cnn_load(3, KM.compile_layers(layers, shp))
     mspec = _mspec(rng, 700)
     mspec[300:304, 2] = -np.inf
