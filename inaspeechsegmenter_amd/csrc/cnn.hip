@@ -810,8 +810,11 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         iss_prof_begin(c, 0, fl);
         if (fp) {
-#define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr, fused); else
-            const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent: 2 workgroups per CU
+#define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr, fused, nh); else
+            // 128 output channels per workgroup where the layer has them: one LDS footprint serves two 64-column halves
+            static const bool no_nh2 = getenv("ISS_NO_NH2") != nullptr;
+            const int nh = (!fused && !no_nh2 && issk::iss_fp_has_nh2(a.H_k, a.kw) && a.Cout % (2 * BN) == 0) ? 2 : 1;
+            const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y / nh);     // persistent: 2 workgroups per CU
             const bool tr = a.pp == 1 && a.Cout % 4 == 0;                   // float4 epilogue on transposed accumulators
             ISS_FP_SHAPES(ISS_FP_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no footprint kernel for %dx%d", a.H_k, a.kw); }
 #undef ISS_FP_CASE

@@ -67,9 +67,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // chunk of 16 rows with distinct (r mod 16) hit 16 different 16-byte bank groups.
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 4 + (chunk ^ ((row >> 2) & 3)); }
 
-template <int KH, int KW, bool PADDED, bool TR, bool FUSED = false>
+// NH = 2: the workgroup computes TWO 64-column halves (128 output channels) of its M tile from one LDS footprint: the
+// tap sequence becomes (tap, half) pairs -- 'virtual taps' -- each with its own 8 KB weight tile, so LDS and the
+// pipeline are unchanged while footprint fetch / conversion / LDS writes per MFMA halve for layers with >= 128 channels.
+template <int KH, int KW, bool PADDED, bool TR, bool FUSED = false, int NH = 1>
 __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
-    constexpr int NT = KH * KW;
+    constexpr int NT = KH * KW * NH;                 // virtual taps per channel chunk
+    static_assert(NH == 1 || NH == 2, "");
+    static_assert(NH == 1 || !FUSED, "");
     static_assert(NT >= 2, "1x1 convolutions use conv_x3_kernel");
     constexpr int BSTAGE = BN * 64;                  // bytes of one plane of one weight stage (64 rows x 32 bf16)
     __shared__ __attribute__((aligned(16))) uint16_t sFh[FPIX * 32];
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * BN * NH;
     const int li = lane & 31, lh = lane >> 5;
     const int M = (int)p.M;
     const int totpix = (int)(p.img_stride / p.Cin) * (M / (p.Hq * p.Wq * p.pp));     // samples * H * W
@@ -139,15 +144,15 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     const int brow = wv * 16 + (lane >> 2);
     const unsigned boff = 2u * ((unsigned)(n0 + brow < p.Cout ? n0 + brow : 0) * (unsigned)p.Kpad + (unsigned)(((lane & 3) ^ ((brow >> 2) & 3)) * 8));   // bytes
     const unsigned sB_base = (unsigned)(size_t)(&sB[0]);
-    auto dma_b = [&](int stage_off, int tap, int c0) {       // stage_off: byte offset of the stage inside sB
-        const unsigned src = boff + 2u * (unsigned)(tap * p.Cin + c0);
+    auto dma_b = [&](int stage_off, int tap, int c0) {       // stage_off: byte offset of the stage inside sB; tap: virtual
+        const unsigned src = boff + 2u * (unsigned)((tap / NH) * p.Cin + c0) + (NH > 1 ? 2u * (unsigned)((tap % NH) * BN * p.Kpad) : 0u);
         glds16(p.wh, src, sB_base + stage_off + wv * 1024);
         glds16(p.wl, src, sB_base + stage_off + BSTAGE + wv * 1024);
     };
 
-    floatx16 acc0, acc1;
+    floatx16 acc0, acc1, acc2, acc3;                 // acc2 / acc3: second half (NH = 2 only)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
 
     // ---- footprint prefetch registers: pixel prow + 32 q, channels [c0 + 4 k8, +4).  Pixels outside
     // [0, totpix) are clamped to a valid address: only rows >= M or zero-padded taps ever read them
@@ -259,23 +264,26 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         f.b1h = *reinterpret_cast<const bf16x8*>(&sB[so + (b1s - (0 ^ bx) + c) * 8]);
         f.b1l = *reinterpret_cast<const bf16x8*>(&sB[so + BSTAGE / 2 + (b1s - (0 ^ bx) + c) * 8]);
     };
-    auto mfma6 = [&](const Frags& f) {
-        if (TR) {                                        // C^T: rows = channels, columns = pixels (see epilogue_tr)
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0h, f.al, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1h, f.al, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0l, f.ah, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1l, f.ah, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0h, f.ah, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1h, f.ah, acc1, 0, 0, 0);
-        } else {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b1h, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0l, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1l, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1h, acc1, 0, 0, 0);
-        }
+#define ISS_MFMA6(A0, A1)                                                                       \
+    if (TR) {                                            /* C^T: rows = channels, columns = pixels (epilogue_tr) */ \
+        A0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0h, f.al, A0, 0, 0, 0);                     \
+        A1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1h, f.al, A1, 0, 0, 0);                     \
+        A0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0l, f.ah, A0, 0, 0, 0);                     \
+        A1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1l, f.ah, A1, 0, 0, 0);                     \
+        A0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b0h, f.ah, A0, 0, 0, 0);                     \
+        A1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b1h, f.ah, A1, 0, 0, 0);                     \
+    } else {                                                                                        \
+        A0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b0h, A0, 0, 0, 0);                     \
+        A1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.b1h, A1, 0, 0, 0);                     \
+        A0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0l, A0, 0, 0, 0);                     \
+        A1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1l, A1, 0, 0, 0);                     \
+        A0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b0h, A0, 0, 0, 0);                     \
+        A1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.b1h, A1, 0, 0, 0);                     \
+    }
+    auto mfma6 = [&](const Frags& f, int half) {         // half: compile-time after unrolling
+        if (NH == 1 || half == 0) { ISS_MFMA6(acc0, acc1) } else { ISS_MFMA6(acc2, acc3) }
     };
+#undef ISS_MFMA6
 
     // ---- software pipeline over the (tile, chunk, tap) sequence.  LDS: three weight stages (B(t), B(t+1), and
     //   the one B(t+2) is being DMA'd into) and the footprint of tap t's chunk.  Tap t:
@@ -333,9 +341,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
                     for (int q = q_lo; q < q_hi; ++q) fetch_fp_part(q, gx, nx_c0);
                 }
                 if (has3) dma_b(st3, (j + 3) % NT, (j + 3) >= NT ? ((j + 3) >= 2 * NT ? nx_c0 + XBK : nx_c0) : c0);
-                read_frags(fb, g, j / KW, j % KW, 1, st0);
+                read_frags(fb, g, (j / NH) / KW, (j / NH) % KW, 1, st0);
                 __builtin_amdgcn_s_setprio(3);
-                mfma6(fa);
+                mfma6(fa, j % NH);
                 __builtin_amdgcn_s_setprio(1);
                 if (has1) {
                     if (j == NT - 1) {               // tap t+1 opens the next chunk: swap the footprint.  Every wave
@@ -345,10 +353,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
                         __builtin_amdgcn_s_setprio(2);
                         __syncthreads();
                     }
-                    read_frags(fa, j == NT - 1 ? gx : g, ((j + 1) % NT) / KW, ((j + 1) % NT) % KW, 0, st1);
+                    read_frags(fa, j == NT - 1 ? gx : g, (((j + 1) % NT) / NH) / KW, (((j + 1) % NT) / NH) % KW, 0, st1);
                 }
                 __builtin_amdgcn_s_setprio(3);
-                mfma6(fb);
+                mfma6(fb, j % NH);
                 __builtin_amdgcn_s_setprio(1);
                 // B(t+1) was DMA'd during tap t-1; vmcnt counts in order, so allow exactly this tap's own VMEM
                 // operations (its footprint loads + 2 DMAs) to stay in flight.  hipcc's own waits for the footprint
@@ -375,12 +383,17 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         __builtin_amdgcn_s_setprio(0);
         if (TR) {
             epilogue_tr(p, acc0, acc1, (long long)tile * BM + wv * 32 + li, n0, lh);
+            if (NH == 2) epilogue_tr(p, acc2, acc3, (long long)tile * BM + wv * 32 + li, n0 + BN, lh);
         } else {
             epilogue_tile(p, acc0, (long long)tile * BM + wv * 32, n0 + li, lh);
             epilogue_tile(p, acc1, (long long)tile * BM + wv * 32, n0 + 32 + li, lh);
+            if (NH == 2) {
+                epilogue_tile(p, acc2, (long long)tile * BM + wv * 32, n0 + BN + li, lh);
+                epilogue_tile(p, acc3, (long long)tile * BM + wv * 32, n0 + BN + 32 + li, lh);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
         __builtin_amdgcn_s_setprio(2);
         g = gn;
     }
@@ -389,11 +402,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
 // one filter shape, all (PADDED, TR) variants; fused = shared first layer (ConvArgs::f_*), unpadded shapes with >= 12
 // taps only (one footprint slice per tap)
 template <int KH, int KW>
-void launch_fp_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused) {
+void launch_fp_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused, int nh) {
     if constexpr (KH * KW >= 12) {
         if (fused) {
             if (tr) hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, false, true, true>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, false, false, true>), grid, dim3(256), 0, st, a);
+            return;
+        }
+    }
+    if constexpr (KH == 3 && KW == 3) {              // two 64-column halves per workgroup (see iss_fp_has_nh2)
+        if (nh == 2) {
+            if (padded && tr) hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, true, true, false, 2>), grid, dim3(256), 0, st, a);
+            else if (padded) hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, true, false, false, 2>), grid, dim3(256), 0, st, a);
+            else if (tr) hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, false, true, false, 2>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, false, false, false, 2>), grid, dim3(256), 0, st, a);
             return;
         }
     }
@@ -402,16 +424,17 @@ void launch_fp_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, 
     else if (tr) hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, false, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_x3_fp_kernel<KH, KW, false, false>), grid, dim3(256), 0, st, a);
 }
+inline bool iss_fp_has_nh2(int kh, int kw) { return kh == 3 && kw == 3; }
 
 }  // namespace issk
 
 // Filter shapes the footprint kernel is instantiated for (the tap loop is unrolled at compile time); other shapes
 // run on conv_x3_kernel.  One extern launcher per shape, defined in the cnn_fp_*.hip units.
 #define ISS_FP_SHAPES(X) X(3, 3) X(5, 3) X(3, 5) X(5, 5) X(2, 2) X(4, 4) X(1, 3) X(3, 1)
-#define ISS_FP_DECL(KH_, KW_) void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused);
+#define ISS_FP_DECL(KH_, KW_) void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused, int nh);
 ISS_FP_SHAPES(ISS_FP_DECL)
 #undef ISS_FP_DECL
 #define ISS_FP_DEFINE(KH_, KW_)                                                                               \
-    void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused) { \
-        issk::launch_fp_shape<KH_, KW_>(a, grid, st, padded, tr, fused);                                          \
+    void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused, int nh) { \
+        issk::launch_fp_shape<KH_, KW_>(a, grid, st, padded, tr, fused, nh);                                          \
     }
