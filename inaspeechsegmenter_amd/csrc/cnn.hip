@@ -361,36 +361,46 @@ __global__ __launch_bounds__(256, 2) void conv1_patch_x3_kernel(const ConvArgs p
 //   R[t][x][c] = sum_{ky,kx} w[c][ky * kw + kx] * mspec[(row0 + t + ky) * 24 + x + kx]       (f32, FMA chain in k order)
 // One thread per (t, x, 4 channels), grid-stride (the weights are transposed into LDS once per workgroup).  Non-finite results are stored as 0: they only ever reach windows whose finite
 // flag is 0, and those are scaled by 0 (their normalised input is all zeros in the reference, segmenter.py:86-88).
+template <int KH_, int KW_>                       // compile-time filter shape (0, 0: run-time kh, kw)
 __global__ __launch_bounds__(256) void first_layer_raw_kernel(const float* __restrict__ mspec, int row0, long long total,
-                                                              int Wout, int Cout, int kh, int kw,
+                                                              int Wout, int Cout, int kh_, int kw_,
                                                               const float* __restrict__ w, int Kpad, float* __restrict__ R) {
     extern __shared__ __attribute__((aligned(16))) float sW[];     // [K][Cout]: a lane's 4 channels of tap k are one ds_read_b128
+    const int kh = KH_ ? KH_ : kh_, kw = KW_ ? KW_ : kw_;
     const int K = kh * kw;
     for (int e = threadIdx.x; e < K * Cout; e += 256) {
         const int co = e / K, k = e - co * K;
         sW[k * Cout + co] = w[(size_t)co * Kpad + k];
     }
     __syncthreads();
-    const int cg = Cout >> 2;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int c4 = (int)(idx % cg) * 4;
-        const long long pix = idx / cg;
-        const int x = (int)(pix % Wout);
-        const long long t = pix / Wout;
-        const float* src = mspec + (size_t)(row0 + t) * 24 + x;
+    const unsigned cg = (unsigned)Cout >> 2, utotal = (unsigned)total;       // total < 2^30 (host: 32-bit offsets into R)
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < utotal; idx += gridDim.x * 256u) {
+        const unsigned pix = idx / cg;
+        const int c4 = (int)(idx - pix * cg) * 4;
+        const unsigned t = pix / (unsigned)Wout;
+        const int x = (int)(pix - t * (unsigned)Wout);
+        const float* src = mspec + (size_t)(row0 + (int)t) * 24 + x;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int ky = 0; ky < kh; ++ky)
-            for (int kx = 0; kx < kw; ++kx) {
-                const float v = src[ky * 24 + kx];
-                const float4 wk = *reinterpret_cast<const float4*>(&sW[(ky * kw + kx) * Cout + c4]);
-                a0 = fmaf(v, wk.x, a0);
-                a1 = fmaf(v, wk.y, a1);
-                a2 = fmaf(v, wk.z, a2);
-                a3 = fmaf(v, wk.w, a3);
-            }
+        auto tap = [&](int ky, int kx) {
+            const float v = src[ky * 24 + kx];
+            const float4 wk = *reinterpret_cast<const float4*>(&sW[(ky * kw + kx) * Cout + c4]);
+            a0 = fmaf(v, wk.x, a0);
+            a1 = fmaf(v, wk.y, a1);
+            a2 = fmaf(v, wk.z, a2);
+            a3 = fmaf(v, wk.w, a3);
+        };
+        if constexpr (KH_ > 0) {
+#pragma unroll
+            for (int ky = 0; ky < KH_; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < KW_; ++kx) tap(ky, kx);
+        } else {
+            for (int ky = 0; ky < kh; ++ky)
+                for (int kx = 0; kx < kw; ++kx) tap(ky, kx);
+        }
         float4 o;
         o.x = isfinite(a0) ? a0 : 0.f; o.y = isfinite(a1) ? a1 : 0.f; o.z = isfinite(a2) ? a2 : 0.f; o.w = isfinite(a3) ? a3 : 0.f;
-        *reinterpret_cast<float4*>(R + idx * 4) = o;
+        *reinterpret_cast<float4*>(R + (size_t)idx * 4) = o;
     }
 }
 
@@ -794,10 +804,15 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 { const int rc = iss_reserve(c, c->raw1, (size_t)rtot * 16); if (rc) return rc; }
                 float* Rraw = (float*)c->raw1.p;
                 iss_prof_begin(c, 2, 0);
-                hipLaunchKernelGGL(first_layer_raw_kernel, dim3((unsigned)std::min<long long>((rtot + 255) / 256, 4096)), dim3(256),
-                                   (size_t)R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4, c->stream,
-                                   (const float*)c->mspec.p, rmin, rtot, R1[ISS_C_WO], R1[ISS_C_COUT], R1[ISS_C_KH], R1[ISS_C_KW],
-                                   (const float*)(n.d_blob + R1[ISS_C_WOFF]), n.kpad[pend], Rraw);
+                const dim3 rgrid((unsigned)std::min<long long>((rtot + 255) / 256, 4096));
+                const size_t rlds = (size_t)R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4;
+                if (R1[ISS_C_KH] == 4 && R1[ISS_C_KW] == 5)
+                    hipLaunchKernelGGL((first_layer_raw_kernel<4, 5>), rgrid, dim3(256), rlds, c->stream, (const float*)c->mspec.p, rmin, rtot,
+                                       R1[ISS_C_WO], R1[ISS_C_COUT], 4, 5, (const float*)(n.d_blob + R1[ISS_C_WOFF]), n.kpad[pend], Rraw);
+                else
+                    hipLaunchKernelGGL((first_layer_raw_kernel<0, 0>), rgrid, dim3(256), rlds, c->stream, (const float*)c->mspec.p, rmin, rtot,
+                                       R1[ISS_C_WO], R1[ISS_C_COUT], R1[ISS_C_KH], R1[ISS_C_KW],
+                                       (const float*)(n.d_blob + R1[ISS_C_WOFF]), n.kpad[pend], Rraw);
                 iss_prof_end(c);
                 a.in = Rraw; a.win_row = d_winrow; a.stats = d_stats; a.finite = d_fin;
                 a.f_bias = n.d_blob + R1[ISS_C_BOFF];
