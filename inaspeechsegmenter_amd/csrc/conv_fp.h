@@ -100,7 +100,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
     if (tile >= tile_end) return;
 
     // ---- per-tile geometry: first pixel of the tile (uniform) and this lane's A row
-    struct Geom { int p_lo, need, lanepix, iy0, ix0; int fy, fx, wr0, wr1; float mean0, mean1, sd0, sd1; bool live0, live1, two; };
+    struct Geom { int p_lo, need, lanepix, iy0, ix0; int fy, fx; bool two; };
+    // FUSED: per-window scalars of the (at most two) windows a tile's footprint touches.  They are LOADED, and hipcc's
+    // s_waitcnt bookkeeping treats a loaded register as possibly pending at every control-flow join: used directly in the
+    // tap loop (whose fetch block is conditional) they cost an s_waitcnt vmcnt(0) per tap, which also drains the weight
+    // DMAs.  So they are loaded one chunk ahead into `wn`, passed once through `settle` (an opaque asm the compiler must
+    // wait in front of) at the start of the tile's last chunk, and only the settled copies are used afterwards.
+    struct Win { int wr0, wr1; float mean0, mean1, sd0, sd1; int live0, live1; };
     auto geometry = [&](int t) {
         Geom g;
         const int m0 = t * BM;
@@ -122,21 +128,31 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         const int hi = FPIX - 1 - ((KH - 1) * p.W + (KW - 1));   // keeps every tap of a row >= M inside the buffer
         g.lanepix = lanepix < 0 ? 0 : (lanepix > hi ? hi : lanepix);
         if (FUSED) {
-            // first footprint pixel in the (window, y, x) grid of first-layer outputs, and the per-window scalars of the
-            // (at most two: H * W >= FPIX) windows the footprint touches: R row of the window's first row, mean, std,
-            // finite flag.  Only loaded here -- nothing below may USE them, or every tile would start with a full
-            // s_waitcnt vmcnt(0); stage_fp turns them into scale and shift one chunk later.
+            // first footprint pixel in the (window, y, x) grid of first-layer outputs (it touches at most two windows:
+            // H * W >= FPIX)
             map_row32(p, m0, b, oy, ox);
             g.fy = oy * p.sh; g.fx = ox * p.sw;
             g.two = g.fy * p.W + g.fx + g.need > p.H * p.W;          // footprint reaches into the next window
             const int nb = M / (p.Hq * p.Wq * p.pp);
-            const unsigned b0 = (unsigned)(b < nb ? b : nb - 1), b1 = (unsigned)(b + 1 < nb ? b + 1 : nb - 1);
-            g.wr0 = p.win_row[b0]; g.mean0 = p.stats[2u * b0]; g.sd0 = p.stats[2u * b0 + 1u]; g.live0 = p.finite[b0] != 0;
-            g.wr1 = p.win_row[b1]; g.mean1 = p.stats[2u * b1]; g.sd1 = p.stats[2u * b1 + 1u]; g.live1 = p.finite[b1] != 0;
         }
         return g;
     };
+    auto windows_of = [&](int t) {                   // loads only: nothing here may USE the values
+        Win w;
+        int b, oy, ox;
+        map_row32(p, t * BM, b, oy, ox);
+        const int nb = M / (p.Hq * p.Wq * p.pp);
+        const unsigned b0 = (unsigned)(b < nb ? b : nb - 1), b1 = (unsigned)(b + 1 < nb ? b + 1 : nb - 1);
+        w.wr0 = p.win_row[b0]; w.mean0 = p.stats[2u * b0]; w.sd0 = p.stats[2u * b0 + 1u]; w.live0 = p.finite[b0];
+        w.wr1 = p.win_row[b1]; w.mean1 = p.stats[2u * b1]; w.sd1 = p.stats[2u * b1 + 1u]; w.live1 = p.finite[b1];
+        return w;
+    };
+    auto settle = [&](Win& w) {
+        asm volatile("" : "+v"(w.wr0), "+v"(w.wr1), "+v"(w.mean0), "+v"(w.mean1), "+v"(w.sd0), "+v"(w.sd1), "+v"(w.live0), "+v"(w.live1));
+    };
     Geom g = geometry(tile), gn = g;
+    Win wc = {}, wn = {}, wx = {};                   // current tile (settled), next tile (pending), target of fetch / stage
+    if (FUSED) { wc = windows_of(tile); settle(wc); wx = wc; }
 
     // ---- weight tiles by LDS-DMA.  Wave wv moves slots [64 wv, 64 wv + 64) of the 256-slot tile: slot = row * 4 +
     // physical chunk; lane reads the LOGICAL chunk that belongs there (swizzle on the source side, LDS linear).
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
             int y = gg.fy + dy;
             const bool second = y >= p.H;
             y -= second ? p.H : 0;
-            const int row = y + (second ? gg.wr1 : gg.wr0) - p.f_rmin;
+            const int row = y + (second ? wx.wr1 : wx.wr0) - p.f_rmin;
             dbmask = (q == 0 ? 0u : dbmask) | (second ? 1u << q : 0u);       // slice 0 is the first fetch of every chunk
             fv[q] = *reinterpret_cast<const float4*>(p.in + ((unsigned)(row * p.W + x) * (unsigned)p.Cin + (unsigned)(c0 + k8 * 4)));
             return;
@@ -196,9 +212,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         if (FUSED) {
             // scale 1 / std and shift bias - mean / std * sum_k w of (window, channel).  A non-finite window is all zeros
             // in the reference (segmenter.py:86-88): scale 0, shift = bias.
-            rs0 = gt.live0 ? 1.0f / gt.sd0 : 0.f;
-            rs1 = gt.live1 ? 1.0f / gt.sd1 : 0.f;
-            const float mr0 = gt.live0 ? -gt.mean0 * rs0 : 0.f, mr1 = gt.live1 ? -gt.mean1 * rs1 : 0.f;
+            rs0 = wx.live0 ? 1.0f / wx.sd0 : 0.f;
+            rs1 = wx.live1 ? 1.0f / wx.sd1 : 0.f;
+            const float mr0 = wx.live0 ? -wx.mean0 * rs0 : 0.f, mr1 = wx.live1 ? -wx.mean1 * rs1 : 0.f;
             const float sw[4] = {fsw.x, fsw.y, fsw.z, fsw.w}, bw[4] = {fbw.x, fbw.y, fbw.z, fbw.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) { t0[i] = fmaf(sw[i], mr0, bw[i]); t1[i] = fmaf(sw[i], mr1, bw[i]); }
@@ -320,9 +336,19 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         for (int ch = 0; ch < nchunk; ++ch) {
             const int c0 = ch * XBK;
             const bool last_chunk = ch + 1 == nchunk;
-            const bool fin = last_chunk && last_tile;            // nothing follows this chunk
+            // The very last chunk of a workgroup prefetches / stages a footprint and weight tiles nobody will use (from the
+            // valid addresses of its last tile) instead of branching around them: with branches in the tap body hipcc's
+            // s_waitcnt bookkeeping loses track at every join and puts an s_waitcnt vmcnt(0) in front of each tap's
+            // footprint load, which drains the weight DMAs the counted waits below are there to keep in flight.
+            constexpr bool fin = false;
             // next tile's geometry one chunk early where possible: the fused variant loads per-window scalars in it
-            if (ch == (nchunk >= 2 ? nchunk - 2 : 0) && !last_tile) gn = geometry(tile + tstep);
+            if (ch == (nchunk >= 2 ? nchunk - 2 : 0) && !last_tile) {
+                gn = geometry(tile + tstep);
+                if (FUSED) wn = windows_of(tile + tstep);
+            }
+            if (FUSED) {                             // target windows of this chunk's fetches and of its closing stage_fp
+                if (last_chunk && !last_tile) { settle(wn); wx = wn; } else { wx = wc; }
+            }
             const Geom gx = last_chunk ? gn : g;                 // tile the next chunk's footprint belongs to (by value:
                                                                  // a runtime choice of references would pin both structs in scratch)
             const int nx_c0 = last_chunk ? 0 : c0 + XBK;
@@ -396,7 +422,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
         for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
         __builtin_amdgcn_s_setprio(2);
         g = gn;
+        if (FUSED) wc = wn;
     }
+    wait_vmcnt<0>();                                 // the unused prefetches of the last chunk
 }
 
 // one filter shape, all (PADDED, TR) variants; fused = shared first layer (ConvArgs::f_*), unpadded shapes with >= 12
