@@ -231,18 +231,23 @@ __global__ __launch_bounds__(256, 2) void conv_x3_fp_kernel(const ConvArgs p) {
             if (p.f_ps) { v.x = v.x * fps.x + fpt.x; v.y = v.y * fps.y + fpt.y; v.z = v.z * fps.z + fpt.z; v.w = v.w * fps.w + fpt.w; }
             return v;
         };
-        if (FUSED && !gt.two) {                      // usual case: the whole footprint lies in one window (uniform branch)
+        // slice q is staged if the tile needs it (uniform) and, for the last slice only, if the lane's pixel exists
+        auto live = [&](int q) { return 32 * q < gt.need && (32 * q + 31 < FPIX || prow + 32 * q < FPIX); };
+        if (FUSED && !gt.two && p.f_act == 1 && !p.f_ps) {
+            // usual case, unswitched by hand (one uniform branch per slice instead of four): the whole footprint lies in
+            // one window, relu, no post-activation affine
 #pragma unroll
             for (int q = 0; q < NFV; ++q) {
-                if (prow + 32 * q >= FPIX || 32 * q >= gt.need) continue;
+                if (!live(q)) continue;
                 const float4 r = fv[q];
-                put(q, act4(make_float4(fmaf(r.x, rs0, t0[0]), fmaf(r.y, rs0, t0[1]), fmaf(r.z, rs0, t0[2]), fmaf(r.w, rs0, t0[3]))));
+                put(q, make_float4(fmaxf(fmaf(r.x, rs0, t0[0]), 0.f), fmaxf(fmaf(r.y, rs0, t0[1]), 0.f),
+                                   fmaxf(fmaf(r.z, rs0, t0[2]), 0.f), fmaxf(fmaf(r.w, rs0, t0[3]), 0.f)));
             }
             return;
         }
 #pragma unroll
         for (int q = 0; q < NFV; ++q) {
-            if (prow + 32 * q >= FPIX || 32 * q >= gt.need) continue;
+            if (!live(q)) continue;
             float4 v = fv[q];
             if (FUSED) {
                 const bool second = (dbmask >> q) & 1u;
