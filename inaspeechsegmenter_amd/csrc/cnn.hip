@@ -772,6 +772,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             a.row_stride = a.W * a.Cin; a.pix_stride = a.Cin; a.img_stride = (long long)a.H * a.W * a.Cin;
         }
         a.nblk = (unsigned)((a.M + BM - 1) / BM);
+        set_fast_div(a, 0, a.pp); set_fast_div(a, 1, a.pw); set_fast_div(a, 2, a.Hq * a.Wq); set_fast_div(a, 3, a.Wq);
         { static const int dbg = getenv("ISS_DBG") ? atoi(getenv("ISS_DBG")) : 0; a.dbg = dbg; }
         a.nblk_n = (unsigned)((a.Cout + BN - 1) / BN);
         dim3 grid(a.nblk, a.nblk_n);

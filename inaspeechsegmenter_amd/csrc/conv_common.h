@@ -60,10 +60,27 @@ struct ConvArgs {
     const float* f_pt;
     int f_act;               // first layer activation: 0 none, 1 relu
     int f_rmin;              // log-mel row of `in`'s first row
+    // exact division of 0 <= n < 2^31 by pp, pw, Hq*Wq, Wq as mulhi + shift (Granlund-Montgomery, N = 31): the footprint
+    // kernel decomposes three GEMM rows per tile, and hipcc expands a 32-bit division by a run-time value into ~28 VALU ops
+    unsigned dv_mul[4];
+    int dv_sh[4];
     unsigned nblk;           // M tiles
     unsigned nblk_n;         // N tiles (generic kernels are launched 1-D: nblk * nblk_n workgroups)
     int dbg;                 // ISS_DBG experiment bits (0 in production)
 };
+
+// Host: magic constants of ConvArgs::dv_* for divisor d >= 1 (mul == 0 means d == 1).
+inline void set_fast_div(ConvArgs& a, int slot, int d) {
+    if (d <= 1) { a.dv_mul[slot] = 0; a.dv_sh[slot] = 0; return; }
+    int l = 0;
+    while ((1ll << l) < d) ++l;                                  // l = ceil(log2 d) >= 1
+    a.dv_mul[slot] = (unsigned)(((1ull << (31 + l)) / (unsigned long long)d) + 1ull);   // < 2^32
+    a.dv_sh[slot] = l - 1;
+}
+__device__ __forceinline__ int fast_div(const ConvArgs& p, int slot, int n) {
+    return p.dv_mul[slot] ? (int)(__umulhi((unsigned)n, p.dv_mul[slot]) >> p.dv_sh[slot]) : n;
+}
+
 
 // GEMM row -> (sample, oy, ox) of the convolution output it stands for
 __device__ __forceinline__ void map_row(const ConvArgs& p, long long m, int& b, int& oy, int& ox) {

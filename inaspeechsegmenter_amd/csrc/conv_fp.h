@@ -25,19 +25,19 @@ struct Frags { bf16x8 ah, al, b0h, b0l, b1h, b1l; };
 // B-stage parity and the footprint-slice schedule become constants.  (With a run-time tap loop the
 // scalar bookkeeping alone was ~80 SALU instructions + a dozen taken branches per 12 MFMAs, more
 // than the five issue slots a wave has between two back-to-back MFMAs.)
-// 32-bit replica of map_row (the launch guarantees M < 2^31): 64-bit integer division is ~100 scalar
-// instructions on gfx950 and this runs once per lane per tile.
+// 32-bit replica of map_row (the launch guarantees M < 2^31) on host-precomputed reciprocals (ConvArgs::dv_*):
+// it runs three times per tile, and run-time integer division is ~28 (32-bit) / ~100 (64-bit) instructions on gfx950.
 __device__ __forceinline__ void map_row32(const ConvArgs& p, int m, int& b, int& oy, int& ox) {
     int q = m, dy = 0, dx = 0;
     if (p.pp > 1) {
-        q = m / p.pp;
+        q = fast_div(p, 0, m);                       // m / pp
         const int j = m - q * p.pp;
-        dy = j / p.pw; dx = j - dy * p.pw;
+        dy = fast_div(p, 1, j); dx = j - dy * p.pw;  // j / pw
     }
     const int hw = p.Hq * p.Wq;
-    b = q / hw;
+    b = fast_div(p, 2, q);                           // q / (Hq * Wq)
     const int rem = q - b * hw;
-    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    const int qy = fast_div(p, 3, rem), qx = rem - qy * p.Wq;    // rem / Wq
     oy = qy * p.ph + dy;
     ox = qx * p.pw + dx;
 }
