@@ -248,6 +248,139 @@ __global__ __launch_bounds__(256, NTN <= 4 ? 2 : 1) void conv_x3_kernel(const Co
     }
 }
 
+// Pointwise (1x1, stride 1, unpadded) convolutions = plain GEMMs on the NHWC pixel list: half of ResNet-101's flops in
+// layers with K = 64 .. 512, i.e. 2 - 16 k-tiles per 128 x 64 output tile.  With one tile per workgroup (conv_x3_kernel)
+// the first global load of every workgroup (~2 us) and its epilogue are exposed: rocprofv3 --pmc showed those launches at
+// 2 TB/s of HBM traffic and 10 % of the matrix peak -- latency-bound, not bandwidth-bound.  Here 2 x 256 persistent
+// workgroups walk the XCD-aware tile order and the register prefetch runs ACROSS tiles (the next tile's first k-tile is
+// fetched during the current tile's last one, its stores drain behind the next tile's MFMAs); no row decomposition
+// (row m of the GEMM is pixel m).
+__global__ __launch_bounds__(256, 2) void conv_x3_pw_kernel(const ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) uint16_t sAh[2][BM * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sAl[2][BM * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBh[2][BN * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBl[2][BN * XLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned ntiles = p.nblk * p.nblk_n;
+    unsigned t = blockIdx.x;
+    if (t >= ntiles) return;
+    const int k8 = tid & 7, lr = tid >> 3;           // A staging: k columns [4 k8, 4 k8 + 4) of rows lr + 32 j
+    const int br = tid >> 2, bseg = tid & 3;         // B staging: 8 bf16 of weight row br, hi and lo
+    // A tile of the GEMM: uniform 64-bit base of its first row + 32-bit per-lane offsets (rows >= M re-read row M - 1:
+    // their accumulator rows are never stored).  No masks and no branches around the loads: a select or a branch right
+    // behind a load makes hipcc wait for it on the spot, in front of the MFMAs it is meant to overlap.
+    struct Tile { long long m0; int n0; const float* abase; unsigned ao[4]; unsigned wo; };
+    auto coords = [&](unsigned tt) {
+        Tile T;
+        unsigned mt, nt;
+        gemm_tile_of_block(tt, p.nblk, p.nblk_n, mt, nt);
+        T.m0 = (long long)mt * BM;
+        T.n0 = (int)nt * BN;
+        T.abase = p.in + T.m0 * p.Cin;
+        const int left = (int)(p.M - T.m0 < BM ? p.M - T.m0 : BM);            // rows of this tile that exist
+#pragma unroll
+        for (int j = 0; j < 4; ++j) T.ao[j] = (unsigned)((lr + 32 * j < left ? lr + 32 * j : left - 1) * p.Cin + k8 * 4);
+        T.wo = (unsigned)((T.n0 + br < p.Cout ? T.n0 + br : 0) * p.Kpad + bseg * 8);
+        return T;
+    };
+    // Two register sets: a k-tile's loads are issued two iterations before they are converted into LDS.  One iteration is
+    // only 12 MFMAs (~0.2 us) against ~2 us of memory latency, so what bounds these layers is the number of bytes in
+    // flight; with a one-iteration distance the launches ran at 2 TB/s and 10 % of the matrix peak.
+    struct Regs { float4 a[4]; uint4 bh, bl; };
+    auto gather = [&](Regs& r, const Tile& T, int kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.a[j] = *reinterpret_cast<const float4*>(T.abase + (T.ao[j] + (unsigned)(kt * XBK)));
+        r.bh = *reinterpret_cast<const uint4*>(p.wh + (T.wo + (unsigned)(kt * XBK)));
+        r.bl = *reinterpret_cast<const uint4*>(p.wl + (T.wo + (unsigned)(kt * XBK)));
+    };
+    auto stage = [&](Regs& r, int buf) {
+        // opaque pass-through: the conversion can only start here, behind the MFMAs of the iteration
+        asm volatile("" : "+v"(r.a[0].x), "+v"(r.a[0].y), "+v"(r.a[0].z), "+v"(r.a[0].w), "+v"(r.a[1].x), "+v"(r.a[1].y), "+v"(r.a[1].z),
+                          "+v"(r.a[1].w), "+v"(r.a[2].x), "+v"(r.a[2].y), "+v"(r.a[2].z), "+v"(r.a[2].w), "+v"(r.a[3].x), "+v"(r.a[3].y),
+                          "+v"(r.a[3].z), "+v"(r.a[3].w));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 h, l;
+            split4(r.a[j], h, l);
+            *reinterpret_cast<bf16x4*>(&sAh[buf][(lr + 32 * j) * XLD + k8 * 4]) = h;
+            *reinterpret_cast<bf16x4*>(&sAl[buf][(lr + 32 * j) * XLD + k8 * 4]) = l;
+        }
+        *reinterpret_cast<uint4*>(&sBh[buf][br * XLD + bseg * 8]) = r.bh;
+        *reinterpret_cast<uint4*>(&sBl[buf][br * XLD + bseg * 8]) = r.bl;
+    };
+
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const int nk = p.Kpad / XBK;
+    const int li = lane & 31, lh = lane >> 5;
+    const int aoff = (wv * 32 + li) * XLD + lh * 8;
+    const int boff_s = li * XLD + lh * 8;
+
+    // load cursor (tile, k-tile), two iterations ahead of the compute cursor; past the last tile it re-reads that tile
+    unsigned tl = t;
+    Tile TL = coords(t);
+    int ktl = 0;
+    auto advance_load = [&]() {
+        if (++ktl == nk) {
+            ktl = 0;
+            tl = tl + gridDim.x < ntiles ? tl + gridDim.x : tl;
+            TL = coords(tl);
+        }
+    };
+    Tile TC = TL;                                    // compute cursor
+    int ktc = 0;
+    Regs r0, r1;
+    gather(r0, TL, ktl); advance_load();
+    gather(r1, TL, ktl); advance_load();
+    stage(r0, 0);
+    __syncthreads();
+    int cur = 0;
+    bool done = false;
+    auto step = [&](Regs& rload, Regs& rstage) {     // one k-tile: loads for +2, MFMAs on `cur`, convert +1 into the other buffer
+        gather(rload, TL, ktl);
+        advance_load();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sAh[cur][aoff + ks * 16]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sAl[cur][aoff + ks * 16]);
+            const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + ks * 16]);
+            const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + ks * 16]);
+            const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + 32 * XLD + ks * 16]);
+            const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + 32 * XLD + ks * 16]);
+            // C^T: rows = channels, columns = pixels (epilogue_tr); two independent accumulators alternate
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0h, al, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1h, al, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0l, ah, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1l, ah, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0h, ah, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1h, ah, acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(rstage, cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        if (++ktc == nk) {                           // tile complete
+            epilogue_tr(p, acc0, acc1, TC.m0 + wv * 32 + li, TC.n0, lh);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+            ktc = 0;
+            t += gridDim.x;
+            if (t >= ntiles) done = true; else TC = coords(t);
+        }
+    };
+    while (true) {
+        step(r0, r1);                                // r0 was staged last: free to load; r1 holds the next k-tile
+        if (done) break;
+        step(r1, r0);
+        if (done) break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // First layer on the z-normalised 68 x h log-mel window (PATCH input, Cin = 1, kh*kw <= 32), bf16x3.
 //
@@ -847,6 +980,11 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const int ntn = 2;
             a.nblk_n = (unsigned)((a.Cout + 32 * ntn - 1) / (32 * ntn));
             const dim3 gridw(a.nblk * a.nblk_n);
+            static const bool no_pw = getenv("ISS_NO_PW") != nullptr;
+            const bool pointwise = !no_pw && a.mode == 0 && tr && a.H_k == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt_ == 0 &&
+                                   a.pl_ == 0 && R[ISS_C_HO] == a.H && R[ISS_C_WO] == a.W && a.Kpad == a.Cin;
+            if (pointwise) hipLaunchKernelGGL(conv_x3_pw_kernel, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), dim3(256), 0, c->stream, a);
+            else
             if (ntn == 4) hipLaunchKernelGGL((conv_x3_kernel<0, true, 4>), gridw, dim3(256), 0, c->stream, a);
             else if (a.mode == 0 && tr) hipLaunchKernelGGL((conv_x3_kernel<0, true, 2>), gridw, dim3(256), 0, c->stream, a);
             else if (a.mode == 0) hipLaunchKernelGGL((conv_x3_kernel<0, false, 2>), gridw, dim3(256), 0, c->stream, a);
