@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pw_kernel(const ConvArgs p) {
         __syncthreads();
         cur ^= 1;
         if (++ktc == nk) {                           // tile complete
-            epilogue_tr(p, acc0, acc1, TC.m0 + wv * 32 + li, TC.n0, lh);
+            epilogue_tr<true>(p, acc0, acc1, TC.m0 + wv * 32 + li, TC.n0, lh);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
             ktc = 0;

@@ -190,11 +190,23 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const floatx16&
 // (pixel) m, register group g of tile t = output channels n0 + 32 t + 8 g + 4 lh + {0..3}.  Every access is a float4:
 // bias / scale / shift, the residual, and the store (8 x 16 B per lane and tile pair instead of 32 x 4 B).  Needs
 // pp == 1 and Cout % 4 == 0 (parameter offsets in the blob are multiples of 8 floats).
+template <bool PRELOAD_RES = false>
 __device__ __forceinline__ void epilogue_tr(const ConvArgs& p, const floatx16& acc0, const floatx16& acc1, long long m,
                                             int n0, int lh) {
     if (m >= p.M) return;
     float* orow = p.out + (size_t)m * p.Cout;
     const float* rrow = p.res ? p.res + (size_t)m * p.Cout : nullptr;
+    // PRELOAD_RES: all eight residual loads first, back to back: inside the per-group code below each one is waited for
+    // on the spot (8 serial round trips to L2 / HBM per tile -- most of the pointwise ResNet layers' time).  Costs 32
+    // VGPRs, which the footprint kernels do not have to spare (their residual-free or 3x3 layers gain nothing from it).
+    float4 r4[8];
+    if (PRELOAD_RES && rrow) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = n0 + 32 * (i >> 2) + 8 * (i & 3) + 4 * lh;
+            r4[i] = *reinterpret_cast<const float4*>(rrow + (c < p.Cout ? c : 0));     // columns >= Cout are not stored
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -207,7 +219,10 @@ __device__ __forceinline__ void epilogue_tr(const ConvArgs& p, const floatx16& a
             v.z = t == 0 ? acc0[4 * g + 2] : acc1[4 * g + 2];
             v.w = t == 0 ? acc0[4 * g + 3] : acc1[4 * g + 3];
             if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + c); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
-            if (rrow) { const float4 r4 = *reinterpret_cast<const float4*>(rrow + c); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+            if (rrow) {
+                const float4 r = PRELOAD_RES ? r4[4 * t + g] : *reinterpret_cast<const float4*>(rrow + c);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
             if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             else if (p.act > 1) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
             if (p.ps) {
