@@ -13,6 +13,7 @@
 //                        (hi*hi + hi*lo + lo*hi, f32 accumulate): 2^-16 relative operand error,
 //                        i.e. float32-class results at 16/3 x the f32-MFMA rate (gfx950 has no
 //                        xf32/TF32).  Default.
+//   conv_x3_pw_kernel    1x1 stride-1 convolutions / dense layers: persistent GEMM, prefetch two k-tiles ahead
 //   conv_igemm_kernel    the same GEMM on v_mfma_f32_32x32x2_f32 (exact f32, 157 TFLOP/s peak);
 //                        iss_set_precision(ctx, ISS_PREC_F32)
 //   both: fused bias, residual add, activation, post-activation scale/shift (BatchNorm),
