@@ -244,3 +244,28 @@ def test_hdf5_converter_roundtrip(tmp_path):
         for k in ('W', 'b', 'gamma', 'beta', 'mean', 'var'):
             if k in b and b[k] is not None:
                 assert np.array_equal(a[k], np.asarray(b[k], np.float32)), (a['type'], k)
+
+
+def test_fast_div_magic_numbers():
+    """The footprint kernel decomposes GEMM rows with host-precomputed reciprocals (conv_common.h set_fast_div / fast_div:
+    q = mulhi(n, M) >> s with M = floor(2^(31+l) / d) + 1, s = l - 1, l = ceil(log2 d)).  Exact for 0 <= n < 2^31
+    (Granlund-Montgomery, N = 31); this restates the formula and checks it, including the divisors the nets produce."""
+    import random
+
+    def magic(d):
+        if d <= 1:
+            return 0, 0
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        return ((1 << (31 + l)) // d) + 1, l - 1
+
+    rnd = random.Random(5)
+    for d in list(range(1, 130)) + [915, 1098, 1105, 1300, 65535, 65536, 65537, 999983, 2 ** 30 - 1, 2 ** 30, 2 ** 31 - 1]:
+        m, sh = magic(d)
+        assert m < 2 ** 32
+        top = (2 ** 31 - 1) // d * d
+        for n in [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, top - 1, top, 2 ** 31 - 1] + [rnd.randrange(2 ** 31) for _ in range(300)]:
+            if 0 <= n < 2 ** 31:
+                q = n if m == 0 else ((n * m) >> 32) >> sh
+                assert q == n // d, (d, n)
