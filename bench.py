@@ -121,13 +121,13 @@ def bench_vbx(args, torch, dev, local_rank, rank, world):
     """BASELINE.json configs[4]: 1 h of 16 kHz audio through get_features (VBx 64-band fbank + CMN) and the
     ResNet-101 x-vector network (144-frame windows, hop 24) -- not the headline metric, printed for DESIGN.md."""
     from inaspeechsegmenter_amd import _native, vbx as V
-    from oracle import vbx as ovbx                       # only for the seeded stand-in parameters
+    from inaspeechsegmenter_amd import keras_model as KM
     ctx = _native.Context(local_rank)
     ctx.set_precision(_native.PREC_BF16X3 if args.precision == 'bf16x3' else _native.PREC_F32)
     if args.workspace_mb:
         ctx.set_workspace_limit(args.workspace_mb << 20)
     fe = V.FeatureExtractor(ctx)
-    ex = V.VBxExtractor(ctx, ovbx.resnet101_random_params(0), batch_windows=512)
+    ex = V.VBxExtractor(ctx, KM.synthetic_resnet101(0), batch_windows=512)
     n = int(args.minutes * 60 * FS)
     sig = synth_recording(rank, n, dev).cpu().numpy().astype(np.float64) / 32768.0
     hours = n / FS / 3600.0

@@ -60,6 +60,16 @@ def lib():
         'iss_signal_pcm16': (C.c_int, [vp, pi16, i64]),
         'iss_signal_f32': (C.c_int, [vp, pf, i64]),
         'iss_signal_pcm16_device': (C.c_int, [vp, vp, i64]),
+        'iss_signal_pcm16_device_stream': (C.c_int, [vp, vp, i64, vp]),
+        'iss_host_alloc': (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+        'iss_host_free': (C.c_int, [vp, vp]),
+        'iss_cnn_probs_async': (C.c_int, [vp, C.c_int, pi32, i32, pf, pu8, pi64]),
+        'iss_wait': (C.c_int, [vp, i64]),
+        'iss_comm_unique_id': (C.c_int, [vp, pu8]),
+        'iss_comm_init': (C.c_int, [vp, pu8, i32, i32]),
+        'iss_comm_destroy': (C.c_int, [vp]),
+        'iss_allgather_segments': (C.c_int, [vp, pi32, i32, i32, pi32, pi32]),
+        'iss_comm_allreduce_max': (C.c_int, [vp, pd]),
         'iss_sidekit': (C.c_int, [vp, pi32]),
         'iss_get_loge': (C.c_int, [vp, pf]),
         'iss_get_mspec': (C.c_int, [vp, pf]),
@@ -127,9 +137,14 @@ class Context:
         self.T = 0
         self._net_out = {}
         self._dither_n = 0          # length of the dither stream cached on the device (vbx)
+        self._pinned = {}           # data address -> hipHostMalloc pointer of pinned_empty() arrays
+        self.comm_rank, self.comm_world = 0, 1
 
     def close(self):
         if getattr(self, '_h', None):
+            for p in list(self._pinned.values()):
+                self._L.iss_host_free(self._h, C.c_void_p(p))
+            self._pinned.clear()
             self._L.iss_destroy(self._h)
             self._h = None
 
@@ -161,8 +176,30 @@ class Context:
             raise TypeError(f"signal dtype {sig.dtype}: need int16 or float32")
         self._keep = sig            # the async H2D copy reads it until the next sync
 
-    def set_signal_device(self, dev_ptr, n):
-        self._ck(self._L.iss_signal_pcm16_device(self._h, C.c_void_p(int(dev_ptr)), int(n)), 'iss_signal_pcm16_device')
+    def set_signal_device(self, dev_ptr, n, producer_stream=None):
+        """PCM16 samples already in this GPU's HBM.  The library's stream is made to wait for everything submitted so
+        far to `producer_stream` (a hipStream_t handle as int, e.g. torch.cuda.current_stream().cuda_stream; None = the
+        legacy default stream); see include/iss.h for the ordering contract."""
+        self._ck(self._L.iss_signal_pcm16_device_stream(self._h, C.c_void_p(int(dev_ptr)), int(n),
+                                                        C.c_void_p(int(producer_stream)) if producer_stream else None),
+                 'iss_signal_pcm16_device')
+
+    # ---- page-locked host arrays
+    def pinned_empty(self, shape, dtype):
+        """numpy array backed by hipHostMalloc memory (freed with the context, or by `pinned_free`)."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        self._ck(self._L.iss_host_alloc(self._h, n, C.byref(p)), 'iss_host_alloc')
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def pinned_free(self, a):
+        p = self._pinned.pop(a.ctypes.data, None)
+        if p is not None and self._h:
+            self._ck(self._L.iss_host_free(self._h, C.c_void_p(p)), 'iss_host_free')
 
     def sidekit(self):
         t = C.c_int32()
@@ -206,6 +243,56 @@ class Context:
         self._ck(self._L.iss_cnn_probs(self._h, net_id, _ptr(wr, C.c_int32), n, _ptr(probs, C.c_float),
                                        _ptr(fin, C.c_uint8)), 'iss_cnn_probs')
         return probs, fin.astype(bool)
+
+    def cnn_probs_async(self, net_id, win_row, probs_out=None, finite_out=None):
+        """Enqueue iss_cnn_probs and return (ticket, probs, finite_u8); the arrays are valid after wait(ticket).
+        Pass pinned_empty() arrays as outputs if the D2H copy is to overlap host work."""
+        wr = np.ascontiguousarray(win_row, dtype=np.int32)
+        n = wr.size
+        if probs_out is None:
+            probs_out = np.empty((n, self._net_out[net_id]), dtype=np.float32)
+        if finite_out is None:
+            finite_out = np.empty(n, dtype=np.uint8)
+        assert probs_out.size >= n * self._net_out[net_id] and finite_out.size >= n
+        t = C.c_int64(-1)
+        self._ck(self._L.iss_cnn_probs_async(self._h, net_id, _ptr(wr, C.c_int32), n, _ptr(probs_out, C.c_float),
+                                             _ptr(finite_out, C.c_uint8), C.byref(t)), 'iss_cnn_probs_async')
+        return t.value, probs_out, finite_out
+
+    def wait(self, ticket=-1):
+        self._ck(self._L.iss_wait(self._h, int(ticket)), 'iss_wait')
+
+    # ---- multi-GPU exchange (RCCL)
+    def comm_unique_id(self):
+        buf = np.zeros(128, dtype=np.uint8)
+        self._ck(self._L.iss_comm_unique_id(self._h, _ptr(buf, C.c_uint8)), 'iss_comm_unique_id')
+        return buf.tobytes()
+
+    def comm_init(self, uid, rank, world):
+        buf = np.frombuffer(bytes(uid), dtype=np.uint8).copy()
+        assert buf.size == 128
+        self._ck(self._L.iss_comm_init(self._h, _ptr(buf, C.c_uint8), int(rank), int(world)), 'iss_comm_init')
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_destroy(self):
+        self._ck(self._L.iss_comm_destroy(self._h), 'iss_comm_destroy')
+        self.comm_rank, self.comm_world = 0, 1
+
+    def allgather_segments(self, rows, capacity):
+        """rows: (k,4) int32 of this rank -> ((world, capacity, 4) int32, counts (world,)); rank r's first
+        min(counts[r], capacity) rows are valid."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
+        world = self.comm_world
+        out = np.zeros((world, capacity, 4), dtype=np.int32)
+        counts = np.zeros(world, dtype=np.int32)
+        self._ck(self._L.iss_allgather_segments(self._h, _ptr(rows, C.c_int32), rows.shape[0], int(capacity),
+                                                _ptr(out, C.c_int32), _ptr(counts, C.c_int32)), 'iss_allgather_segments')
+        return out, counts
+
+    def comm_allreduce_max(self, value):
+        v = C.c_double(float(value))
+        self._ck(self._L.iss_comm_allreduce_max(self._h, C.byref(v)), 'iss_comm_allreduce_max')
+        return v.value
 
     def cnn_forward(self, net_id, x):
         x = np.ascontiguousarray(x, dtype=np.float32)

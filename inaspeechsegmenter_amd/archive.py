@@ -3,10 +3,10 @@
 The reference scales out with a Pyro4 pull queue handing (src, dst) pairs to independent
 `batch_process` workers (scripts/ina_speech_segmenter_pyro_server.py:34-68, ..._client.py:64-74).
 Here the same independence is used inside one node: one process per GPU (launch with
-`python -m torch.distributed.run --nproc-per-node N ...`), files dealt to ranks by size
+`python -m torch.distributed.run --nproc-per-node N ...` or any launcher that sets RANK / WORLD_SIZE), files dealt to ranks by size
 (sharding.shard_files), every rank runs its own files through its own Segmenter and writes their
-outputs, and ONE all-gather of int32 segment tables (RCCL) leaves the complete
-{file: segments} table on every rank.  Without torch.distributed it degrades to a plain loop.
+outputs, and ONE all-gather of int32 segment tables (`iss_allgather_segments`: ncclAllGather from librccl, no torch)
+leaves the complete {file: segments} table on every rank.  Without a communicator it degrades to a plain loop.
 """
 import os
 import sys
@@ -15,27 +15,32 @@ import time
 import numpy as np
 
 from . import sharding
+from ._native import NativeError
 from .export_funcs import seg2csv, seg2textgrid
 
 
-def _dist():
-    try:
-        import torch.distributed as dist
-        return dist if dist.is_available() and dist.is_initialized() else None
-    except ImportError:
-        return None
+def _default_comm(device):
+    """A running torch.distributed process group, if the caller set one up (CPU tests: gloo); else single process.
+    torch is only looked at when the caller has already imported it."""
+    dist = getattr(sys.modules.get('torch'), 'distributed', None)
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        return sharding.TorchComm(device=device)
+    return None
 
 
 def segment_archive(segment_file, linput, loutput=None, output_format='csv', sizes=None, skipifexist=False,
-                    capacity=None, device=None):
+                    capacity=None, device=None, comm=None):
     """segment_file(path) -> [(label, start_sec, stop_sec)] with times on the 20 ms grid (what
     Segmenter.__call__ returns).  linput / loutput: all files, identical on every rank.
     Returns (table, lmsg): table = {file_index: [(label, start_sec, stop_sec)]} for ALL files (gathered),
     lmsg = this rank's [(dst, code, text)] in the reference's batch_process convention
-    (0 ok / 1 already exists / 2 error, segmenter.py:352,370,372)."""
-    dist = _dist()
-    world = dist.get_world_size() if dist else 1
-    rank = dist.get_rank() if dist else 0
+    (0 ok / 1 already exists / 2 error, segmenter.py:352,370,372).
+    comm: sharding.RcclComm (GPU box: the C-ABI's ncclAllGather) or sharding.TorchComm; None = a running
+    torch.distributed group if there is one, else a single process."""
+    if comm is None:
+        comm = _default_comm(device)
+    world = comm.world if comm else 1
+    rank = comm.rank if comm else 0
     if output_format not in ('csv', 'textgrid'):
         raise NotImplementedError()
     fexport = seg2csv if output_format == 'csv' else seg2textgrid
@@ -51,20 +56,23 @@ def segment_archive(segment_file, linput, loutput=None, output_format='csv', siz
         b = time.time()
         try:
             lseg = segment_file(linput[i])
-            if dst is not None:
-                d = os.path.dirname(dst)
-                if d and not os.path.isdir(d):
-                    os.makedirs(d, exist_ok=True)
-                fexport(lseg, dst)
-            slots = [(lab, int(round(s / .02)), int(round(e / .02))) for lab, s, e in lseg]
-            rows.append(sharding.pack_segments(i, slots))
-            lmsg.append((dst, 0, 'ok ' + str(time.time() - b)))
-        except Exception:                                     # per-file errors do not stop the archive (segmenter.py:364-370)
-            lmsg.append((dst, 2, 'error: ' + str(sys.exc_info()[0])))
+        except NativeError:                                   # a broken device context is not a per-file problem
+            raise
+        except Exception as exc:                              # undecodable / missing / too short media do not stop the
+            lmsg.append((dst, 2, 'error: %s %s' % (type(exc), exc)))   # archive (segmenter.py:364-370; ffmpeg failures are
+            continue                                          # plain Exception(stderr), io.py:72-75)
+        if dst is not None:                                   # export errors propagate, as in the reference (:322)
+            d = os.path.dirname(dst)
+            if d and not os.path.isdir(d):
+                os.makedirs(d, exist_ok=True)
+            fexport(lseg, dst)
+        slots = [(lab, int(round(s / .02)), int(round(e / .02))) for lab, s, e in lseg]
+        rows.append(sharding.pack_segments(i, slots))
+        lmsg.append((dst, 0, 'ok ' + str(time.time() - b)))
     local = np.concatenate(rows, axis=0) if rows else np.zeros((0, 4), np.int32)
-    if dist:
+    if comm:
         cap = capacity or max(1024, 64 * (len(linput) // world + 1))
-        allrows = sharding.allgather_segment_tables(local, capacity=cap, device=device)
+        allrows = comm.allgather(local, cap)
     else:
         allrows = local
     return sharding.unpack_segments(allrows), lmsg

@@ -1043,8 +1043,13 @@ int plan_chunk(iss_ctx* c, IssNet& n, int total, int* bc_out) {
     int64_t bc = (int64_t)(c->ws_limit / (uint64_t)(per * sizeof(float)));
     if (bc < 1) bc = 1;
     if (bc > total) bc = total;
+    // keep every per-buffer float index below 2^31: several kernels form element offsets in 32 bits (first_layer_raw_kernel's
+    // `(unsigned)total`, the footprint kernels' row * Cout offsets), whatever workspace limit the caller has set
+    int64_t emax = 1;
+    for (auto e : n.buf_elems) emax = std::max<int64_t>(emax, e);
+    bc = std::min<int64_t>(bc, ((1ll << 31) - 1) / emax);
+    if (bc < 1) return iss_fail(c, ISS_EINVAL, "network activation of %lld floats per sample exceeds the 2^31 element limit", (long long)emax);
     if (bc > 8) bc -= bc % 8;
-    // keep every per-buffer float index below 2^31 (ConvArgs uses 64-bit bases, pool uses 64-bit too; this is a sanity cap)
     if ((int)c->act.size() < n.nbuf) c->act.resize(n.nbuf);
     for (int i = 0; i < n.nbuf; ++i) {
         int rc = iss_reserve(c, c->act[i], (size_t)bc * n.buf_elems[i] * sizeof(float));
@@ -1056,9 +1061,10 @@ int plan_chunk(iss_ctx* c, IssNet& n, int total, int* bc_out) {
 
 }  // namespace
 
-extern "C" int iss_cnn_probs(iss_ctx* c, int id, const int32_t* win_row, int32_t nslots, float* probs_out,
-                             uint8_t* finite_out) {
+static int cnn_probs_impl(iss_ctx* c, int id, const int32_t* win_row, int32_t nslots, float* probs_out,
+                          uint8_t* finite_out, bool async, int64_t* ticket_out) {
     if (!c) return ISS_EINVAL;
+    if (ticket_out) *ticket_out = -1;
     if (id < 0 || id >= ISS_MAX_NETS || nslots < 0 || (nslots > 0 && (!win_row || !probs_out || !finite_out)))
         return iss_fail(c, ISS_EINVAL, "iss_cnn_probs: bad argument");
     IssNet& n = c->nets[id];
@@ -1077,7 +1083,14 @@ extern "C" int iss_cnn_probs(iss_ctx* c, int id, const int32_t* win_row, int32_t
     if ((rc = iss_reserve(c, c->d_out, (size_t)nslots * n.out_dim * 4))) return rc;
     int bc = 0;
     if ((rc = plan_chunk(c, n, nslots, &bc))) return rc;
-    ISS_HIP(c, hipMemcpyAsync(c->d_winrow.p, win_row, (size_t)nslots * 4, hipMemcpyHostToDevice, c->stream));
+    if (async) {                                     // the caller may reuse win_row as soon as we return: stage it (pinned)
+        void* pinned; int slot;
+        if ((rc = iss_stage_host(c, win_row, (size_t)nslots * 4, &pinned, &slot))) return rc;
+        ISS_HIP(c, hipMemcpyAsync(c->d_winrow.p, pinned, (size_t)nslots * 4, hipMemcpyHostToDevice, c->stream));
+        iss_stage_mark(c, slot);
+    } else {
+        ISS_HIP(c, hipMemcpyAsync(c->d_winrow.p, win_row, (size_t)nslots * 4, hipMemcpyHostToDevice, c->stream));
+    }
     iss_prof_begin(c, 2, 0);
     hipLaunchKernelGGL(patch_stats_kernel, dim3((nslots + 3) / 4), dim3(256), 0, c->stream, (const float*)c->mspec.p,
                        (const int32_t*)c->d_winrow.p, nslots, n.in_w, (float*)c->d_stats.p, (uint8_t*)c->d_finite.p);
@@ -1085,7 +1098,8 @@ extern "C" int iss_cnn_probs(iss_ctx* c, int id, const int32_t* win_row, int32_t
     ISS_HIP(c, hipGetLastError());
     // Shared first layer (ConvArgs::f_*): decided per call from the whole window list, not per chunk, so that the result
     // does not depend on the workspace limit: on when the windows overlap at least 4-fold on average.
-    bool share = !getenv("ISS_NO_FUSE");
+    static const bool no_fuse = getenv("ISS_NO_FUSE") != nullptr;
+    bool share = !no_fuse;
     {
         int gmin = win_row[0], gmax = win_row[0];
         for (int i = 1; i < nslots; ++i) { gmin = std::min(gmin, win_row[i]); gmax = std::max(gmax, win_row[i]); }
@@ -1108,9 +1122,28 @@ extern "C" int iss_cnn_probs(iss_ctx* c, int id, const int32_t* win_row, int32_t
     ISS_HIP(c, hipGetLastError());
     ISS_HIP(c, hipMemcpyAsync(probs_out, c->d_out.p, (size_t)tot * 4, hipMemcpyDeviceToHost, c->stream));
     ISS_HIP(c, hipMemcpyAsync(finite_out, c->d_finite.p, (size_t)nslots, hipMemcpyDeviceToHost, c->stream));
+    if (async) {
+        hipEvent_t ev;
+        if (!c->ev_pool.empty()) { ev = c->ev_pool.back(); c->ev_pool.pop_back(); }
+        else ISS_HIP(c, hipEventCreate(&ev));
+        ISS_HIP(c, hipEventRecord(ev, c->stream));
+        c->ticket_ev.push_back(ev);
+        if (ticket_out) *ticket_out = c->ticket_base + (int64_t)c->ticket_ev.size() - 1;
+        return ISS_OK;
+    }
     ISS_HIP(c, hipStreamSynchronize(c->stream));
     iss_prof_collect(c);
     return ISS_OK;
+}
+
+extern "C" int iss_cnn_probs(iss_ctx* c, int id, const int32_t* win_row, int32_t nslots, float* probs_out,
+                             uint8_t* finite_out) {
+    return cnn_probs_impl(c, id, win_row, nslots, probs_out, finite_out, false, nullptr);
+}
+
+extern "C" int iss_cnn_probs_async(iss_ctx* c, int id, const int32_t* win_row, int32_t nslots, float* probs_out,
+                                   uint8_t* finite_out, int64_t* ticket_out) {
+    return cnn_probs_impl(c, id, win_row, nslots, probs_out, finite_out, true, ticket_out);
 }
 
 extern "C" int iss_cnn_forward(iss_ctx* c, int id, const float* x, int32_t nsamp, float* out) {

@@ -82,6 +82,11 @@ extern "C" void iss_destroy(iss_ctx* c) {
     for (auto& b : c->act) free_buf(b);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto& e : c->ticket_ev) (void)hipEventDestroy(e);
+    for (auto& s : c->staging) { if (s.p) (void)hipHostFree(s.p); if (s.done) (void)hipEventDestroy(s.done); }
+    if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+    iss_comm_destroy(c);
+    free_buf(c->comm_send); free_buf(c->comm_recv);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -147,9 +152,96 @@ static int put_signal(iss_ctx* c, const void* host, int64_t n, size_t esz, int k
 }
 extern "C" int iss_signal_pcm16(iss_ctx* c, const int16_t* pcm, int64_t n) { return put_signal(c, pcm, n, 2, 1); }
 extern "C" int iss_signal_f32(iss_ctx* c, const float* sig, int64_t n) { return put_signal(c, sig, n, 4, 2); }
-extern "C" int iss_signal_pcm16_device(iss_ctx* c, const void* dev, int64_t n) {
+extern "C" int iss_signal_pcm16_device_stream(iss_ctx* c, const void* dev, int64_t n, void* producer_stream) {
     if (!c || (!dev && n > 0) || n < 0) return iss_fail(c, ISS_EINVAL, "iss_signal_pcm16_device: bad argument");
+    ISS_HIP(c, hipSetDevice(c->device));
+    if (n > 0) {
+        hipPointerAttribute_t at;
+        hipError_t e = hipPointerGetAttributes(&at, dev);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return iss_fail(c, ISS_EINVAL, "iss_signal_pcm16_device: %p is not a HIP allocation (%s)", dev, hipGetErrorString(e));
+        }
+        if (at.type != hipMemoryTypeDevice || at.device != c->device)
+            return iss_fail(c, ISS_EINVAL, "iss_signal_pcm16_device: pointer belongs to %s %d, the context runs on device %d",
+                            at.type == hipMemoryTypeDevice ? "device" : "host / managed memory of device", at.device, c->device);
+    }
+    // the library's stream is non-blocking: order it behind the producer explicitly (see iss.h)
+    if (!c->order_ev) ISS_HIP(c, hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
+    ISS_HIP(c, hipEventRecord(c->order_ev, (hipStream_t)producer_stream));
+    ISS_HIP(c, hipStreamWaitEvent(c->stream, c->order_ev, 0));
     c->sig_ptr = dev; c->sig_kind = 1; c->sig_n = n; c->have_feats = false;
+    return ISS_OK;
+}
+extern "C" int iss_signal_pcm16_device(iss_ctx* c, const void* dev, int64_t n) {
+    return iss_signal_pcm16_device_stream(c, dev, n, nullptr);
+}
+
+// ---------------------------------------------------------------- pinned host memory
+extern "C" int iss_host_alloc(iss_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return iss_fail(c, ISS_EINVAL, "iss_host_alloc: NULL argument");
+    *out = nullptr;
+    ISS_HIP(c, hipSetDevice(c->device));
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return iss_fail(c, ISS_ENOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    return ISS_OK;
+}
+extern "C" int iss_host_free(iss_ctx* c, void* p) {
+    if (!c) return ISS_EINVAL;
+    if (!p) return ISS_OK;
+    ISS_HIP(c, hipSetDevice(c->device));
+    ISS_HIP(c, hipStreamSynchronize(c->stream));     // nothing of ours may still read / write it
+    ISS_HIP(c, hipHostFree(p));
+    return ISS_OK;
+}
+
+// Copy `bytes` of caller memory into a pinned staging buffer of the context (the caller may reuse its memory as soon
+// as we return; the async H2D copy then reads the staging buffer).  A buffer is reused once the event recorded by
+// iss_stage_mark behind its consumer has completed.
+int iss_stage_host(iss_ctx* c, const void* src, size_t bytes, void** pinned_out, int* slot_out) {
+    int slot = -1;
+    for (size_t i = 0; i < c->staging.size(); ++i) {
+        auto& s = c->staging[i];
+        if (s.busy && hipEventQuery(s.done) == hipSuccess) s.busy = false;
+        if (!s.busy && s.cap >= bytes && slot < 0) slot = (int)i;
+    }
+    if (slot < 0) {
+        for (size_t i = 0; i < c->staging.size() && slot < 0; ++i)        // grow an idle one rather than piling up buffers
+            if (!c->staging[i].busy) slot = (int)i;
+        if (slot < 0) { c->staging.emplace_back(); slot = (int)c->staging.size() - 1; }
+        auto& s = c->staging[slot];
+        if (s.p) { (void)hipHostFree(s.p); s.p = nullptr; s.cap = 0; }
+        const size_t want = bytes + (bytes >> 2) + 4096;
+        hipError_t e = hipHostMalloc(&s.p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { s.p = nullptr; return iss_fail(c, ISS_ENOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        s.cap = want;
+        if (!s.done) ISS_HIP(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    memcpy(c->staging[slot].p, src, bytes);
+    *pinned_out = c->staging[slot].p;
+    *slot_out = slot;
+    return ISS_OK;
+}
+void iss_stage_mark(iss_ctx* c, int slot) {
+    auto& s = c->staging[slot];
+    (void)hipEventRecord(s.done, c->stream);
+    s.busy = true;
+}
+
+extern "C" int iss_wait(iss_ctx* c, int64_t ticket) {
+    if (!c) return ISS_EINVAL;
+    ISS_HIP(c, hipSetDevice(c->device));
+    const int64_t last = c->ticket_base + (int64_t)c->ticket_ev.size() - 1;
+    if (ticket < 0 || ticket >= last) {
+        ISS_HIP(c, hipStreamSynchronize(c->stream));
+        for (auto e : c->ticket_ev) c->ev_pool.push_back(e);
+        c->ticket_base += (int64_t)c->ticket_ev.size();
+        c->ticket_ev.clear();
+        iss_prof_collect(c);
+        return ISS_OK;
+    }
+    if (ticket < c->ticket_base) return ISS_OK;       // already waited for
+    ISS_HIP(c, hipEventSynchronize(c->ticket_ev[(size_t)(ticket - c->ticket_base)]));
     return ISS_OK;
 }
 

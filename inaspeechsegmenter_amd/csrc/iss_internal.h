@@ -77,6 +77,19 @@ struct iss_ctx {
     int32_t vbx_T = 0;
     int64_t vbx_dither_n = 0;              // length of the dither stream cached in vbx_dither (0 = none)
 
+    // pinned staging buffers of the asynchronous entry points (window lists): reused once their copy has completed
+    struct Staging { void* p = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+    std::vector<Staging> staging;
+    // tickets of iss_cnn_probs_async: ticket t <-> ticket_ev[t - ticket_base]
+    std::vector<hipEvent_t> ticket_ev;
+    int64_t ticket_base = 1;
+    hipEvent_t order_ev = nullptr;        // iss_signal_pcm16_device*: producer stream -> library stream
+
+    // multi-GPU (RCCL, dlopen'ed)
+    void* comm = nullptr;                 // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
+    DevBuf comm_send, comm_recv;
+
     // profiling
     bool prof = false;
     double prof_ms[3] = {0, 0, 0};
@@ -89,6 +102,8 @@ struct iss_ctx {
 
 int iss_fail(iss_ctx* c, int code, const char* fmt, ...);
 int iss_reserve(iss_ctx* c, DevBuf& b, size_t bytes);
+int iss_stage_host(iss_ctx* c, const void* src, size_t bytes, void** pinned_out, int* slot_out);   // copy into a pinned staging buffer
+void iss_stage_mark(iss_ctx* c, int slot);                                                       // record 'consumed' on the stream
 
 #define ISS_HIP(c, call)                                                                  \
     do {                                                                                  \

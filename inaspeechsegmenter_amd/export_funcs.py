@@ -6,7 +6,7 @@ seg2csv      <-> export_funcs.py:29-31  pandas `DataFrame.to_csv(sep='\\t', inde
 seg2textgrid <-> export_funcs.py:33-39  pytextgrid `PraatTextGrid.save`: long ("ooTextFile")
                  format, one IntervalTier named inaSpeechSegmenter, `%f` times.
 Both are written natively (no pandas / pytextgrid import): per-file export cost matters when
-a node segments thousands of short files per second.  tests/test_export.py checks the bytes
+a node segments thousands of short files per second.  tests/test_host.py::test_exporters_byte_identical_to_reference_goldens checks the bytes
 against the reference's golden files (media/musanmix-smn-gender.{csv,TextGrid}) and against
 pandas.
 """

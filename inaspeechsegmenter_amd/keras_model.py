@@ -509,3 +509,34 @@ def synthetic_ina_like(nmel, nclasses, seed=0):
     L += [dict(type='flatten'), dense(h * w * 128, 192, 'linear'), bn(192), relu, dict(type='dropout'),
           dense(192, 128, 'relu'), dense(128, nclasses, 'softmax')]
     return L, (68, nmel, 1)
+
+
+def synthetic_resnet101(seed=0):
+    """Seeded, numerically tame ResNet-101 parameters keyed like resnet.py's state_dict (test / bench stand-in)."""
+    rng = np.random.default_rng(seed)
+    params = {}
+
+    def conv(name, cout, cin, k):
+        params[name + '.weight'] = rng.normal(0, np.sqrt(1.0 / (cin * k * k)), (cout, cin, k, k)).astype(np.float32)
+
+    def bn(name, c):
+        params[name + '.weight'] = rng.uniform(0.8, 1.2, c).astype(np.float32)
+        params[name + '.bias'] = rng.normal(0, 0.1, c).astype(np.float32)
+        params[name + '.running_mean'] = rng.normal(0, 0.1, c).astype(np.float32)
+        params[name + '.running_var'] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+
+    m = 32
+    conv('conv1', m, 1, 3); bn('bn1', m)
+    inp = m
+    for li, (planes, nblocks, stride) in enumerate(zip((m, 2 * m, 4 * m, 8 * m), (3, 4, 23, 3), (1, 2, 2, 2)), 1):
+        for bi in range(nblocks):
+            p = f'layer{li}.{bi}'
+            conv(p + '.conv1', planes, inp, 1); bn(p + '.bn1', planes)
+            conv(p + '.conv2', planes, planes, 3); bn(p + '.bn2', planes)
+            conv(p + '.conv3', 4 * planes, planes, 1); bn(p + '.bn3', 4 * planes)
+            if (stride if bi == 0 else 1) != 1 or inp != 4 * planes:
+                conv(p + '.shortcut.0', 4 * planes, inp, 1); bn(p + '.shortcut.1', 4 * planes)
+            inp = 4 * planes
+    params['embedding.weight'] = rng.normal(0, np.sqrt(1.0 / 16384), (256, 16384)).astype(np.float32)
+    params['embedding.bias'] = rng.normal(0, 0.05, 256).astype(np.float32)
+    return params

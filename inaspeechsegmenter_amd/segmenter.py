@@ -76,8 +76,8 @@ def _binidx2seglist(binidx):
     """Run-length encode a label sequence, segmenter.py:91-108 (vectorised)."""
     a = np.asarray(binidx)
     n = len(a)
-    if n == 0:
-        return [(None, -1, 0)]                          # what the reference's loop yields for []
+    if n == 0:                                          # (the reference's loop dies with UnboundLocalError on [])
+        raise ValueError('_binidx2seglist: empty label sequence')
     cut = np.flatnonzero(a[1:] != a[:-1]) + 1
     starts = np.concatenate(([0], cut))
     stops = np.concatenate((cut, [n]))
@@ -360,8 +360,10 @@ class Segmenter:
                 lseg = self.segment_feats(mspec, loge, difflen, 0)
                 fexport(lseg, dst)
                 lmsg.append((dst, 0, 'ok ' + str(time.time() - b)))
-            except Exception:                                      # feature errors count like decode errors (:364-370)
-                lmsg.append((dst, 2, 'error: ' + str(sys.exc_info()[0])))
+            except ValueError as exc:                              # undecodable / too short media: a per-file error like the
+                lmsg.append((dst, 2, 'error: %s %s' % (type(exc), exc)))   # reference's feature-extraction failures (:364-370).
+                # Device failures (NativeError) and unwritable outputs (OSError) propagate, as segment_feats / fexport
+                # errors do in the reference (:316-322): a broken context must not mark every remaining file 'error'.
             if verbose:
                 print('%d/%d' % (done, len(linput)), [lmsg[-1]])
         worker.join()

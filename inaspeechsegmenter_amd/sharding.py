@@ -3,9 +3,12 @@
 The reference has no multi-GPU code; its only scale-out facility is a Pyro4 pull queue that
 hands (src, dst) pairs to independent workers (scripts/ina_speech_segmenter_pyro_server.py:34-68)
 because files are independent units (segmenter.py:314-327 loops over them with no shared state).
-Here: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in the CPU tests), files are dealt to ranks up front, every rank segments its own files,
+Here: one process per GPU, files are dealt to ranks up front, every rank segments its own files,
 and ONE all-gather of a fixed-capacity int32 table collects all segment boundaries on every rank.
+On the GPU box the collective is `iss_allgather_segments` of the C-ABI (include/iss.h): ncclAllGather
+from librccl on the context's own stream -- no torch in that path (`RcclComm`; the 128-byte
+communicator id travels over a plain TCP socket, `rccl_rendezvous`).  `TorchComm` (torch.distributed,
+"gloo") exists for the world_size-2 CPU tests and for callers that already run a process group.
 
 Segment table row = (file_id, label_id, start_slot, stop_slot) int32; times are slot * 0.02 s
 (segmenter.py:276) and are materialised on the host after the gather.  Row 0 of each rank's
@@ -47,6 +50,110 @@ def unpack_segments(rows, start_sec=0):
     for fid, lid, a, b in np.asarray(rows).tolist():
         out.setdefault(fid, []).append((LABELS[lid], start_sec + a * .02, start_sec + b * .02))
     return out
+
+
+def _merge_gathered(parts, counts, capacity, regather):
+    """parts[r]: (capacity,4) rows of rank r, counts[r] = rows it has; one larger gather if someone overflowed."""
+    need = int(max(counts))
+    if need > capacity:                      # rare: some rank had more rows than agreed -> one bigger gather
+        parts, counts = regather(need)
+    out = [np.asarray(parts[r])[:int(counts[r])] for r in range(len(counts))]
+    return np.concatenate(out, axis=0) if out else np.zeros((0, 4), np.int32)
+
+
+class RcclComm:
+    """The exchange step on the GPU box: a native context whose communicator was set up by `rccl_rendezvous`."""
+
+    def __init__(self, ctx):
+        self.ctx, self.rank, self.world = ctx, ctx.comm_rank, ctx.comm_world
+
+    def allgather(self, rows, capacity):
+        rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
+        first = self.ctx.allgather_segments(rows, int(capacity))
+        return _merge_gathered(first[0], first[1], int(capacity), lambda cap: self.ctx.allgather_segments(rows, cap))
+
+    def max_over_ranks(self, value):
+        return self.ctx.comm_allreduce_max(value)
+
+    def barrier(self):
+        self.ctx.comm_allreduce_max(0.0)
+
+
+class TorchComm:
+    """Same interface on a torch.distributed process group ("gloo" in the CPU tests)."""
+
+    def __init__(self, group=None, device=None):
+        import torch.distributed as dist
+        self.group, self.device = group, device
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def allgather(self, rows, capacity):
+        return allgather_segment_tables(rows, capacity=capacity, device=self.device, group=self.group)
+
+    def max_over_ranks(self, value):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device or 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def barrier(self):
+        import torch.distributed as dist
+        dist.barrier(self.group)
+
+
+def exchange_unique_id(uid, rank, world, addr=None, port=None, timeout=120.0):
+    """Rank 0 hands `uid` (bytes) to the other ranks over TCP; returns the id on every rank.  addr / port default to
+    MASTER_ADDR (127.0.0.1) and ISS_RDV_PORT or MASTER_PORT + 1 (MASTER_PORT itself belongs to torchrun's store)."""
+    import os
+    import socket
+    import time
+    if world == 1:
+        return uid
+    addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(port or os.environ.get('ISS_RDV_PORT') or int(os.environ.get('MASTER_PORT', '29500')) + 1)
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        seen = set()
+        try:
+            while len(seen) < world - 1:
+                conn, _ = srv.accept()
+                with conn:
+                    conn.settimeout(timeout)
+                    r = int.from_bytes(conn.recv(4), 'little')
+                    conn.sendall(uid)
+                    seen.add(r)
+        finally:
+            srv.close()
+        return uid
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as conn:
+                conn.sendall(int(rank).to_bytes(4, 'little'))
+                buf = b''
+                while len(buf) < len(uid or b'\0' * 128):
+                    chunk = conn.recv(128 - len(buf))
+                    if not chunk:
+                        raise ConnectionError('rendezvous peer closed the connection')
+                    buf += chunk
+                return buf
+        except (ConnectionRefusedError, ConnectionResetError, socket.timeout, ConnectionError):
+            if time.time() > deadline:
+                raise
+            time.sleep(0.05)
+
+
+def rccl_rendezvous(ctx, rank, world, addr=None, port=None):
+    """Create the RCCL communicator of `ctx` (one context = one GPU = one rank) and return an `RcclComm`."""
+    uid = ctx.comm_unique_id() if rank == 0 else None
+    uid = exchange_unique_id(uid, rank, world, addr, port)
+    ctx.comm_init(uid, rank, world)
+    return RcclComm(ctx)
 
 
 def allgather_segment_tables(rows, capacity=4096, device=None, group=None):

@@ -4,7 +4,7 @@ They are built with the same numpy expressions the reference evaluates so that t
 (and, for the mel banks, the floor() bin decisions) are the ones the reference gets on the
 same host: sidekit_mfcc.py:118-197 (trfbank, nlinfilt=0 branch), :223 (numpy.hanning);
 features_vbx.py:31-59 (mel_fbank_mx, htk_bug=False), :123-124 (povey_window).
-tests/test_tables.py compares them with the committed reference outputs.
+tests/test_host.py::test_tables_match_reference compares them with the committed reference outputs.
 """
 import numpy as np
 

@@ -87,17 +87,23 @@ class VoiceFemininityScoring:
     def __init__(self, gd_model_criteria='bgc', backend='onnx', ffmpeg='ffmpeg', device=0, models=None):
         """gd_model_criteria / backend: as vbx_segmenter.py:97-127.  models: None -> files from the
         remote_utils search path (raw_81.pth for the x-vector net: the ONNX graph itself is not parsed here);
-        'synthetic' -> seeded stand-ins; or a dict {'resnet': state_dict-like, 'mlp': (layers, in_shape)}."""
+        'synthetic' -> seeded stand-ins; or a dict {'resnet': state_dict-like, 'mlp': (layers, in_shape),
+        'vad': the `models` argument of the inner Segmenter (optional; default = its Keras files)}."""
         assert backend in ['onnx'], "Backend should be 'onnx' (or 'pytorch' if uncommented)."
         assert gd_model_criteria in ['bgc', 'vfp'], "Gender detection model Criteria must be 'bgc' (default) or 'vfp'"
         gd_model, self.vad_thresh = ('interspeech2023_all.hdf5', 0.7) if gd_model_criteria == 'bgc' else ('interspeech2023_cvfr.hdf5', 0.62)
         self.ffmpeg = ffmpeg
-        self.vad = Segmenter(vad_engine='smn', detect_gender=False, ffmpeg=ffmpeg, device=device,
-                             models='synthetic' if models == 'synthetic' else None)
+        if models == 'synthetic':
+            vad_models = 'synthetic'
+        elif isinstance(models, dict):
+            vad_models = models.get('vad')                # {'keras_speech_music_noise_cnn.hdf5': (layers, in_shape)} or 'synthetic'
+        else:
+            vad_models = None
+        self.vad = Segmenter(vad_engine='smn', detect_gender=False, ffmpeg=ffmpeg, device=device, models=vad_models)
         self.ctx = self.vad.ctx
         if models == 'synthetic':
             rng = np.random.default_rng(23)
-            resnet = _synthetic_resnet()
+            resnet = keras_model.synthetic_resnet101()
             mlp = ([dict(type='dense', W=rng.normal(0, 0.1, (256, 64)).astype(np.float32), b=np.zeros(64, np.float32), activation='relu'),
                     dict(type='dense', W=rng.normal(0, 0.3, (64, 1)).astype(np.float32), b=np.zeros(1, np.float32), activation='sigmoid')],
                    (1, 1, 256))
@@ -129,37 +135,8 @@ class VoiceFemininityScoring:
         feats = self.features(signal)
         x_vectors = self.xvector_model(basename, feats, duration)
         x_vectors = apply_vad(x_vectors, speech, self.vad_thresh)
+        if not x_vectors:                                 # (the reference fails inside the MLP predict on an empty batch)
+            return None, speech_duration, 0
         pred = self.gender_predict(np.asarray([x for _, _, x in x_vectors])).reshape(len(x_vectors), -1)[:, 0]
         g = [(seg[0], seg[1], p) for (_, seg, _), p in zip(x_vectors, pred)]
         return get_femininity_score(g), speech_duration, len(g)
-
-
-def _synthetic_resnet(seed=0):
-    """Seeded, numerically tame ResNet-101 parameters keyed like resnet.py's state_dict (test / bench stand-in)."""
-    rng = np.random.default_rng(seed)
-    params = {}
-
-    def conv(name, cout, cin, k):
-        params[name + '.weight'] = rng.normal(0, np.sqrt(1.0 / (cin * k * k)), (cout, cin, k, k)).astype(np.float32)
-
-    def bn(name, c):
-        params[name + '.weight'] = rng.uniform(0.8, 1.2, c).astype(np.float32)
-        params[name + '.bias'] = rng.normal(0, 0.1, c).astype(np.float32)
-        params[name + '.running_mean'] = rng.normal(0, 0.1, c).astype(np.float32)
-        params[name + '.running_var'] = rng.uniform(0.5, 1.5, c).astype(np.float32)
-
-    m = 32
-    conv('conv1', m, 1, 3); bn('bn1', m)
-    inp = m
-    for li, (planes, nblocks, stride) in enumerate(zip((m, 2 * m, 4 * m, 8 * m), (3, 4, 23, 3), (1, 2, 2, 2)), 1):
-        for bi in range(nblocks):
-            p = f'layer{li}.{bi}'
-            conv(p + '.conv1', planes, inp, 1); bn(p + '.bn1', planes)
-            conv(p + '.conv2', planes, planes, 3); bn(p + '.bn2', planes)
-            conv(p + '.conv3', 4 * planes, planes, 1); bn(p + '.bn3', 4 * planes)
-            if (stride if bi == 0 else 1) != 1 or inp != 4 * planes:
-                conv(p + '.shortcut.0', 4 * planes, inp, 1); bn(p + '.shortcut.1', 4 * planes)
-            inp = 4 * planes
-    params['embedding.weight'] = rng.normal(0, np.sqrt(1.0 / 16384), (256, 16384)).astype(np.float32)
-    params['embedding.bias'] = rng.normal(0, 0.05, 256).astype(np.float32)
-    return params

@@ -64,8 +64,21 @@ int iss_sidekit_tables(iss_ctx* ctx, const double* window400, const float* melba
 int iss_signal_pcm16(iss_ctx* ctx, const int16_t* pcm, int64_t n);
 int iss_signal_f32(iss_ctx* ctx, const float* sig, int64_t n);
 /* Same, but the samples are ALREADY in device memory (hipMalloc'ed pointer, e.g. a
- * torch tensor's data_ptr); no copy, the buffer must outlive the feature call.   */
+ * torch tensor's data_ptr); no copy, the buffer must outlive the feature call.
+ * ORDERING CONTRACT: the library works on its own non-blocking stream.  The call makes that
+ * stream wait (hipStreamWaitEvent) for everything submitted so far to `producer_stream`
+ * (a hipStream_t; NULL = the legacy default stream, which is what torch uses unless the
+ * caller switched streams), so a tensor produced there -- async H2D copy, kernel output --
+ * is complete before the front end reads it.  Work the caller submits to OTHER streams is
+ * the caller's to synchronise.  The pointer must belong to the context's device
+ * (checked with hipPointerGetAttributes; ISS_EINVAL otherwise).                         */
 int iss_signal_pcm16_device(iss_ctx* ctx, const void* dev_pcm, int64_t n);
+int iss_signal_pcm16_device_stream(iss_ctx* ctx, const void* dev_pcm, int64_t n, void* producer_stream);
+
+/* Page-locked host memory (hipHostMalloc) for decode buffers and result arrays: copies
+ * from / to it are truly asynchronous (pageable memory is staged by the runtime).        */
+int iss_host_alloc(iss_ctx* ctx, size_t bytes, void** out);
+int iss_host_free(iss_ctx* ctx, void* p);
 
 /* Run the front end on the resident signal.  Results stay in HBM (mspec (T,24),
  * loge (T,)); *T_out = int((n-400)/160)+1 (sidekit_mfcc.py:254), 0 if n < 400. */
@@ -126,6 +139,17 @@ int iss_cnn_load(iss_ctx* ctx, int net_id, const int32_t* prog, int32_t nrows,
 int iss_cnn_probs(iss_ctx* ctx, int net_id, const int32_t* win_row, int32_t n,
                   float* probs_out /* n*out_dim */, uint8_t* finite_out /* n */);
 
+/* Asynchronous form: enqueues the same work on the context's stream and returns; win_row
+ * is consumed before the call returns, probs_out / finite_out (page-locked memory from
+ * iss_host_alloc if the copy is to overlap host work) are valid after iss_wait(ctx, ticket)
+ * (or any other call that synchronises the context).  The resident mel spectrogram must not
+ * be replaced before iss_wait.  Lets the host run the Viterbi of one network
+ * (segmenter.py:176) while the device already evaluates the next one.                  */
+int iss_cnn_probs_async(iss_ctx* ctx, int net_id, const int32_t* win_row, int32_t n,
+                        float* probs_out /* n*out_dim */, uint8_t* finite_out /* n */, int64_t* ticket_out);
+/* Block until the work of `ticket` (and everything enqueued before it) is complete; ticket < 0 = the whole stream. */
+int iss_wait(iss_ctx* ctx, int64_t ticket);
+
 /* Generic batched forward on caller-supplied host input (n, in_h, in_w, in_c) f32 NHWC:
  * replaces vbx_segmenter.py:262-266 `OnnxBackendExtractor.get_embedding` (ResNet-101
  * of resnet.py:78-135, one launch sequence for many windows instead of batch 1).  */
@@ -163,6 +187,28 @@ int iss_vbx_features_pcm16(iss_ctx* ctx, const int16_t* pcm, int64_t n,
  * width; its first conv must be a window-mode conv, ISS_C_INMODE 2): replaces the window loop of
  * vbx_segmenter.py:222-231 + get_embedding (:262-266) without copying windows through the host.                        */
 int iss_vbx_embed(iss_ctx* ctx, int net_id, const int32_t* starts, int32_t n, float* out /* n*out_dim */);
+
+/* ------------------------------------------- multi-GPU: the single exchange step
+ * Long archives shard file-parallel over the GPUs of one node (one process per GPU; files
+ * are independent units, segmenter.py:314-327 / scripts/ina_speech_segmenter_pyro_server.py:
+ * 34-68).  After local processing every rank holds a table of int32 rows
+ * (file_id, label_id, start_slot, stop_slot); ONE ncclAllGather (RCCL over xGMI) of
+ * fixed-capacity buffers with a header row (n_rows, capacity, rank, 0) leaves every
+ * rank's rows on every rank.  librccl is dlopen'ed on first use: single-GPU users do not
+ * need it.  Rendezvous: rank 0 calls iss_comm_unique_id and hands the 128 bytes to the
+ * other ranks by any out-of-band means (inaspeechsegmenter_amd/sharding.py uses a TCP
+ * socket on MASTER_ADDR); then every rank calls iss_comm_init.                        */
+#define ISS_COMM_ID_BYTES 128
+int iss_comm_unique_id(iss_ctx* ctx, uint8_t id_out[ISS_COMM_ID_BYTES]);
+int iss_comm_init(iss_ctx* ctx, const uint8_t id[ISS_COMM_ID_BYTES], int32_t rank, int32_t world);
+int iss_comm_destroy(iss_ctx* ctx);
+/* local_rows: (n_local,4) int32.  all_rows: (world*capacity,4) int32, rank r's rows start at
+ * r*capacity; counts[r] = rows rank r HAS (may exceed capacity: then only the first
+ * `capacity` arrived and the caller repeats the call with capacity >= max(counts)).     */
+int iss_allgather_segments(iss_ctx* ctx, const int32_t* local_rows, int32_t n_local, int32_t capacity,
+                           int32_t* all_rows, int32_t* counts /* world */);
+/* max over ranks of a double (bench timing) and a barrier, on the same communicator */
+int iss_comm_allreduce_max(iss_ctx* ctx, double* value);
 
 /* ------------------------------------------------------------ profiling hooks */
 /* Accumulated device time (ms, hipEvent-timed on the context's stream) and launch

@@ -59,6 +59,47 @@ def synth_signal(seed, n):
     return pcm
 
 
+def check_segmenter_pin(pin, feats):
+    """oracle/segment.py == the reference's own lines (recorded by ref_segmenter_pin.py).  Also run by
+    tests/test_oracle_golden.py on the committed fixture."""
+    sys.path.insert(0, HERE)
+    from fake_predict import make_predict
+    from oracle import segment as oseg
+    for engine, nvad in (('smn', 3), ('sm', 2)):
+        for tag in ('musanmix', 'silence', 'synth', 'short'):
+            if f'{engine}_{tag}_labels' not in pin.files:
+                continue
+            if tag == 'short':
+                mspec, difflen = pin['short_padded_mspec'], int(pin['short_difflen'])
+            else:
+                mspec, difflen = feats[tag + '_mspec'], 0
+            with np.errstate(divide='ignore', invalid='ignore'):
+                got = oseg.segment_feats(mspec, feats[tag + '_loge'], difflen, 0, engine, make_predict(nvad, 1), make_predict(2, 2))
+            assert [g[0] for g in got] == list(pin[f'{engine}_{tag}_labels']), (engine, tag)
+            assert np.array_equal(np.array([[a, b] for _, a, b in got], dtype=np.float64).reshape(-1, 2),
+                                  pin[f'{engine}_{tag}_bounds'].reshape(-1, 2)), (engine, tag)
+    for key in pin.files:
+        if not key.startswith('patches_') or key.endswith(('_idx', '_rowsum', '_shape', '_first_last')):
+            continue
+        _, tag, h = key.split('_')
+        m = pin['short_padded_mspec'] if tag == 'short' else feats[tag + '_mspec']
+        with np.errstate(divide='ignore', invalid='ignore'):
+            p, f = oseg.get_patches(m[:, :int(h)].copy(), 68, 2)
+        assert np.array_equal(f, pin[f'finite_{tag}_{h}']), key
+        want = pin[key]
+        if f'{key}_idx' in pin.files:
+            assert np.allclose(p.astype(np.float64).sum(axis=(1, 2)), pin[f'{key}_rowsum'], rtol=1e-9, atol=1e-6, equal_nan=True), key
+            p = p[pin[f'{key}_idx']]
+        assert p.dtype == want.dtype and np.array_equal(p, want, equal_nan=True), key
+    m = feats['musanmix_mspec']
+    for T in (68, 69, 70, 131):
+        p, f = oseg.get_patches(m[100:100 + T, :21].copy(), 68, 2)
+        assert tuple(pin[f'patches_T{T}_shape']) == p.shape, T
+        assert np.array_equal(np.stack((p[0], p[-1])), pin[f'patches_T{T}_first_last']), T
+    seqs = [[0, 0, 1, 1, 1, 0], [1], [2.0, 2.0, 0.0], ['a', 'a', 'b']]
+    assert repr([oseg.binidx2seglist(s) for s in seqs]) == str(pin['binidx_cases'])
+
+
 def main():
     from oracle import sidekit as osk, viterbi as ovit, segment as oseg, vbx as ovbx
 
@@ -91,8 +132,15 @@ def main():
         assert np.array_equal(loge, loge_o, equal_nan=True) and np.array_equal(mspec, mspec_o, equal_nan=True), tag
         out[tag + '_loge'] = loge
         out[tag + '_mspec'] = mspec
+        if tag == 'short':
+            out['short_sig'] = sig                              # input of the reference's _media2feats in ref_segmenter_pin.py
         print(tag, mspec.shape)
     np.savez_compressed(f'{HERE}/sidekit_feats.npz', **out)
+
+    # ---- segmentation bookkeeping: the reference's own lines (ast-extracted, skimage interpreter) vs the oracle ------
+    pin = f'{HERE}/segmenter_pin.npz'
+    subprocess.run(['/opt/conda/bin/python3.9', f'{HERE}/ref_segmenter_pin.py', f'{HERE}/sidekit_feats.npz', pin], check=True)
+    check_segmenter_pin(np.load(pin), np.load(f'{HERE}/sidekit_feats.npz'))
 
     # ---- viterbi known-answer cases --------------------------------------------------------
     rng = np.random.default_rng(42)

@@ -269,3 +269,53 @@ def test_fast_div_magic_numbers():
             if 0 <= n < 2 ** 31:
                 q = n if m == 0 else ((n * m) >> 32) >> sh
                 assert q == n // d, (d, n)
+
+
+class _FakeCtx:
+    """Stands in for the device context in CPU tests of the host mirror: holds the 'resident' mel spectrogram and
+    answers cnn_probs(net, win_rows) with tests/golden/fake_predict.py on windows it z-normalises itself."""
+
+    def __init__(self, predicts, nmels):
+        self.predicts, self.nmels, self.mspec = predicts, nmels, None
+
+    def set_mspec(self, m):
+        self.mspec = np.asarray(m, dtype=np.float32)
+
+    def cnn_probs(self, net_id, win_rows):
+        h = self.nmels[net_id]
+        pats = np.stack([self.mspec[r:r + 68, :h] for r in win_rows]).reshape(len(win_rows), -1)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            pats = (pats - np.mean(pats, axis=1).reshape(-1, 1)) / np.std(pats, axis=1).reshape(-1, 1)
+        fin = np.all(np.isfinite(pats), axis=1)
+        p = self.predicts[net_id](pats.reshape(-1, 68, h, 1))
+        p[~fin] = 0.5                                             # what iss_cnn_probs does (segmenter.py:175)
+        return p, fin
+
+
+@pytest.mark.parametrize('engine,nvad', [('smn', 3), ('sm', 2)])
+def test_host_mirror_bookkeeping_equals_reference_lines(engine, nvad):
+    """Segmenter.segment_feats / DnnSegmenter.__call__ / _window_rows / _energy_activity / compiled Viterbi of the PRODUCT,
+    with the device replaced by a fake context, reproduce what the reference's own lines (segmenter.py:69-108,135-179,
+    250-276, executed by tests/golden/ref_segmenter_pin.py) returned for the same inputs and the same stand-in predictor."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from fake_predict import make_predict
+    pin = np.load(os.path.join(GOLDEN, 'segmenter_pin.npz'))
+    feats = np.load(os.path.join(GOLDEN, 'sidekit_feats.npz'))
+    fake = _FakeCtx({0: make_predict(nvad, 1), 1: make_predict(2, 2)}, {0: 21, 1: 24})
+    seg = object.__new__(S.Segmenter)
+    seg.energy_ratio, seg.detect_gender, seg.ctx = 0.03, True, fake
+    seg.vad = object.__new__(S.SpeechMusicNoise if engine == 'smn' else S.SpeechMusic)
+    seg.gender = object.__new__(S.Gender)
+    seg.vad.ctx = seg.gender.ctx = fake
+    for tag in ('musanmix', 'silence', 'synth', 'short'):
+        if f'{engine}_{tag}_labels' not in pin.files:
+            continue
+        if tag == 'short':
+            mspec, difflen = pin['short_padded_mspec'], int(pin['short_difflen'])
+        else:
+            mspec, difflen = feats[tag + '_mspec'], 0
+        got = seg.segment_feats(mspec, feats[tag + '_loge'], difflen, 0)
+        assert [g[0] for g in got] == list(pin[f'{engine}_{tag}_labels']), tag
+        assert np.array_equal(np.array([[a, b] for _, a, b in got], dtype=np.float64).reshape(-1, 2),
+                              pin[f'{engine}_{tag}_bounds'].reshape(-1, 2)), tag

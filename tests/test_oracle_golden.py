@@ -79,3 +79,14 @@ def test_vbx_features_match_reference_h5():
     assert np.array_equal(fea, g['lamartine_fea'])
     assert np.array_equal(fea[:144], g['test_h5_melbands'])      # media/test.h5, run_test.py:189-195
     assert ovbx.window_list(len(fea))[-1][1] == len(fea)
+
+
+def test_segmentation_bookkeeping_pinned_against_reference_lines(golden):
+    """oracle/segment.py (get_patches, dnn_segment, segment_feats, binidx2seglist) == what the reference's own lines
+    (segmenter.py:53-108,135-179,250-276, ast-extracted and executed by tests/golden/ref_segmenter_pin.py under the
+    skimage interpreter) produced: bit-identical patches / finite masks, identical labels and boundaries."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden', os.path.join(golden, 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    mg.check_segmenter_pin(np.load(os.path.join(golden, 'segmenter_pin.npz')), np.load(os.path.join(golden, 'sidekit_feats.npz')))

@@ -76,3 +76,56 @@ def test_allgather_two_gloo_ranks(nrows, capacity):
     for rank, blob, shape, _ in res:
         got = np.frombuffer(blob, dtype=np.int32).reshape(shape)
         assert np.array_equal(got, want), rank
+
+
+def test_unique_id_exchange_over_tcp():
+    """The out-of-band step of the RCCL rendezvous (sharding.exchange_unique_id): rank 0 serves the 128-byte id, the
+    other ranks (started first here, so they must retry) fetch it."""
+    import threading
+    port = _free_port()
+    uid = bytes(range(128))
+    got = {}
+
+    def run(rank):
+        got[rank] = sh.exchange_unique_id(uid if rank == 0 else None, rank, 3, '127.0.0.1', port, timeout=30)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in (1, 2)]
+    for t in th:
+        t.start()
+    import time
+    time.sleep(0.3)
+    run(0)
+    for t in th:
+        t.join()
+    assert got == {0: uid, 1: uid, 2: uid}
+
+
+def test_merge_gathered_overflow_path():
+    rows = [np.arange(20, dtype=np.int32).reshape(5, 4), np.arange(100, 136, dtype=np.int32).reshape(9, 4)]
+
+    def regather(cap):
+        parts = np.zeros((2, cap, 4), np.int32)
+        for r in range(2):
+            parts[r, :len(rows[r])] = rows[r]
+        return parts, np.array([5, 9])
+
+    parts = np.stack([rows[0][:4], rows[1][:4]])     # capacity 4 < 5, 9: truncated first pass
+    out = sh._merge_gathered(parts, np.array([5, 9]), 4, regather)
+    assert np.array_equal(out, np.concatenate(rows))
+
+
+@pytest.mark.gpu
+def test_rccl_allgather_single_rank():
+    """iss_comm_* / iss_allgather_segments of the C-ABI on the one GPU of the test box: world size 1 exercises the
+    librccl binding, communicator set-up, staging and the header-row protocol (the 8-GPU run is the driver's)."""
+    from inaspeechsegmenter_amd import _native
+    ctx = _native.Context(0)
+    comm = sh.rccl_rendezvous(ctx, 0, 1)
+    rows = np.array([[0, 3, 0, 10], [0, 5, 10, 25], [2, 0, 0, 7]], dtype=np.int32)
+    assert np.array_equal(comm.allgather(rows, 8), rows)
+    assert np.array_equal(comm.allgather(rows, 2), rows)          # overflow -> second, larger gather
+    assert np.array_equal(comm.allgather(np.zeros((0, 4), np.int32), 4), np.zeros((0, 4), np.int32))
+    assert comm.max_over_ranks(3.25) == 3.25
+    comm.barrier()
+    ctx.comm_destroy()
+    ctx.close()
