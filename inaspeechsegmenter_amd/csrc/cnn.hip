@@ -1098,8 +1098,7 @@ static int cnn_probs_impl(iss_ctx* c, int id, const int32_t* win_row, int32_t ns
     ISS_HIP(c, hipGetLastError());
     // Shared first layer (ConvArgs::f_*): decided per call from the whole window list, not per chunk, so that the result
     // does not depend on the workspace limit: on when the windows overlap at least 4-fold on average.
-    static const bool no_fuse = getenv("ISS_NO_FUSE") != nullptr;
-    bool share = !no_fuse;
+    bool share = !getenv("ISS_NO_FUSE");               // read per call: the tests toggle it
     {
         int gmin = win_row[0], gmax = win_row[0];
         for (int i = 1; i < nslots; ++i) { gmin = std::min(gmin, win_row[i]); gmax = std::max(gmax, win_row[i]); }

@@ -194,12 +194,13 @@ class _Builder:
         self.buf_elems[b] = max(self.buf_elems.get(b, 0), int(elems))
 
     def conv(self, src, dst, shape_in, Wm, kh, kw, sh, sw, pt, pl, ho, wo, bias=None, act=0, ps=None, pt_=None,
-             res=-1, inmode=0, fpool=None):
+             res=-1, inmode=0, fpool=None, alg_kc=None):
         """Wm: (Cout, kh*kw*Cin) in (ky,kx,cin) order.  fpool = (ph, pw, kind) fuses a non-overlapping
         pool over ph*pw in {2,4} conv outputs into the epilogue; the OUT buffer then holds the pooled map."""
         h, w, cin = shape_in
         cout, K = Wm.shape
         assert K == kh * kw * cin
+        fk = alg_kc if alg_kc is not None else K * cout      # algorithmic MACs per output pixel (channel padding excluded)
         kpad = -(-K // N.K_ALIGN) * N.K_ALIGN
         Wp = np.zeros((cout, kpad), np.float32)
         Wp[:, :K] = Wm
@@ -219,10 +220,10 @@ class _Builder:
             ph, pw, kind = fpool
             assert ph * pw in (2, 4) and res < 0 and ho // ph >= 1 and wo // pw >= 1
             r[N.C_FPOOLH], r[N.C_FPOOLW], r[N.C_POOLKIND] = ph, pw, kind
-            self.flops += 2 * K * cout * (ho // ph * ph) * (wo // pw * pw)     # only the pooled region is computed
+            self.flops += 2 * fk * (ho // ph * ph) * (wo // pw * pw)     # only the pooled region is computed
             ho, wo = ho // ph, wo // pw
         else:
-            self.flops += 2 * K * cout * ho * wo
+            self.flops += 2 * fk * ho * wo
         self.rows.append(r)
         self.use_buf(dst, ho * wo * cout)
         return (ho, wo, cout)
@@ -282,13 +283,23 @@ def _bn_affine(L):
     return sc, sh
 
 
-def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True):
+CH_ALIGN = 32      # channel counts of intermediate activations are padded to this (the k-tile of the MFMA kernels)
+
+
+def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_channels=True):
     """Lower a sequential layer list onto the op program.  Fusions: conv/dense + bias,
     + BatchNorm directly after (folded into W, b), + relu/sigmoid/tanh, + BatchNorm after the
     activation (epilogue scale/shift), + a non-overlapping 'valid' max/avg pool over 2 or 4 outputs.
-    Anything left over becomes an identity 1x1 conv."""
+    Anything left over becomes an identity 1x1 conv.
+
+    pad_channels: an intermediate activation whose channel count is not a multiple of 32 (48, 96, 20 ...) is stored with
+    zero channels appended (zero weight rows / bias / scale in the producer, zero weight columns in every consumer), so
+    that every conv / dense behind the first layer runs on the vectorised MFMA kernels (Cin % 32 == 0) instead of the
+    scalar-gather path (only from 16 channels up: below that the padding would more than double the work); results are unchanged (the extra products are exact zeros) and `flops_per_sample` keeps counting
+    the model's own MACs."""
     B = _Builder()
     shape = tuple(int(v) for v in in_shape)
+    pmap = np.arange(shape[2])                      # physical channel -> logical channel of the current activation (-1 = padding)
     cur = N.BUF_INPUT
     first = True
     i, n = 0, len(layers)
@@ -308,7 +319,10 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True):
             i += 1
             continue
         if ty == 'flatten':
-            shape = (1, 1, shape[0] * shape[1] * shape[2])
+            hw, c = shape[0] * shape[1], shape[2]
+            pmap = (np.where(pmap >= 0, pmap, -(1 << 40))[None, :] + (np.arange(hw) * c)[:, None]).ravel()
+            pmap = np.where(pmap >= 0, pmap, -1)
+            shape = (1, 1, hw * c)
             i += 1
             continue
         if ty in ('conv2d', 'dense', 'batchnorm', 'activation') and not (ty == 'activation' and L['fn'] == 'softmax'):
@@ -386,9 +400,33 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True):
             inmode = 1 if (first and patch_input) else 0
             if inmode == 1 and not (cin == 1 and h == 68 and w <= 24):
                 raise ValueError(f"patch input must be (68, <=24, 1); got {shape}")
-            shape = B.conv(cur, dst, (h, w, cin), Wm.astype(np.float32), kh, kw, sh, sw, pt, pl, ho, wo,
-                           bias=None if bias is None else np.asarray(bias, np.float32),
-                           act=_ACT_CODE[act_name], ps=ps, pt_=pt_, inmode=inmode, fpool=fpool)
+            # physical operand: input channels follow `pmap` (zero columns for padding channels); output channels are
+            # padded when another conv / dense consumes them
+            alg_kc = Wm.shape[0] * Wm.shape[1]
+            cin_p = len(pmap)
+            if cin_p != cin or np.any(pmap != np.arange(cin)):
+                W3 = Wm.reshape(cout, kh * kw, cin)
+                Wp3 = np.zeros((cout, kh * kw, cin_p))
+                Wp3[:, :, pmap >= 0] = W3[:, :, pmap[pmap >= 0]]
+                Wm = Wp3.reshape(cout, kh * kw * cin_p)
+            later = any(l['type'] in ('conv2d', 'dense', 'batchnorm') or (l['type'] == 'activation' and l['fn'] != 'softmax')
+                        for l in layers[j:])
+            cout_p = cout
+            if pad_channels and later and not softmax_after and cout % CH_ALIGN and cout >= CH_ALIGN // 2:   # at most 2x the work
+                cout_p = -(-cout // CH_ALIGN) * CH_ALIGN
+                Wm = np.concatenate((Wm, np.zeros((cout_p - cout, Wm.shape[1]))), axis=0)
+                zpad = np.zeros(cout_p - cout)
+                bias = None if bias is None else np.concatenate((np.asarray(bias, np.float64), zpad))
+                if ps is not None:
+                    ps, pt_ = np.concatenate((ps, zpad)).astype(np.float32), np.concatenate((pt_, zpad)).astype(np.float32)
+                elif _ACT_CODE[act_name] >= 2:               # sigmoid(0) / tanh(0): keep padding channels at exactly 0
+                    ps = np.concatenate((np.ones(cout), zpad)).astype(np.float32)
+                    pt_ = np.zeros(cout_p, np.float32)
+            pshape = B.conv(cur, dst, (h, w, cin_p), Wm.astype(np.float32), kh, kw, sh, sw, pt, pl, ho, wo,
+                            bias=None if bias is None else np.asarray(bias, np.float32),
+                            act=_ACT_CODE[act_name], ps=ps, pt_=pt_, inmode=inmode, fpool=fpool, alg_kc=alg_kc)
+            shape = (pshape[0], pshape[1], cout)
+            pmap = np.concatenate((np.arange(cout), np.full(cout_p - cout, -1)))
             cur, first = dst, False
             if softmax_after:
                 dst = nxt_buf()
@@ -400,7 +438,10 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True):
             dst = nxt_buf()
             shape = B.conv(cur, dst, shape, np.eye(1, dtype=np.float32), 1, 1, 1, 1, 0, 0, shape[0], shape[1], inmode=1)
             cur, first = dst, False
+        pshape = (shape[0], shape[1], len(pmap))    # pools / softmax work on the stored (padded) channel axis
         if ty == 'activation' and L['fn'] == 'softmax':
+            if len(pmap) != shape[2]:
+                raise NotImplementedError("softmax over a channel-padded activation")
             dst = nxt_buf()
             shape = B.softmax(cur, dst, shape)
             cur = dst
@@ -416,12 +457,14 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True):
             else:
                 ho, wo, pt, pl = (h - ph) // sh + 1, (w - pw) // sw + 1, 0, 0
             dst = nxt_buf()
-            shape = B.pool(cur, dst, shape, ph, pw, sh, sw, pt, pl, ho, wo, 0 if ty == 'maxpool' else 1)
+            B.pool(cur, dst, pshape, ph, pw, sh, sw, pt, pl, ho, wo, 0 if ty == 'maxpool' else 1)
+            shape = (ho, wo, c)
             cur = dst
         elif ty in ('globalavgpool', 'globalmaxpool'):
             h, w, c = shape
             dst = nxt_buf()
-            shape = B.pool(cur, dst, shape, h, w, h, w, 0, 0, 1, 1, 1 if ty == 'globalavgpool' else 0)
+            B.pool(cur, dst, pshape, h, w, h, w, 0, 0, 1, 1, 1 if ty == 'globalavgpool' else 0)
+            shape = (1, 1, c)
             cur = dst
         else:
             raise NotImplementedError(ty)
@@ -429,6 +472,8 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True):
         i += 1
     if cur == N.BUF_INPUT:
         raise ValueError("empty network")
+    if len(pmap) != shape[2]:
+        raise NotImplementedError("network output is channel-padded")
     out_dim = shape[0] * shape[1] * shape[2]
     return B.finish(in_shape, out_dim, patch_input)
 

@@ -1,0 +1,64 @@
+"""CPU executor of the op program (include/iss.h ISS_OP_* rows) -- test infrastructure.
+
+Runs what inaspeechsegmenter_amd/keras_model.py lowers a layer list to, with torch-CPU float64 convolutions, so that the
+lowering itself (BatchNorm folding, fused activations / pools, channel padding, flatten maps, buffer ping-pong) can be
+checked against the Keras-semantics oracle without a GPU.  Input: z-normalised patches (N,H,W,C) for a patch network.
+"""
+import numpy as np
+
+from inaspeechsegmenter_amd import _native as N
+
+
+def run(comp, x):
+    import torch
+    import torch.nn.functional as F
+    prog, blob = np.asarray(comp.prog), np.asarray(comp.blob, dtype=np.float64)
+    bufs = {N.BUF_INPUT: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))}
+    out = None
+    for R in prog:
+        src = bufs[int(R[N.C_IN])]
+        op = int(R[N.C_OP])
+        h, w, cin, ho, wo, cout = (int(R[c]) for c in (N.C_H, N.C_W, N.C_CIN, N.C_HO, N.C_WO, N.C_COUT))
+        src = src.reshape(-1, h, w, cin)
+        if op == N.OP_CONV:
+            kh, kw, sh, sw, pt, pl = (int(R[c]) for c in (N.C_KH, N.C_KW, N.C_SH, N.C_SW, N.C_PT, N.C_PL))
+            K = kh * kw * cin
+            kpad = -(-K // N.K_ALIGN) * N.K_ALIGN
+            W = blob[R[N.C_WOFF]:R[N.C_WOFF] + cout * kpad].reshape(cout, kpad)[:, :K].reshape(cout, kh, kw, cin)
+            t = src.permute(0, 3, 1, 2)
+            pb = max((ho - 1) * sh + kh - h - pt, 0)
+            pr = max((wo - 1) * sw + kw - w - pl, 0)
+            t = F.pad(t, (pl, pr, pt, pb))
+            y = F.conv2d(t, torch.from_numpy(np.ascontiguousarray(W.transpose(0, 3, 1, 2))), stride=(sh, sw))[:, :, :ho, :wo]
+            y = y.permute(0, 2, 3, 1)
+            if R[N.C_BOFF] >= 0:
+                y = y + torch.from_numpy(blob[R[N.C_BOFF]:R[N.C_BOFF] + cout])
+            if R[N.C_RES] >= 0:
+                y = y + bufs[int(R[N.C_RES])].reshape(y.shape)
+            act = int(R[N.C_ACT])
+            y = [y, torch.relu(y), torch.sigmoid(y), torch.tanh(y)][act]
+            if R[N.C_PSOFF] >= 0:
+                y = y * torch.from_numpy(blob[R[N.C_PSOFF]:R[N.C_PSOFF] + cout]) + torch.from_numpy(blob[R[N.C_PTOFF]:R[N.C_PTOFF] + cout])
+            ph, pw = max(int(R[N.C_FPOOLH]), 1), max(int(R[N.C_FPOOLW]), 1)
+            if ph * pw > 1:
+                y = y[:, :ho // ph * ph, :wo // pw * pw].reshape(-1, ho // ph, ph, wo // pw, pw, cout)
+                y = y.amax(dim=(2, 4)) if R[N.C_POOLKIND] == 0 else y.mean(dim=(2, 4))
+            out = y
+        elif op == N.OP_POOL:
+            kh, kw, sh, sw, pt, pl = (int(R[c]) for c in (N.C_KH, N.C_KW, N.C_SH, N.C_SW, N.C_PT, N.C_PL))
+            t = src.permute(0, 3, 1, 2)
+            pb = max((ho - 1) * sh + kh - h - pt, 0)
+            pr = max((wo - 1) * sw + kw - w - pl, 0)
+            if R[N.C_POOLKIND] == 0:
+                t = F.pad(t, (pl, pr, pt, pb), value=float('-inf'))
+                y = F.max_pool2d(t, (kh, kw), (sh, sw))
+            else:
+                assert pt == pl == pb == pr == 0
+                y = F.avg_pool2d(t, (kh, kw), (sh, sw))
+            out = y[:, :, :ho, :wo].permute(0, 2, 3, 1)
+        elif op == N.OP_SOFTMAX:
+            out = torch.softmax(src, dim=-1)
+        else:
+            raise NotImplementedError(op)
+        bufs[int(R[N.C_OUT])] = out.contiguous()
+    return out.reshape(len(x), -1).numpy()

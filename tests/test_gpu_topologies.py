@@ -1,0 +1,97 @@
+"""GPU parity of the CNN engine over the topology sweep (tests/topologies.py): every plausible variant of the
+un-vendored nets -- padded / small / large filters, 32..128 channels incl. 48 / 96 (channel-padded), BatchNorm before
+or after the activation, big dense heads, pools in odd places -- must match the Keras-semantics oracle to 1e-4 on
+probabilities, on the overlapping-window path (shared first layer where it applies) AND on scattered windows, and
+through the asynchronous entry.  Plus the BASELINE config-size check: one hour of slots in several passes."""
+import numpy as np
+import pytest
+
+from inaspeechsegmenter_amd import keras_model as KM, segmenter as S
+from oracle import keras_cnn as ocnn
+import topologies as TP
+
+pytestmark = pytest.mark.gpu
+
+
+def _mspec(rng, T):
+    """log-mel-like rows with slow and fast structure (values around -3 +- 2), a silent gap and a constant stretch."""
+    t = np.arange(T)[:, None]
+    m = -3 + 1.5 * np.sin(t / 37.0 + np.arange(24)[None, :] / 5.0) + rng.normal(0, 1.2, (T, 24))
+    return m.astype(np.float32)
+
+
+def _oracle_probs(layers, mspec, nmel, rows):
+    patches = np.stack([mspec[r:r + 68, :nmel] for r in rows])
+    flat = patches.reshape(len(rows), -1)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        z = (flat - flat.mean(axis=1, keepdims=True)) / flat.std(axis=1, keepdims=True)
+    fin = np.all(np.isfinite(z), axis=1)
+    z = np.where(fin[:, None], z, 0).reshape(len(rows), 68, nmel, 1).astype(np.float32)
+    p = ocnn.forward(layers, z)
+    p[~fin] = 0.5
+    return p, fin
+
+
+@pytest.mark.parametrize('name', sorted(TP.SPECS))
+def test_topology_parity(ctx, name):
+    rng = np.random.default_rng(sum(map(ord, name)))
+    T = 1500
+    mspec = _mspec(rng, T)
+    mspec[700:703, 5] = -np.inf
+    ctx.set_mspec(mspec)
+    for k, (net, (layers, shp)) in enumerate(sorted(TP.nets(name).items())):
+        nmel = shp[1]
+        ctx.cnn_load(5, KM.compile_layers(layers, shp))
+        rows = S._window_rows(T)                                        # overlapping: the segmenter's own list
+        probs, fin = ctx.cnn_probs(5, rows)
+        ref, rfin = _oracle_probs(layers, mspec, nmel, rows)
+        assert np.array_equal(fin, rfin), (name, net)
+        err = np.abs(probs - ref).max()
+        scat = np.sort(rng.integers(0, T - 68, 64)).astype(np.int32)     # scattered: per-window first layer
+        p2, f2 = ctx.cnn_probs(5, scat)
+        r2, rf2 = _oracle_probs(layers, mspec, nmel, scat)
+        err2 = np.abs(p2 - r2).max()
+        print(f'{name}/{net}: overlapping {err:.2e}, scattered {err2:.2e}')
+        assert err < 1e-4 and err2 < 1e-4 and np.array_equal(f2, rf2), (name, net, err, err2)
+        # asynchronous entry: same bits, result arrays in page-locked memory
+        pp = ctx.pinned_empty((len(rows), probs.shape[1]), np.float32)
+        pf = ctx.pinned_empty((len(rows),), np.uint8)
+        rows_tmp = rows.copy()
+        tk, _, _ = ctx.cnn_probs_async(5, rows_tmp, pp, pf)
+        rows_tmp[:] = 0                                                  # the list is consumed before the call returns
+        tk2, p3, f3 = ctx.cnn_probs_async(5, scat)                       # a second request queued behind the first
+        ctx.wait(tk)
+        assert np.array_equal(pp, probs) and np.array_equal(pf.astype(bool), fin)
+        ctx.wait(tk2)
+        assert np.array_equal(p3, p2) and np.array_equal(f3.astype(bool), f2)
+        ctx.pinned_free(pp)
+        ctx.pinned_free(pf)
+
+
+def test_one_hour_of_slots_config_size(ctx):
+    """BASELINE.json configs[1] size: 359 998 frames -> 179 999 overlapping slots through both stand-in nets, in ~11
+    passes of the default 6 GiB workspace and in 2 passes of a 48 GiB one (large first-layer row buffers and batch
+    offsets); 768 sampled slots (pass boundaries and both ends included) against the oracle, and pass-size independence."""
+    rng = np.random.default_rng(2024)
+    T = 359998
+    mspec = _mspec(rng, T)
+    mspec[100000:100050, :] = -np.inf
+    ctx.set_mspec(mspec)
+    rows = S._window_rows(T)
+    assert len(rows) == 179999
+    for nmel, ncls, seed in ((21, 3, 1), (24, 2, 2)):
+        layers, shp = KM.synthetic_ina_like(nmel, ncls, seed=seed)
+        ctx.cnn_load(5, KM.compile_layers(layers, shp))
+        ctx.set_workspace_limit(6 << 30)
+        a, fa = ctx.cnn_probs(5, rows)
+        ctx.set_workspace_limit(48 << 30)
+        b, fb = ctx.cnn_probs(5, rows)
+        ctx.set_workspace_limit(6 << 30)
+        assert np.array_equal(fa, fb) and np.abs(a - b).max() < 2e-6      # tile boundaries move with the pass size
+        idx = np.unique(np.concatenate((np.arange(0, 40), np.arange(len(rows) - 40, len(rows)),
+                                        rng.integers(0, len(rows), 600), np.arange(49990, 50040))))
+        ref, rfin = _oracle_probs(layers, mspec, nmel, rows[idx])
+        assert np.array_equal(fa[idx], rfin) and (~rfin).sum() > 10
+        err = np.abs(a[idx] - ref).max()
+        print(f'1 h, nmel {nmel}: max |p_gpu - p_oracle| = {err:.2e} over {len(idx)} sampled slots of {len(rows)}')
+        assert err < 1e-4
