@@ -22,7 +22,7 @@
 //   softmax_kernel       softmax over channels
 //   statpool_kernel      mean || std over time                           (resnet.py:123-127)
 #include "conv_common.h"
-#include "conv_fp.h"
+#include "conv_fp2.h"
 
 using namespace issk;
 
@@ -801,7 +801,7 @@ inline bool fp_shape_compiled(int kh, int kw) {
 // Host replica of the device's row mapping / footprint arithmetic: does every 128-row tile of this
 // launch touch at most FPIX pixels?  The pattern is periodic in the sample index (period <= BM
 // samples), so tiles covering the first BM + 2 samples decide.
-bool footprint_fits(const ConvArgs& a) {
+int footprint_pixels(const ConvArgs& a) {      // largest pixel span of a 128-row tile of this launch (INT_MAX: irregular)
     const long long rows_per_sample = (long long)a.Hq * a.Wq * a.pp;
     const long long samples = a.M / rows_per_sample;
     const long long lim_rows = std::min<long long>(a.M, rows_per_sample * std::min<long long>(samples, BM + 2));
@@ -816,15 +816,16 @@ bool footprint_fits(const ConvArgs& a) {
         const int oy = qy * a.ph + dy, ox = qx * a.pw + dx;
         return (b * a.H + (oy * a.sh - a.pt_ + ky)) * a.W + (ox * a.sw - a.pl_ + kx);
     };
+    long long worst = 0;
     for (long long m0 = 0; m0 < lim_rows; m0 += BM) {
         const long long m_last = std::min<long long>(m0 + BM, a.M) - 1;
         const long long lo = pix_of(m0, 0, 0), hi = pix_of(m_last, a.H_k - 1, a.kw - 1);
-        if (hi - lo + 1 > FPIX) return false;
+        worst = std::max<long long>(worst, hi - lo + 1);
         // rows inside the tile never reach below lo / above hi (row-major or pool-window-major order); check anyway
         for (long long m = m0; m <= m_last; ++m)
-            if (pix_of(m, 0, 0) < lo || pix_of(m, a.H_k - 1, a.kw - 1) > hi) return false;
+            if (pix_of(m, 0, 0) < lo || pix_of(m, a.H_k - 1, a.kw - 1) > hi) return 0x7fffffff;
     }
-    return true;
+    return (int)std::min<long long>(worst, 0x7fffffff);
 }
 
 // Run the op program on `bc` samples.  src: PATCH mode uses (d_winrow + s0, stats, finite),
@@ -851,7 +852,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         if (R1[ISS_C_BOFF] < 0 || (R1[ISS_C_PSOFF] >= 0) != (R1[ISS_C_PTOFF] >= 0) || R1[ISS_C_COUT] % 4 != 0 || n.wsum_off[r] < 0) return false;
         if (R2[ISS_C_OP] != ISS_OP_CONV || R2[ISS_C_INMODE] != 0 || R2[ISS_C_IN] != R1[ISS_C_OUT] || R2[ISS_C_RES] >= 0) return false;
         if (R2[ISS_C_CIN] != R1[ISS_C_COUT] || R2[ISS_C_CIN] % XBK != 0 || R2[ISS_C_H] != R1[ISS_C_HO] || R2[ISS_C_W] != R1[ISS_C_WO]) return false;
-        if (R2[ISS_C_KH] * R2[ISS_C_KW] < 12 || !fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW])) return false;
+        if (R2[ISS_C_KH] * R2[ISS_C_KW] < 8 || !fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW])) return false;   // (>= 12 on the first-generation kernel, see conv_row)
         if (R2[ISS_C_PT] != 0 || R2[ISS_C_PL] != 0 || (R2[ISS_C_HO] - 1) * R2[ISS_C_SH] + R2[ISS_C_KH] > R2[ISS_C_H] ||
             (R2[ISS_C_WO] - 1) * R2[ISS_C_SW] + R2[ISS_C_KW] > R2[ISS_C_W]) return false;
         // the footprint may touch two windows at most, and the x / W trick of the kernel needs a small W
@@ -912,19 +913,23 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         dim3 grid(a.nblk, a.nblk_n);
         const dim3 grid1(a.nblk * a.nblk_n);          // generic kernels: 1-D, XCD-aware (gemm_tile_of_block)
         double fl = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * a.Cin * (double)a.Cout * (double)a.M;
-        bool fp = false;
+        bool fp = false, fp2 = false;                  // LDS-footprint kernel usable: first / second generation
+        static const bool no_v2 = getenv("ISS_FP_V2") == nullptr;       // the 16-channel-chunk variant (conv_fp2.h) measured 3-5 % slower
+                                                                        // than the first-generation kernel: opt-in for A/B runs
         if (x3 && a.mode == 0 && fp_shape_compiled(a.H_k, a.kw) && a.M < (1ll << 31)) {
             const long long key = ((long long)r << 32) | (unsigned)bc;
-            auto it = n.fp_ok.find(key);
-            if (it == n.fp_ok.end()) it = n.fp_ok.emplace(key, footprint_fits(a)).first;
-            fp = it->second;
+            auto it = n.fp_pix.find(key);
+            if (it == n.fp_pix.end()) it = n.fp_pix.emplace(key, footprint_pixels(a)).first;
+            fp = it->second <= FPIX;
+            fp2 = !no_v2 && it->second <= F2_PIX && a.H_k * a.kw >= 8;
+            fp = fp || fp2;
         }
         const bool padded = a.pt_ != 0 || a.pl_ != 0 ||
                             (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
         bool fused = false;
         if (pend >= 0) {
             const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
-            fused = fp && !padded && a.H_k * a.kw >= 12 && d_winrow != nullptr &&
+            fused = fp && !padded && (fp2 || a.H_k * a.kw >= 12) && d_winrow != nullptr &&
                     ((long long)(rmax - rmin) + Rp[ISS_C_HO]) * Rp[ISS_C_WO] * Rp[ISS_C_COUT] < (1ll << 32);   // 32-bit offsets into R
         }
         if (!fused && (long long)bc * a.img_stride >= (1ll << 32)) fp = false;        // 32-bit offsets into the input batch
@@ -960,7 +965,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         iss_prof_begin(c, 0, fl);
         if (fp) {
-#define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr, fused, nh); else
+#define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr, fused, nh, fp2); else
             // 128 output channels per workgroup where the layer has them: one LDS footprint serves two 64-column halves
             static const bool no_nh2 = getenv("ISS_NO_NH2") != nullptr;
             const int nh = (!fused && !no_nh2 && issk::iss_fp_has_nh2(a.H_k, a.kw) && a.Cout % (2 * BN) == 0) ? 2 : 1;

@@ -77,7 +77,8 @@ inline void set_fast_div(ConvArgs& a, int slot, int d) {
     a.dv_mul[slot] = (unsigned)(((1ull << (31 + l)) / (unsigned long long)d) + 1ull);   // < 2^32
     a.dv_sh[slot] = l - 1;
 }
-__device__ __forceinline__ int fast_div(const ConvArgs& p, int slot, int n) {
+template <class P>
+__device__ __forceinline__ int fast_div(const P& p, int slot, int n) {
     return p.dv_mul[slot] ? (int)(__umulhi((unsigned)n, p.dv_mul[slot]) >> p.dv_sh[slot]) : n;
 }
 
@@ -122,8 +123,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // ACT: 0 none, 1 relu, -1 = read p.act at run time (sigmoid / tanh); PP: fused pool window size (1, 2, 4);
 // HAS_PS: post-activation scale/shift; HAS_RES: residual add.  The common combinations are compiled without any
 // per-element branch (the fully generic form, inlined 32 times per tile, was ~6000 ISA lines of mostly skipped code).
-template <int ACT, int PP, bool HAS_PS, bool HAS_RES>
-__device__ __forceinline__ void epilogue_impl(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
+// P: ConvArgs, or the EpiArgs subset the second-generation footprint kernel loads at the end of a tile (conv_fp2.h)
+template <int ACT, int PP, bool HAS_PS, bool HAS_RES, class P>
+__device__ __forceinline__ void epilogue_impl(const P& p, const floatx16& acc, long long mrow0, int n, int lh) {
     if (n >= p.Cout) return;
     const float bias = p.bias ? p.bias[n] : 0.f;
     const float s = HAS_PS ? p.ps[n] : 1.f;
@@ -162,8 +164,8 @@ __device__ __forceinline__ void epilogue_impl(const ConvArgs& p, const floatx16&
     }
 }
 
-template <int PP>
-__device__ __forceinline__ void epilogue_pp(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
+template <int PP, class P>
+__device__ __forceinline__ void epilogue_pp(const P& p, const floatx16& acc, long long mrow0, int n, int lh) {
     const bool ps = p.ps != nullptr;
     if (p.res) {                                             // residual add (ResNet): run-time activation
         if (ps) epilogue_impl<-1, PP, true, true>(p, acc, mrow0, n, lh);
@@ -180,7 +182,8 @@ __device__ __forceinline__ void epilogue_pp(const ConvArgs& p, const floatx16& a
     }
 }
 
-__device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const floatx16& acc, long long mrow0, int n, int lh) {
+template <class P>
+__device__ __forceinline__ void epilogue_tile(const P& p, const floatx16& acc, long long mrow0, int n, int lh) {
     if (p.pp == 1) epilogue_pp<1>(p, acc, mrow0, n, lh);
     else if (p.pp == 4) epilogue_pp<4>(p, acc, mrow0, n, lh);
     else epilogue_pp<2>(p, acc, mrow0, n, lh);
@@ -190,8 +193,8 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& p, const floatx16&
 // (pixel) m, register group g of tile t = output channels n0 + 32 t + 8 g + 4 lh + {0..3}.  Every access is a float4:
 // bias / scale / shift, the residual, and the store (8 x 16 B per lane and tile pair instead of 32 x 4 B).  Needs
 // pp == 1 and Cout % 4 == 0 (parameter offsets in the blob are multiples of 8 floats).
-template <bool PRELOAD_RES = false>
-__device__ __forceinline__ void epilogue_tr(const ConvArgs& p, const floatx16& acc0, const floatx16& acc1, long long m,
+template <bool PRELOAD_RES = false, class P = ConvArgs>
+__device__ __forceinline__ void epilogue_tr(const P& p, const floatx16& acc0, const floatx16& acc1, long long m,
                                             int n0, int lh) {
     if (m >= p.M) return;
     float* orow = p.out + (size_t)m * p.Cout;

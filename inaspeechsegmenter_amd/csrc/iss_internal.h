@@ -34,7 +34,7 @@ struct IssNet {
     std::vector<int64_t> buf_elems;
     int in_h = 0, in_w = 0, in_c = 0, out_dim = 0;
     double flops_per_sample = 0;
-    std::unordered_map<long long, bool> fp_ok;   // (row << 32 | samples) -> LDS-footprint kernel usable
+    std::unordered_map<long long, int> fp_pix;   // (row << 32 | samples) -> pixels a 128-row tile's LDS footprint spans
 };
 
 struct iss_ctx {
