@@ -30,8 +30,8 @@ def _default_comm(device):
 
 def segment_archive(segment_file, linput, loutput=None, output_format='csv', sizes=None, skipifexist=False,
                     capacity=None, device=None, comm=None):
-    """segment_file(path) -> [(label, start_sec, stop_sec)] with times on the 20 ms grid (what
-    Segmenter.__call__ returns).  linput / loutput: all files, identical on every rank.
+    """segment_file: a `Segmenter` (its share of the files runs through pipeline.process_files), or any callable
+    path -> [(label, start_sec, stop_sec)] with times on the 20 ms grid (what Segmenter.__call__ returns).  linput / loutput: all files, identical on every rank.
     Returns (table, lmsg): table = {file_index: [(label, start_sec, stop_sec)]} for ALL files (gathered),
     lmsg = this rank's [(dst, code, text)] in the reference's batch_process convention
     (0 ok / 1 already exists / 2 error, segmenter.py:352,370,372).
@@ -48,6 +48,38 @@ def segment_archive(segment_file, linput, loutput=None, output_format='csv', siz
         sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in linput]
     mine = sharding.shard_files(sizes, world)[rank]
     rows, lmsg = [], []
+    if hasattr(segment_file, 'batch_process') and hasattr(segment_file, 'ctx'):
+        # a Segmenter: this rank's share runs through the multi-file pipeline (super-batches, two device contexts)
+        from . import pipeline
+        seg = segment_file
+        mine = sorted(mine)
+        msgs, skip = {}, set()
+        for k, i in enumerate(mine):
+            dst = loutput[i] if loutput is not None else None
+            if skipifexist and dst is not None and os.path.exists(dst):
+                msgs[k] = (dst, 1, 'already exists')
+                skip.add(k)
+            elif dst is not None:
+                d = os.path.dirname(dst)
+                if d and not os.path.isdir(d):
+                    os.makedirs(d, exist_ok=True)
+        t0 = time.time()
+        got = {}
+
+        def on_result(k, src, lseg, err):
+            dst = loutput[mine[k]] if loutput is not None else None
+            if lseg is None:
+                msgs[k] = (dst, 2, err)
+                return
+            if dst is not None:
+                fexport(lseg, dst)
+            got[k] = sharding.pack_segments(mine[k], [(lab, int(round(s / .02)), int(round(e / .02))) for lab, s, e in lseg])
+            msgs[k] = (dst, 0, 'ok ' + str(time.time() - t0))
+
+        pipeline.process_files(seg, [linput[i] for i in mine], on_result, skip=skip)
+        rows = [got[k] for k in sorted(got)]
+        lmsg = [msgs[k] for k in range(len(mine))]
+        mine = []
     for i in sorted(mine):
         dst = loutput[i] if loutput is not None else None
         if skipifexist and dst is not None and os.path.exists(dst):

@@ -22,7 +22,7 @@
 //   softmax_kernel       softmax over channels
 //   statpool_kernel      mean || std over time                           (resnet.py:123-127)
 #include "conv_common.h"
-#include "conv_fp2.h"
+#include "conv_ws.h"
 
 using namespace issk;
 
@@ -791,6 +791,12 @@ namespace {
 
 // Kernel shapes conv_x3_fp_kernel is instantiated for (the tap loop is unrolled at compile time);
 // other shapes run on conv_x3_kernel.
+inline bool ws_shape_compiled(int kh, int kw) {
+#define ISS_WS_HAS(KH_, KW_) if (kh == KH_ && kw == KW_) return true;
+    ISS_WS_SHAPES(ISS_WS_HAS)
+#undef ISS_WS_HAS
+    return false;
+}
 inline bool fp_shape_compiled(int kh, int kw) {
 #define ISS_FP_HAS(KH_, KW_) if (kh == KH_ && kw == KW_) return true;
     ISS_FP_SHAPES(ISS_FP_HAS)
@@ -801,10 +807,10 @@ inline bool fp_shape_compiled(int kh, int kw) {
 // Host replica of the device's row mapping / footprint arithmetic: does every 128-row tile of this
 // launch touch at most FPIX pixels?  The pattern is periodic in the sample index (period <= BM
 // samples), so tiles covering the first BM + 2 samples decide.
-int footprint_pixels(const ConvArgs& a) {      // largest pixel span of a 128-row tile of this launch (INT_MAX: irregular)
+int footprint_pixels(const ConvArgs& a, int TM = BM) {      // largest pixel span of a TM-row tile of this launch (INT_MAX: irregular)
     const long long rows_per_sample = (long long)a.Hq * a.Wq * a.pp;
     const long long samples = a.M / rows_per_sample;
-    const long long lim_rows = std::min<long long>(a.M, rows_per_sample * std::min<long long>(samples, BM + 2));
+    const long long lim_rows = std::min<long long>(a.M, rows_per_sample * std::min<long long>(samples, TM + 2));
     auto pix_of = [&](long long m, int ky, int kx) {
         long long q = m;
         int dy = 0, dx = 0;
@@ -817,8 +823,8 @@ int footprint_pixels(const ConvArgs& a) {      // largest pixel span of a 128-ro
         return (b * a.H + (oy * a.sh - a.pt_ + ky)) * a.W + (ox * a.sw - a.pl_ + kx);
     };
     long long worst = 0;
-    for (long long m0 = 0; m0 < lim_rows; m0 += BM) {
-        const long long m_last = std::min<long long>(m0 + BM, a.M) - 1;
+    for (long long m0 = 0; m0 < lim_rows; m0 += TM) {
+        const long long m_last = std::min<long long>(m0 + TM, a.M) - 1;
         const long long lo = pix_of(m0, 0, 0), hi = pix_of(m_last, a.H_k - 1, a.kw - 1);
         worst = std::max<long long>(worst, hi - lo + 1);
         // rows inside the tile never reach below lo / above hi (row-major or pool-window-major order); check anyway
@@ -924,12 +930,22 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             fp2 = !no_v2 && it->second <= F2_PIX && a.H_k * a.kw >= 8;
             fp = fp || fp2;
         }
+        // weight-stationary kernel (conv_ws.h): the shared-first-layer convolution, 8..16 taps, one N tile of 64 channels
+        bool ws = false;
+        static const bool no_ws = getenv("ISS_NO_WS") != nullptr;
+        if (!no_ws && fp && pend >= 0 && a.H_k * a.kw >= 8 && a.H_k * a.kw <= WS_MAXNT && ws_shape_compiled(a.H_k, a.kw) &&
+            a.Cin % F2_CH == 0 && a.W <= 64 && a.H * a.W >= WS_PIX + 64) {
+            const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 62);
+            auto it = n.fp_pix.find(key);
+            if (it == n.fp_pix.end()) it = n.fp_pix.emplace(key, footprint_pixels(a, WS_TM)).first;
+            ws = it->second <= WS_PIX && n.prog[(size_t)pend * ISS_PROG_COLS + ISS_C_PSOFF] < 0;     // (a post-activation affine of the
+        }                                                                                            //  first layer stays on conv_x3_fp_kernel)
         const bool padded = a.pt_ != 0 || a.pl_ != 0 ||
                             (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
         bool fused = false;
         if (pend >= 0) {
             const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
-            fused = fp && !padded && (fp2 || a.H_k * a.kw >= 12) && d_winrow != nullptr &&
+            fused = fp && !padded && (fp2 || ws || a.H_k * a.kw >= 12) && d_winrow != nullptr &&
                     ((long long)(rmax - rmin) + Rp[ISS_C_HO]) * Rp[ISS_C_WO] * Rp[ISS_C_COUT] < (1ll << 32);   // 32-bit offsets into R
         }
         if (!fused && (long long)bc * a.img_stride >= (1ll << 32)) fp = false;        // 32-bit offsets into the input batch
@@ -963,8 +979,16 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 fl += 2.0 * R1[ISS_C_KH] * R1[ISS_C_KW] * (double)R1[ISS_C_COUT] * (double)bc * R1[ISS_C_HO] * R1[ISS_C_WO];
             }
         }
+        ws = ws && fused;
         iss_prof_begin(c, 0, fl);
-        if (fp) {
+        if (ws) {
+            const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
+            const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);         // persistent: one 512-thread workgroup per CU
+            const bool tr = a.pp == 1 && a.Cout % 4 == 0;
+#define ISS_WS_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_ws_launch_##KH_##x##KW_(a, wgrid, c->stream, padded, tr, fused); else
+            ISS_WS_SHAPES(ISS_WS_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no weight-stationary kernel for %dx%d", a.H_k, a.kw); }
+#undef ISS_WS_CASE
+        } else if (fp) {
 #define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr, fused, nh, fp2); else
             // 128 output channels per workgroup where the layer has them: one LDS footprint serves two 64-column halves
             static const bool no_nh2 = getenv("ISS_NO_NH2") != nullptr;

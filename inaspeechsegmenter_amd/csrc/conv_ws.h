@@ -1,0 +1,405 @@
+// conv_x3_ws_kernel: weight-stationary LDS-footprint bf16x3 implicit GEMM (8 <= kh*kw <= 16 taps, Cin % 16 == 0,
+// one 64-column N tile per workgroup).
+//
+// The footprint kernels of conv_fp.h / conv_fp2.h stream an 8 KB weight tile per 12 MFMAs and wave through LDS (LDS-DMA,
+// a ring of stages, a counted vmcnt wait and a workgroup barrier per tile): for the 5x3 64->64 convolution that is 63 % of
+// a segmenter step the weights of one tile (245 KB) are 3.5 x its input footprint, and they are the SAME for every tile.
+// rocprofv3 counters (profiles/r01_pmc.md) showed those kernels at 47 % matrix-pipe occupancy with 30 % of the wave
+// cycles parked at barriers / waits and 39 % issue-stalled.  Here the loop nest is turned around:
+//
+//   for each group of G = 4 tiles (256 rows each; their 4 x 2 accumulators stay in registers: 128 VGPRs)
+//     for each 16-channel chunk c
+//       load the weights of ALL taps of chunk c into LDS once (NT x 4 KB, LDS-DMA)            <- once per 4 tiles
+//       for each tile t of the group                                                          <- one "block"
+//         NT steps of 6 MFMAs: A fragments from the tile's LDS footprint, B fragments from the resident weights;
+//         behind them, the footprint of the NEXT block is fetched, split into bf16 hi / lo and written into the
+//         other footprint buffer; one barrier at the end of the block (90 MFMAs per wave for a 5x3 filter).
+//
+// No weight ring, no vmcnt bookkeeping and no barrier inside a block: a wave's stream is ds_read_b128 + MFMA with
+// a conversion slice every other step.  512 threads = 8 waves (two per SIMD, decoupled between barriers) share one
+// footprint of 512 pixels (41 KB per buffer, 80-byte linear rows as in conv_fp2.h) and the weight block (60 KB for 5x3).
+#pragma once
+#include "conv_fp2.h"
+
+namespace issk {
+
+constexpr int WS_TM = 256;                         // GEMM rows per tile: 8 waves x 32
+constexpr int WS_G = 4;                            // tiles per group
+constexpr int WS_PIX = 512;                        // footprint capacity in pixels (host-validated per launch)
+constexpr int WS_ZERO = WS_PIX * F2_ROW;           // byte offset of the all-zero pixel behind a footprint
+constexpr int WS_BUF = (WS_PIX + 1) * F2_ROW;      // bytes of one footprint buffer (41 040)
+constexpr int WS_NFV = WS_PIX / 128;               // 128-pixel slices per footprint (4): 512 threads x 4 channels each
+constexpr int WS_MAXNT = 16;                       // taps: NT x 4 KB of weights + two footprints must fit 160 KB of LDS
+constexpr int ws_lds_bytes(int nt) { return 2 * WS_BUF + nt * F2_BST; }
+
+template <int KH, int KW, bool PADDED, bool TR, bool FUSED>
+__global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
+    constexpr int NT = KH * KW;
+    static_assert(NT >= 8 && NT <= WS_MAXNT, "");
+    // [NT weight tiles][footprint 0][footprint 1]: the weights first, so that (lane base + tap * 4096 + plane / half offset)
+    // fits the 16-bit immediate offset of ds_read (<= 64 512) and every tap shares ONE address register
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[ws_lds_bytes(NT)];
+    const unsigned sB_base = (unsigned)(size_t)smem;
+    const unsigned sF_base = sB_base + NT * F2_BST;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
+    const int n0 = blockIdx.y * BN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int M = (int)p.M;
+    int totpix;                                      // samples * H * W
+    { const int spp = p.Hq * p.Wq * p.pp; totpix = (int)(p.img_stride / p.Cin) * (M / spp); }
+    const int ntiles = (M + WS_TM - 1) / WS_TM;
+    const int ngroups = (ntiles + WS_G - 1) / WS_G;
+    int grp = (int)blockIdx.x;
+    if (grp >= ngroups) return;
+
+    // ---- geometry (row decomposition parameters through the kernel-argument pointer, see conv_fp2.h)
+    auto geo_args = [&]() {
+        KArg q = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(q));
+        GeoArgs ga;
+        ga.H = q->H; ga.W = q->W; ga.Hq = q->Hq; ga.Wq = q->Wq; ga.ph = q->ph; ga.pw = q->pw; ga.pp = q->pp;
+        ga.sh = q->sh; ga.sw = q->sw; ga.pt_ = q->pt_; ga.pl_ = q->pl_;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ga.dv_mul[i] = q->dv_mul[i]; ga.dv_sh[i] = q->dv_sh[i]; }
+        return ga;
+    };
+    struct TGeo { int p_lo, need, fy, fx, wb; };     // uniform per tile: first pixel, pixels needed, FUSED: (y, x) of it and its window
+    auto clamp_tile = [&](int t) { return t < ntiles ? t : ntiles - 1; };
+    auto geo_uniform = [&](const GeoArgs& ga, int tile) {
+        TGeo u;
+        const int m0 = clamp_tile(tile) * WS_TM;
+        int b, oy, ox;
+        map_row32(ga, m0, b, oy, ox);
+        u.p_lo = (b * ga.H + (oy * ga.sh - ga.pt_)) * ga.W + (ox * ga.sw - ga.pl_);
+        u.fy = oy * ga.sh; u.fx = ox * ga.sw; u.wb = b;
+        const int ml = m0 + WS_TM - 1 < M - 1 ? m0 + WS_TM - 1 : M - 1;
+        int b2, oy2, ox2;
+        map_row32(ga, ml, b2, oy2, ox2);
+        u.need = (b2 * ga.H + (oy2 * ga.sh - ga.pt_ + KH - 1)) * ga.W + (ox2 * ga.sw - ga.pl_ + KW - 1) - u.p_lo + 1;
+        return u;
+    };
+    auto geo_lane = [&](const GeoArgs& ga, int tile, const TGeo& u, int& lanepix, unsigned& vmask) {   // lanepix: see read_a (lpb)
+        const int m0 = clamp_tile(tile) * WS_TM;
+        const int m = m0 + wv * 32 + li;
+        int b, oy, ox;
+        map_row32(ga, m < M ? m : m0, b, oy, ox);
+        const int iy0 = oy * ga.sh - ga.pt_, ix0 = ox * ga.sw - ga.pl_;
+        const int lp = (b * ga.H + iy0) * ga.W + ix0 - u.p_lo;
+        const int hi = WS_PIX - 1 - ((KH - 1) * ga.W + (KW - 1));    // keeps every tap of a row >= M inside the buffer
+        lanepix = (int)sF_base + (lp < 0 ? 0 : (lp > hi ? hi : lp)) * F2_ROW + lh * 16;      // LDS byte address of the lane's first tap
+        vmask = 0xffffffffu;
+        if (PADDED) {
+            unsigned vm = 0;
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+                    vm |= ((unsigned)(iy0 + ky) < (unsigned)ga.H && (unsigned)(ix0 + kx) < (unsigned)ga.W) ? 1u << (ky * KW + kx) : 0u;
+            vmask = vm;
+        }
+    };
+    // FUSED: per-window scalars of the (at most two) windows a footprint touches.  Loaded one block before they are used
+    // (`wpend`), then moved to SGPRs (`settle`): they are wave-uniform, and VGPRs are what this kernel is short of.
+    struct Win { int wr0, wr1; float mean0, mean1, sd0, sd1; int live0, live1; };
+    int nwin;
+    { const int spp = p.Hq * p.Wq * p.pp; nwin = M / spp; }
+    auto windows_of = [&](int b) {                   // loads only: nothing here may USE the values (see conv_fp.h)
+        Win w;
+        const unsigned b0 = (unsigned)(b < nwin ? b : nwin - 1), b1 = (unsigned)(b + 1 < nwin ? b + 1 : nwin - 1);
+        w.wr0 = p.win_row[b0]; w.mean0 = p.stats[2u * b0]; w.sd0 = p.stats[2u * b0 + 1u]; w.live0 = p.finite[b0];
+        w.wr1 = p.win_row[b1]; w.mean1 = p.stats[2u * b1]; w.sd1 = p.stats[2u * b1 + 1u]; w.live1 = p.finite[b1];
+        return w;
+    };
+    auto settle = [&](const Win& w) {
+        Win s;
+        s.wr0 = __builtin_amdgcn_readfirstlane(w.wr0); s.wr1 = __builtin_amdgcn_readfirstlane(w.wr1);
+        s.mean0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.mean0)));
+        s.mean1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.mean1)));
+        s.sd0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.sd0)));
+        s.sd1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w.sd1)));
+        s.live0 = __builtin_amdgcn_readfirstlane(w.live0); s.live1 = __builtin_amdgcn_readfirstlane(w.live1);
+        return s;
+    };
+
+    // ---- weights of one 16-channel chunk: NT tiles of 4 KB = 4 NT pieces of 1 KB; wave w moves pieces w, w + 8, ...
+    // piece i: tap i >> 2, plane (i >> 1) & 1 (hi / lo), half i & 1 (rows 0-31 / 32-63).  Lane l of a piece writes 16-byte
+    // slot 64 half + l and fetches the (row n, k half h) that belongs there: n = 32 half + (l >> 1),
+    // h = (l & 1) ^ ((n >> 3) & 1)  (conv_fp2.h: conflict-free B reads).  Rows >= Cout read row 0 (never stored).
+    unsigned boff[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int n = 32 * half + (lane >> 1), h = (lane & 1) ^ ((n >> 3) & 1);
+        boff[half] = 2u * ((unsigned)(n0 + n < p.Cout ? n0 + n : 0) * (unsigned)p.Kpad + (unsigned)(h * 8));      // bytes
+    }
+    auto load_weights = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < (4 * NT + 7) / 8; ++k) {
+            const int i = wv + 8 * k;                // uniform
+            if (i < 4 * NT) {
+                const int tap = i >> 2, plane = (i >> 1) & 1, half = i & 1;
+                const uint16_t* src = (plane ? p.wl : p.wh) + (tap * p.Cin + c0);
+                glds16(src, half ? boff[1] : boff[0],
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)(sB_base + tap * F2_BST + plane * 2048 + half * 1024)));
+            }
+        }
+    };
+    unsigned bread = sB_base + (unsigned)((2 * li + (lh ^ ((li >> 3) & 1))) * 16);
+    asm volatile("" : "+v"(bread));                  // opaque base: the per-tap offsets stay immediates (no per-tap address registers)
+
+    // ---- footprint slices: thread -> pixel 128 q + (tid >> 2), channels [c0 + 4 (tid & 3), + 4)
+    const int cg = tid & 3, prow = tid >> 2;
+    float4 fv[WS_NFV];
+    unsigned dbmask = 0;
+    float4 fsw = make_float4(0.f, 0.f, 0.f, 0.f), fbw = fsw;     // FUSED: weight sums / bias of this thread's 4 first-layer channels
+    Win wx = {}, wpend = {};                         // windows of the footprint being built (settled) / of the one after it (pending)
+    const int magicW = (65536 + p.W - 1) / p.W;      // x / W == (x * magicW) >> 16 for x < 1024, W <= 64 (host-checked for FUSED)
+    const unsigned cin4 = (unsigned)p.Cin * 4u, cg16 = (unsigned)cg * 16u;         // byte strides (32-bit offsets from a uniform base)
+    auto fetch_block = [&](const TGeo& u, int c0) {  // all loads of one footprint chunk (FUSED: with wx = its windows' scalars)
+        if (FUSED) {
+            const unsigned o = (unsigned)(c0 + cg * 4);
+            fsw = *reinterpret_cast<const float4*>(p.f_wsum + o);
+            fbw = *reinterpret_cast<const float4*>(p.f_bias + o);
+        }
+        dbmask = 0;
+#pragma unroll
+        for (int q = 0; q < WS_NFV; ++q) {
+            const int qq = 128 * q < u.need ? q : 0; // unneeded slices re-load slice 0
+            if (FUSED) {
+                int x = u.fx + prow + 128 * qq;
+                const int dy = (x * magicW) >> 16;
+                x -= dy * p.W;
+                int y = u.fy + dy;
+                const bool second = y >= p.H;
+                y -= second ? p.H : 0;
+                dbmask |= second ? 1u << q : 0u;
+                const int row = y + (second ? wx.wr1 : wx.wr0) - p.f_rmin;
+                fv[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.in + c0) + ((unsigned)(row * p.W + x) * cin4 + cg16));
+            } else {
+                int gp = u.p_lo + prow + 128 * qq;
+                gp = gp < 0 ? 0 : (gp > totpix - 1 ? totpix - 1 : gp);
+                fv[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.in + c0) + ((unsigned)gp * cin4 + cg16));
+            }
+        }
+    };
+    const float f_lob = p.f_act == 1 ? 0.f : -INFINITY;
+    float t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f}, rs0 = 0.f, rs1 = 0.f;
+    auto conv_consts = [&]() {
+        if (!FUSED) return;
+        asm volatile("" : "+v"(fsw.x), "+v"(fsw.y), "+v"(fsw.z), "+v"(fsw.w), "+v"(fbw.x), "+v"(fbw.y), "+v"(fbw.z), "+v"(fbw.w));
+        rs0 = wx.live0 ? 1.0f / wx.sd0 : 0.f;
+        rs1 = wx.live1 ? 1.0f / wx.sd1 : 0.f;
+        const float mr0 = wx.live0 ? -wx.mean0 * rs0 : 0.f, mr1 = wx.live1 ? -wx.mean1 * rs1 : 0.f;
+        const float sw[4] = {fsw.x, fsw.y, fsw.z, fsw.w}, bw[4] = {fbw.x, fbw.y, fbw.z, fbw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { t0[i] = fmaf(sw[i], mr0, bw[i]); t1[i] = fmaf(sw[i], mr1, bw[i]); }
+    };
+    auto convert_slice = [&](int q, int buf) {       // q, buf: compile-time
+        float4 v = fv[q];
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(dbmask));    // not before this point (conv_fp2.h)
+        if (FUSED) {
+            const bool second = (dbmask >> q) & 1u;
+            const float sc = second ? rs1 : rs0;
+            v = make_float4(fmaf(v.x, sc, second ? t1[0] : t0[0]), fmaf(v.y, sc, second ? t1[1] : t0[1]),
+                            fmaf(v.z, sc, second ? t1[2] : t0[2]), fmaf(v.w, sc, second ? t1[3] : t0[3]));
+            v.x = fmaxf(v.x, f_lob); v.y = fmaxf(v.y, f_lob); v.z = fmaxf(v.z, f_lob); v.w = fmaxf(v.w, f_lob);
+        }
+        bf16x4 h, l;
+        split4(v, h, l);
+        const unsigned dst = sF_base + (unsigned)(buf * WS_BUF + (prow + 128 * q) * F2_ROW + cg * 8);
+        *(LdsW8)(dst) = h;
+        *(LdsW8)(dst + 32) = l;
+    };
+
+    // ---- fragments
+    struct AFr { bf16x8 h, l; };
+    struct BFr { bf16x8 b0h, b0l, b1h, b1l; };
+    // lpb: lane base of a tile = sF_base + lanepix * 80 + lh * 16 (per tile, kept in one register); the tap offset
+    // (ky * W + kx) * 80 is wave-uniform and added per step.  The opaque copy keeps hipcc from materialising all KH * KW
+    // addresses of a tile at once (15 address registers per tile drove the first build of this kernel into scratch).
+    const unsigned zbase = sF_base + (unsigned)WS_ZERO + (unsigned)(lh * 16);
+    const unsigned row_step = (unsigned)((p.W - (KW - 1)) * F2_ROW);    // from the last tap of a filter row to the first of the next
+    // `cur` walks the taps: + 80 bytes within a filter row, + row_step at the end of one (a loop-carried value, so hipcc
+    // cannot materialise all KH * KW addresses of a tile at once)
+    auto read_a = [&](AFr& f, unsigned cur, unsigned vmask, int buf, int tap) {          // buf, tap: compile-time
+        unsigned a = cur;
+        if (PADDED) a = (vmask >> tap) & 1u ? a : zbase;
+        f.h = *(LdsR16)(a + (unsigned)(buf * WS_BUF));
+        f.l = *(LdsR16)(a + (unsigned)(buf * WS_BUF + 32));
+    };
+    auto next_tap = [&](unsigned cur, int tap) {     // address of tap + 1
+        asm volatile("" : "+v"(cur));
+        return cur + ((tap + 1) % KW == 0 ? row_step : (unsigned)F2_ROW);
+    };
+    auto read_b = [&](BFr& f, int tap) {
+        const unsigned a = bread + (unsigned)(tap * F2_BST);
+        f.b0h = *(LdsR16)(a);
+        f.b1h = *(LdsR16)(a + 1024);
+        f.b0l = *(LdsR16)(a + 2048);
+        f.b1l = *(LdsR16)(a + 3072);
+    };
+    // the six MFMAs of a step as three pairs (the two accumulators alternate): a.l * b.h, a.h * b.l, a.h * b.h
+    auto mfma2 = [&](int k, const AFr& a, const BFr& b, floatx16& c0, floatx16& c1) {       // k: compile-time
+        const bf16x8& av = k == 0 ? a.l : a.h;
+        const bf16x8& b0 = k == 1 ? b.b0l : b.b0h;
+        const bf16x8& b1 = k == 1 ? b.b1l : b.b1h;
+        if (TR) {                                        // C^T: rows = channels, columns = pixels (epilogue_tr)
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, av, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, av, c1, 0, 0, 0);
+        } else {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, c1, 0, 0, 0);
+        }
+    };
+
+    // accumulators of the group's four tiles: named variables, not an array (an array that is passed by reference into the
+    // pooled epilogue ended up in scratch memory)
+    static_assert(WS_G == 4, "");
+    floatx16 acc00, acc01, acc10, acc11, acc20, acc21, acc30, acc31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc00[i] = 0.f; acc01[i] = 0.f; acc10[i] = 0.f; acc11[i] = 0.f; acc20[i] = 0.f; acc21[i] = 0.f; acc30[i] = 0.f; acc31[i] = 0.f; }
+
+    // conversion schedule inside a block of NT steps: loads at step 0, constants at step CS - 1, slice q at step CS + q * CSTRIDE
+    constexpr int CS = NT >= 12 ? 7 : 4;
+    constexpr int CSTRIDE = (NT - 1 - CS) / WS_NFV >= 1 ? (NT - 1 - CS) / WS_NFV : 1;
+    static_assert(CS + (WS_NFV - 1) * CSTRIDE <= NT - 1, "");
+
+    // ---- prologue: zero pixels; geometry of the first group; its first footprint converted serially
+    if (tid < 2 * (F2_ROW / 4)) *(LdsW4)(sF_base + (unsigned)((tid / (F2_ROW / 4)) * WS_BUF + WS_ZERO + (tid % (F2_ROW / 4)) * 4)) = 0u;
+    TGeo ug[WS_G + 2];                               // the group's tiles + the next group's first two tiles
+    int lanepix[WS_G];
+    unsigned vmask[WS_G];
+    auto group_geometry = [&](int g0) {
+        const GeoArgs ga = geo_args();
+#pragma unroll
+        for (int t = 0; t < WS_G; ++t) { ug[t] = geo_uniform(ga, g0 * WS_G + t); geo_lane(ga, g0 * WS_G + t, ug[t], lanepix[t], vmask[t]); }
+    };
+    group_geometry(grp);
+    ug[WS_G] = ug[0]; ug[WS_G + 1] = ug[1];
+    if (FUSED) { wx = settle(windows_of(ug[0].wb)); wpend = windows_of(ug[1].wb); }
+    fetch_block(ug[0], 0);
+    conv_consts();
+#pragma unroll
+    for (int q = 0; q < WS_NFV; ++q) convert_slice(q, 0);
+
+    const int nchunk = p.Cin / F2_CH;
+    const int gstep = (int)gridDim.x;
+    for (; grp < ngroups; grp += gstep) {
+        const bool last_group = grp + gstep >= ngroups;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int c0 = ch * F2_CH;
+            const bool last_chunk = ch + 1 == nchunk;
+            // ---- weights of this chunk.  Every wave has passed the barrier that ends the previous block, so nobody reads
+            // the old ones any more; the geometry of the next group's first tiles is computed while the DMAs are in flight.
+            load_weights(c0);
+            if (last_chunk) {
+                if (!last_group) {
+                    const GeoArgs ga = geo_args();
+                    ug[WS_G] = geo_uniform(ga, (grp + gstep) * WS_G);
+                    ug[WS_G + 1] = geo_uniform(ga, (grp + gstep) * WS_G + 1);
+                } else { ug[WS_G] = ug[0]; ug[WS_G + 1] = ug[1]; }     // nothing follows: re-build this group's first footprint (never read)
+            }
+            wait_vmcnt<0>();
+            __syncthreads();
+            // one block = one tile x one chunk: t and the accumulators are compile-time constants after inlining
+            auto run_block = [&](const int t, floatx16& c0acc, floatx16& c1acc) __attribute__((always_inline)) {
+                // the footprint this block builds (for the block after it) and the one after that (whose windows it loads)
+                const TGeo un = t + 1 < WS_G ? ug[t + 1] : (last_chunk ? ug[WS_G] : ug[0]);
+                const TGeo un2 = t + 2 < WS_G ? ug[t + 2] : (last_chunk ? ug[t + 2] : ug[t + 2 - WS_G]);
+                const int nc0 = t + 1 < WS_G ? c0 : (last_chunk ? 0 : c0 + F2_CH);
+                const int buf = t & 1, nbuf = (t + 1) & 1;
+                // Fragments are double-buffered by hand and the order is PINNED (sched_barrier): left alone, hipcc sinks every
+                // ds_read to just in front of its MFMA to save registers, and the waves then sit in s_waitcnt lgkmcnt for
+                // half of their cycles (rocprofv3: 48 % of the wave cycles parked).  Per step: the reads of step v + 1 and the
+                // conversion work are spread between the three MFMA pairs of step v.
+                AFr a[2];
+                BFr b[2];
+                unsigned cur = (unsigned)lanepix[t];
+                read_a(a[0], cur, vmask[t], buf, 0);
+                read_b(b[0], 0);
+#pragma unroll
+                for (int v = 0; v < NT; ++v) {
+                    const AFr& ac = a[v & 1];
+                    const BFr& bc = b[v & 1];
+                    // (measured: all six reads in front of the six MFMAs -- one s_waitcnt per step -- is 8 % SLOWER than
+                    // spreading them between the pairs: 44 % vs 50 % matrix-pipe occupancy)
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma2(0, ac, bc, c0acc, c1acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (v + 1 < NT) { cur = next_tap(cur, v); read_a(a[(v + 1) & 1], cur, vmask[t], buf, v + 1); }
+                    if (v == 0) {
+                        if (FUSED) { wx = settle(wpend); wpend = windows_of(un2.wb); }
+                        fetch_block(un, nc0);
+                    }
+                    if (v == CS - 1) conv_consts();
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma2(1, ac, bc, c0acc, c1acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (v + 1 < NT) read_b(b[(v + 1) & 1], v + 1);
+#pragma unroll
+                    for (int q = 0; q < WS_NFV; ++q)
+                        if (v == CS + q * CSTRIDE) convert_slice(q, nbuf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma2(2, ac, bc, c0acc, c1acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+            };
+            run_block(0, acc00, acc01);
+            run_block(1, acc10, acc11);
+            run_block(2, acc20, acc21);
+            run_block(3, acc30, acc31);
+        }
+        // ---- group complete: epilogue parameters through the kernel-argument pointer (conv_fp2.h)
+        {
+            KArg q = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(q));
+            EpiArgs e;
+            e.bias = q->bias; e.ps = q->ps; e.pt = q->pt; e.res = q->res; e.out = q->out;
+            e.M = q->M; e.Cout = q->Cout; e.act = q->act; e.pp = q->pp; e.poolkind = q->poolkind;
+            auto finish = [&](const int t, floatx16& c0acc, floatx16& c1acc) __attribute__((always_inline)) {
+                const int tile = grp * WS_G + t;
+                if (tile < ntiles) {
+                    if (TR) epilogue_tr(e, c0acc, c1acc, (long long)tile * WS_TM + wv * 32 + li, n0, lh);
+                    else {
+                        epilogue_tile(e, c0acc, (long long)tile * WS_TM + wv * 32, n0 + li, lh);
+                        epilogue_tile(e, c1acc, (long long)tile * WS_TM + wv * 32, n0 + 32 + li, lh);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { c0acc[i] = 0.f; c1acc[i] = 0.f; }
+            };
+            finish(0, acc00, acc01);
+            finish(1, acc10, acc11);
+            finish(2, acc20, acc21);
+            finish(3, acc30, acc31);
+        }
+        if (!last_group) {
+            group_geometry(grp + gstep);
+            // (ug[WS_G], ug[WS_G + 1] are rewritten at the next group's last chunk)
+        }
+    }
+}
+
+template <int KH, int KW>
+void launch_ws_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused) {
+    if constexpr (KH * KW >= 8 && KH * KW <= WS_MAXNT) {
+#define ISS_WS_LAUNCH(...) hipLaunchKernelGGL((conv_x3_ws_kernel<KH, KW, __VA_ARGS__>), grid, dim3(512), 0, st, a)
+        // instantiated for the shared-first-layer convolution only (the dominant launch of the segmenter nets); the other
+        // footprint layers stay on conv_x3_fp_kernel -- every instantiation costs minutes of compile time
+        (void)padded;
+        if (fused) { if (tr) ISS_WS_LAUNCH(false, true, true); else ISS_WS_LAUNCH(false, false, true); }
+#undef ISS_WS_LAUNCH
+    }
+}
+
+}  // namespace issk
+
+// Filter shapes the weight-stationary kernel is instantiated for (cnn_ws.hip)
+#define ISS_WS_SHAPES_A(X) X(3, 3) X(5, 3)
+#define ISS_WS_SHAPES_B(X) X(3, 5) X(4, 4)
+#define ISS_WS_SHAPES(X) ISS_WS_SHAPES_A(X) ISS_WS_SHAPES_B(X)
+#define ISS_WS_DECL(KH_, KW_) void iss_ws_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused);
+ISS_WS_SHAPES(ISS_WS_DECL)
+#undef ISS_WS_DECL

@@ -1,0 +1,258 @@
+"""Multi-file engine behind `Segmenter.batch_process` and the archive driver.
+
+The reference processes a file list one file at a time: features of file i+1 are extracted on a helper thread while the
+main thread runs the two Keras `predict` calls, the Viterbi smoothing and the export of file i
+(segmenter.py:297-335, medialist2feats :338-374).  On an MI355X a 5-minute file is ~14 ms of device work, so per-file
+launches, copies and Python bookkeeping become the limit.  Here files are processed in SUPER-BATCHES:
+
+  decode threads   N files  ->  int16 PCM (RIFF parse, or the ffmpeg pipe)
+  packer           the PCM of a super-batch (default 32 files / <= 3 h of audio) is laid end to end in ONE page-locked
+                   buffer, every file starting on a multiple of 160 samples: frame t of file f is then frame
+                   off_f / 160 + t of the concatenation, and the frames that straddle two files are simply never used
+  device worker    ONE H2D copy, ONE sidekit launch, one log-energy read-back; per-file energy Viterbi (compiled);
+                   ONE iss_cnn_probs call for the VAD windows of all files, per-segment Viterbi; ONE call for the
+                   gender windows, Viterbi; hand the segment lists to the exporter
+  exporter         CSV / TextGrid writers
+
+Two device workers with a context each (own stream, own workspace) alternate super-batches, so while one is in its host
+phases (Viterbi, bookkeeping) the other's kernels run.  Results are identical to per-file processing: every frame and
+every 20 ms slot is computed from the same samples by the same kernels (tests/test_gpu_segmenter.py).
+"""
+import os
+import queue
+import sys
+import threading
+import time
+import warnings
+
+import numpy as np
+
+from . import _native
+from .io import decode_pcm
+
+FRAME_HOP = 160
+MIN_SAMPLES = 400 + FRAME_HOP * 67                  # 68 frames: shorter media take the single-file path (mspec padding)
+
+
+class _Batch:
+    __slots__ = ('idx', 'sigs', 'names')
+
+    def __init__(self):
+        self.idx, self.sigs, self.names = [], [], []
+
+    def samples(self):
+        return sum(-(-s.size // FRAME_HOP) * FRAME_HOP for s in self.sigs)
+
+
+def _decode_stage(items, ffmpeg, nbtry, trydelay, out_q, nthreads):
+    """items: [(index, src)].  Puts (index, src, sig | None, errtext | None) on out_q in completion order, then None."""
+    import random
+    in_q = queue.Queue()
+    for it in items:
+        in_q.put(it)
+
+    def work():
+        while True:
+            try:
+                i, src = in_q.get_nowait()
+            except queue.Empty:
+                return
+            sig, err, itry = None, None, 0
+            while sig is None and itry < nbtry:
+                try:
+                    sig = decode_pcm(src, None, None, ffmpeg)
+                except:                                            # noqa: E722  (reference semantics, segmenter.py:364-370)
+                    itry += 1
+                    err = 'error: ' + str(sys.exc_info()[0])
+                    if itry != nbtry:
+                        time.sleep(random.random() * trydelay)
+            out_q.put((i, src, sig, err))
+
+    ths = [threading.Thread(target=work, daemon=True) for _ in range(max(1, nthreads))]
+    for t in ths:
+        t.start()
+
+    def closer():
+        for t in ths:
+            t.join()
+        out_q.put(None)
+    threading.Thread(target=closer, daemon=True).start()
+
+
+class _Worker:
+    """One device context + the networks of `seg` loaded on it."""
+
+    def __init__(self, seg, ctx=None):
+        from . import tables
+        self.seg = seg
+        if ctx is None:
+            ctx = _native.Context(seg.ctx.device)
+            ctx.sidekit_tables(tables.sidekit_window(), tables.sidekit_melbank())
+            ctx.cnn_load(seg.vad.net_id, seg.vad.compiled)
+            if seg.detect_gender:
+                ctx.cnn_load(seg.gender.net_id, seg.gender.compiled)
+            self.owned = True
+        else:
+            self.owned = False
+        self.ctx = ctx
+        self.pin = None
+
+    def close(self):
+        if self.owned:
+            self.ctx.close()
+
+    def pinned(self, nsamples):
+        if self.pin is None or self.pin.size < nsamples:
+            if self.pin is not None:
+                self.ctx.pinned_free(self.pin)
+            self.pin = self.ctx.pinned_empty((int(nsamples * 1.25) + 4096,), np.int16)
+        return self.pin
+
+    def run(self, batch):
+        """-> [ [(label, start_slot, stop_slot)] per file of the batch ]"""
+        from . import segmenter as S
+        seg, ctx = self.seg, self.ctx
+        offs, pos = [], 0
+        for s in batch.sigs:
+            offs.append(pos)
+            pos += -(-s.size // FRAME_HOP) * FRAME_HOP
+        buf = self.pinned(pos)
+        for s, o in zip(batch.sigs, offs):
+            if s.dtype == np.int16:
+                buf[o:o + s.size] = s
+            else:                                    # float sources: what libsndfile's float32 read holds, re-quantised is NOT exact
+                raise TypeError('float media take the single-file path')
+            buf[o + s.size:o + -(-s.size // FRAME_HOP) * FRAME_HOP] = 0
+        ctx.set_signal(buf[:pos])
+        ctx.sidekit()
+        loge = ctx.get_loge()
+        g0 = [o // FRAME_HOP for o in offs]
+        nfr = [(s.size - 400) // FRAME_HOP + 1 for s in batch.sigs]
+        # energy segmentation per file (segmenter.py:261-267)
+        lsegs = []
+        for f in range(len(batch.sigs)):
+            le = loge[g0[f]:g0[f] + nfr[f]]
+            lseg = []
+            for lab, start, stop in S._binidx2seglist(S._energy_activity(le, seg.energy_ratio)[::2]):
+                lseg.append(('noEnergy' if lab == 0 else 'energy', start, stop))
+            lsegs.append(lseg)
+        for net in ([seg.vad, seg.gender] if seg.detect_gender else [seg.vad]):
+            rows, spans = [], []
+            for f, lseg in enumerate(lsegs):
+                wr = S._window_rows(nfr[f]) + np.int32(g0[f])
+                for lab, start, stop in lseg:
+                    if lab == net.inlabel:
+                        rows.append(wr[start:stop])
+                        spans.append(stop - start)
+            if rows:
+                probs, _fin = ctx.cnn_probs(net.net_id, np.concatenate(rows))
+            trans = S.diag_trans_exp(net.viterbi_arg, len(net.outlabels))
+            pos, out = 0, []
+            for lseg in lsegs:
+                ret = []
+                for lab, start, stop in lseg:
+                    if lab != net.inlabel:
+                        ret.append((lab, start, stop))
+                        continue
+                    n = stop - start
+                    with np.errstate(divide='ignore'):
+                        pred = S.viterbi_decoding(np.log(probs[pos:pos + n]), trans)
+                    pos += n
+                    for lab2, start2, stop2 in S._binidx2seglist(pred):
+                        ret.append((net.outlabels[int(lab2)], start2 + start, stop2 + start))
+                out.append(ret)
+            lsegs = out
+        return lsegs
+
+
+def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch_files=32, batch_seconds=3 * 3600,
+                  workers=2, decode_threads=4):
+    """Segment `linput` with the networks of `seg`; on_result(index, src, lseg | None, errtext | None) is called from the
+    worker threads (serialised by a lock) as results become available, lseg = [(label, start_sec, stop_sec)].
+    skip: set of indices not to process.  Device failures (NativeError) propagate to the caller."""
+    from . import segmenter as S
+    items = [(i, src) for i, src in enumerate(linput) if not (skip and i in skip)]
+    dec_q = queue.Queue(maxsize=4 * batch_files)
+    _decode_stage(items, seg.ffmpeg, nbtry, trydelay, dec_q, decode_threads)
+    batch_q = queue.Queue(maxsize=max(2, workers))
+    lock = threading.Lock()
+    failure = []
+
+    def packer():
+        cur = _Batch()
+        try:
+            while True:
+                it = dec_q.get()
+                if it is None:
+                    break
+                i, src, sig, err = it
+                if sig is None:
+                    with lock:
+                        on_result(i, src, None, err)
+                    continue
+                if sig.dtype != np.int16 or sig.size < MIN_SAMPLES:
+                    batch_q.put(('single', i, src, sig))
+                    continue
+                cur.idx.append(i); cur.sigs.append(sig); cur.names.append(src)
+                if len(cur.idx) >= batch_files or cur.samples() >= batch_seconds * 16000:
+                    batch_q.put(('batch', cur))
+                    cur = _Batch()
+            if cur.idx:
+                batch_q.put(('batch', cur))
+        finally:
+            for _ in range(workers):
+                batch_q.put(None)
+
+    def work(w):
+        try:
+            while True:
+                job = batch_q.get()
+                if job is None:
+                    return
+                if failure:
+                    continue
+                if job[0] == 'single':
+                    _, i, src, sig = job
+                    try:
+                        with warnings.catch_warnings():
+                            warnings.simplefilter('ignore')
+                            mspec, loge, difflen = S._sig2feats(w.ctx, sig, src)
+                        lseg = [(lab, a * .02, b * .02) for lab, a, b in _slots(seg, w.ctx, mspec, loge, difflen)]
+                        res = (lseg, None)
+                    except ValueError as exc:                      # too short to analyse: a per-file error
+                        res = (None, 'error: %s %s' % (type(exc), exc))
+                    with lock:
+                        on_result(i, src, res[0], res[1])
+                    continue
+                b = job[1]
+                lsegs = w.run(b)
+                with lock:
+                    for i, src, lseg in zip(b.idx, b.names, lsegs):
+                        on_result(i, src, [(lab, a * .02, c * .02) for lab, a, c in lseg], None)
+        except BaseException as exc:                               # noqa: B902  propagate to the caller's thread
+            failure.append(exc)
+
+    ws = [_Worker(seg, seg.ctx if k == 0 else None) for k in range(max(1, workers))]
+    threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in ws]
+    pk = threading.Thread(target=packer, daemon=True)
+    pk.start()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    pk.join()
+    for w in ws:
+        w.close()
+    if failure:
+        raise failure[0]
+
+
+def _slots(seg, ctx, mspec, loge, difflen):
+    """segment_slots of `seg` on another context (the networks are loaded there under the same ids)."""
+    from . import segmenter as S
+    lseg = []
+    for lab, start, stop in S._binidx2seglist(S._energy_activity(loge, seg.energy_ratio)[::2]):
+        lseg.append(('noEnergy' if lab == 0 else 'energy', start, stop))
+    for net in ([seg.vad, seg.gender] if seg.detect_gender else [seg.vad]):
+        lseg = net(mspec, lseg, difflen, ctx=ctx)
+    return lseg

@@ -144,22 +144,24 @@ class DnnSegmenter:
         """(n,C) float32 probabilities (+ finite mask) for the given slots of the resident mspec."""
         return self.ctx.cnn_probs(self.net_id, win_rows)
 
-    def __call__(self, mspec, lseg, difflen=0, dense=False):
+    def __call__(self, mspec, lseg, difflen=0, dense=False, ctx=None):
         """mspec: the RESIDENT mel spectrogram's frame count holder (`_Resident`) or a (T,24)
         array (uploaded first).  lseg: [(label, start, stop)] in 20 ms slots.  Returns the
         refined list, like segmenter.py:135-179.
         dense=True evaluates the network on EVERY slot of the file and then keeps the rows of
-        the `inlabel` segments (same result; input-independent device work, used by bench.py)."""
-        nframes = _ensure_resident(self.ctx, mspec)
+        the `inlabel` segments (same result; input-independent device work, used by bench.py).
+        ctx: another device context on which this network is loaded under the same id (pipeline workers)."""
+        ctx = ctx or self.ctx
+        nframes = _ensure_resident(ctx, mspec)
         rows = _window_rows(nframes, difflen)
         todo = [(start, stop) for lab, start, stop in lseg if lab == self.inlabel]
         if todo:
             idx = np.concatenate([np.arange(s, e) for s, e in todo])
             if dense:
-                allpred, _finite = self.predict_slots(rows)
+                allpred, _finite = ctx.cnn_probs(self.net_id, rows)
                 rawpred = allpred[idx]
             else:
-                rawpred, _finite = self.predict_slots(rows[idx])  # non-finite windows already at 0.5 (:175)
+                rawpred, _finite = ctx.cnn_probs(self.net_id, rows[idx])  # non-finite windows already at 0.5 (:175)
         ret = []
         trans = diag_trans_exp(self.viterbi_arg, len(self.outlabels))
         pos = 0
@@ -320,10 +322,15 @@ class Segmenter:
             start_sec = 0
         return self.segment_feats(mspec, loge, difflen, start_sec)
 
-    def batch_process(self, linput, loutput, verbose=False, skipifexist=False, nbtry=1, trydelay=2., output_format='csv'):
+    def batch_process(self, linput, loutput, verbose=False, skipifexist=False, nbtry=1, trydelay=2., output_format='csv',
+                      batch_files=32, workers=2):
         """segmenter.py:297-335: same arguments, same (t_batch_dur, nb_processed, avg, lmsg) with
-        lmsg entries (dst, code, text), code 0 ok / 1 already exists / 2 error.  Decoding of the
-        next files overlaps the device work of the current one (host thread, depth-2 queue)."""
+        lmsg entries (dst, code, text), code 0 ok / 1 already exists / 2 error, in input order.
+        The files run through pipeline.process_files: decode threads, super-batches of `batch_files` files per device
+        pass, `workers` device contexts alternating (the reference overlaps the feature extraction of file i+1 with the
+        networks of file i, :377-387).  Undecodable or too-short media are per-file errors (code 2) as in the
+        reference; device failures and unwritable outputs raise."""
+        from . import pipeline
         if verbose:
             print('batch_processing %d files' % len(linput))
         if output_format == 'csv':
@@ -334,66 +341,32 @@ class Segmenter:
             raise NotImplementedError()
 
         t_batch_start = time.time()
-        lmsg = []
-        q = queue.Queue(maxsize=2)
-        worker = threading.Thread(target=_decode_worker, daemon=True,
-                                  args=(list(linput), list(loutput), self.ffmpeg, skipifexist, nbtry, trydelay, q))
-        worker.start()
-        done = 0
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            dst, code, text, sig, src = item
-            done += 1
-            if code != 0:
-                lmsg.append((dst, code, text))
-                if verbose:
-                    print('%d/%d' % (done, len(linput)), [lmsg[-1]])
-                continue
-            b = time.time()
-            try:
-                with warnings.catch_warnings():
-                    if not verbose:
-                        warnings.simplefilter('ignore')
-                    mspec, loge, difflen = _sig2feats(self.ctx, sig, src)
-                lseg = self.segment_feats(mspec, loge, difflen, 0)
-                fexport(lseg, dst)
-                lmsg.append((dst, 0, 'ok ' + str(time.time() - b)))
-            except ValueError as exc:                              # undecodable / too short media: a per-file error like the
-                lmsg.append((dst, 2, 'error: %s %s' % (type(exc), exc)))   # reference's feature-extraction failures (:364-370).
-                # Device failures (NativeError) and unwritable outputs (OSError) propagate, as segment_feats / fexport
-                # errors do in the reference (:316-322): a broken context must not mark every remaining file 'error'.
-            if verbose:
-                print('%d/%d' % (done, len(linput)), [lmsg[-1]])
-        worker.join()
+        linput, loutput = list(linput), list(loutput)
+        msgs, skip, done = {}, set(), [0]
+        for i, dst in enumerate(loutput):
+            if skipifexist and os.path.exists(dst):
+                msgs[i] = (dst, 1, 'already exists')
+                skip.add(i)
+            else:
+                dname = os.path.dirname(dst)
+                if dname and not os.path.isdir(dname):
+                    os.makedirs(dname, exist_ok=True)
 
+        def on_result(i, src, lseg, err):
+            dst = loutput[i]
+            if lseg is None:
+                msgs[i] = (dst, 2, err)
+            else:
+                fexport(lseg, dst)
+                msgs[i] = (dst, 0, 'ok ' + str(time.time() - t_batch_start))
+            done[0] += 1
+            if verbose:
+                print('%d/%d' % (done[0] + len(skip), len(linput)), [msgs[i]])
+
+        pipeline.process_files(self, linput, on_result, skip=skip, nbtry=nbtry, trydelay=trydelay,
+                               batch_files=batch_files, workers=workers)
+        lmsg = [msgs[i] for i in range(len(linput))]
         t_batch_dur = time.time() - t_batch_start
         nb_processed = len([e for e in lmsg if e[1] == 0])
         avg = t_batch_dur / nb_processed if nb_processed > 0 else -1
         return t_batch_dur, nb_processed, avg, lmsg
-
-
-def _decode_worker(lin, lout, ffmpeg, skipifexist, nbtry, trydelay, q):
-    """Host-side producer: the decode half of medialist2feats (segmenter.py:338-374)."""
-    for src, dst in zip(lin, lout):
-        if skipifexist and os.path.exists(dst):
-            q.put((dst, 1, 'already exists', None, src))
-            continue
-        dname = os.path.dirname(dst)
-        if dname and not os.path.isdir(dname):
-            os.makedirs(dname)
-        sig, errmsg, itry = None, None, 0
-        while sig is None and itry < nbtry:
-            try:
-                sig = decode_pcm(src, None, None, ffmpeg)
-            except:                                                # noqa: E722  (reference semantics)
-                itry += 1
-                errmsg = sys.exc_info()[0]
-                if itry != nbtry:
-                    time.sleep(random.random() * trydelay)
-        if sig is None:
-            q.put((dst, 2, 'error: ' + str(errmsg), None, src))
-        else:
-            q.put((dst, 0, 'ok', sig, src))
-    q.put(None)
