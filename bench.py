@@ -5,7 +5,16 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
 RCCL).  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1] input, with the metric's smn + gender nets): every rank holds
+Workloads
+  segmenter (default for --gpus 1)   the configuration the metric is quoted on, below
+  batch                              BASELINE.json configs[2]: 128 x 5 min WAV files in /dev/shm through
+                                     Segmenter.batch_process -- decode, H2D, device, Viterbi and CSV export inside the timed region
+  archive   (default for --gpus > 1) BASELINE.json configs[3] shape: 3-minute WAV files, file-parallel over the ranks through
+                                     archive.segment_archive, ONE RCCL all-gather of the segment tables per step (C-ABI
+                                     iss_allgather_segments); --files-per-gpu of them per rank (weak scaling)
+  vbx                                BASELINE.json configs[4]
+
+segmenter workload (BASELINE.json configs[1] input, with the metric's smn + gender nets): every rank holds
 ONE 1 h synthetic 16 kHz mono PCM16 recording, already resident in HBM when the timed region
 starts (SURVEY.md section 8(d) generator: silence / -30 dBFS noise / harmonic "voiced" source /
 sustained chords, seeded with 20250926 + file index).  One step = one pass of the whole hot path
@@ -88,33 +97,172 @@ def synth_recording(file_index, n_samples, device):
 # ------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(seg, pcm_host, target_s=15.0):
     """The oracle (numpy restatement of the reference feature path + torch-CPU Keras-semantics
-    forward + the reference-order Viterbi) on a bounded sample of the same recording."""
+    forward + the reference-order Viterbi) on a bounded sample of the same recording.  Also returns what the parity check
+    needs: the oracle's segments and raw network outputs on that sample."""
     import torch
     from oracle import sidekit as osk, segment as oseg, keras_cnn as ocnn
-    threads = min(os.cpu_count() or 1, 64)      # torch-CPU conv stops scaling (and oversubscribes) beyond ~64 threads
+    cores_host = os.cpu_count() or 1
+    threads = min(cores_host, 64)               # torch-CPU conv stops scaling (and oversubscribes) beyond ~64 threads
     torch.set_num_threads(threads)
     vad_layers, gen_layers = seg.vad.layers, seg.gender.layers
 
-    def run(nsec):
+    def run(nsec, keep=False):
         sig = (pcm_host[:nsec * FS] / 32768.0).astype(np.float32)
         t0 = time.perf_counter()
         mspec, loge, difflen = osk.media2feats(sig)
-        oseg.segment_feats(mspec, loge, difflen, 0, 'smn',
-                           lambda b: ocnn.forward(vad_layers, b, batch_size=1024),
-                           lambda b: ocnn.forward(gen_layers, b, batch_size=1024))
-        return time.perf_counter() - t0
+        lseg0 = oseg.energy_seglist(loge, 0.03)
+        lseg1, raw_vad = oseg.dnn_segment('smn', lambda b: ocnn.forward(vad_layers, b, batch_size=1024), mspec, lseg0, difflen, return_raw=True)
+        lseg2, raw_gen = oseg.dnn_segment('gender', lambda b: ocnn.forward(gen_layers, b, batch_size=1024), mspec, lseg1, difflen, return_raw=True)
+        dt = time.perf_counter() - t0
+        det = dict(lseg0=lseg0, lseg1=lseg1, lseg2=lseg2, raw_vad=raw_vad, raw_gen=raw_gen, nframes=len(loge)) if keep else None
+        return dt, det
 
     probe = 20
-    t_probe = run(probe)
+    t_probe, _ = run(probe)
     nsec = int(max(probe, min(len(pcm_host) // FS, probe * target_s / max(t_probe, 1e-3))))
     nsec = min(nsec, 600)
-    t = run(nsec) if nsec > probe else t_probe
-    return {"value": (nsec / 3600.0) / t, "unit": "hours-of-audio/s", "cores": threads, "kind": "port",
-            "sample": f"first {nsec} s of the rank-0 recording, reference semantics (VAD on energy slots, gender on "
-                      f"speech slots), oracle/ numpy feature path + torch-CPU Keras-semantics CNN forward at "
-                      f"batch_size 1024 + reference-order Python Viterbi; {t:.2f} s wall; "
-                      f"stand-in for the TensorFlow/CPU path (TensorFlow is not installable here)",
-            "x_realtime": nsec / t}
+    t, det = run(nsec, keep=True)
+    # the CNN forward alone at the reference's default and recommended batch sizes (segmenter.py:222-224)
+    legs = {}
+    x = np.random.default_rng(0).normal(0, 1, (2048, 68, 21, 1)).astype(np.float32)
+    for bs in (32, 1024):
+        t0 = time.perf_counter()
+        ocnn.forward(vad_layers, x, batch_size=bs)
+        legs[f'vad_cnn_forward_batch{bs}_slots_per_s'] = len(x) / (time.perf_counter() - t0)
+    if os.path.isdir('/root/reference/inaSpeechSegmenter'):      # build container only: the unmodified reference front end
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('ref_sidekit_mfcc', '/root/reference/inaSpeechSegmenter/sidekit_mfcc.py')
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        sig = (pcm_host[:nsec * FS] / 32768.0).astype(np.float32)
+        t0 = time.perf_counter()
+        with np.errstate(divide='ignore'):
+            m.mfcc(sig, get_mspec=True)
+        legs['reference_sidekit_mfcc_x_realtime_1thread'] = nsec / (time.perf_counter() - t0)
+    out = {"value": (nsec / 3600.0) / t, "unit": "hours-of-audio/s", "cores": threads, "threads_used": threads,
+           "cores_host": cores_host, "kind": "port",
+           "sample": f"first {nsec} s of the rank-0 recording, reference semantics (VAD on energy slots, gender on "
+                     f"speech slots), oracle/ numpy feature path (1 thread) + torch-CPU Keras-semantics CNN forward at "
+                     f"batch_size 1024 ({threads} threads: torch-CPU convolutions stop scaling beyond ~64) + "
+                     f"reference-order Python Viterbi; {t:.2f} s wall; "
+                     f"stand-in for the TensorFlow/CPU path (TensorFlow is not installable here)",
+           "x_realtime": nsec / t, "legs": legs}
+    return out, nsec, det
+
+
+def parity_check(seg, pcm_host, nsec, det):
+    """GPU vs oracle on the cpu_baseline sample: identical segments, and max |p_gpu - p_oracle| over every slot the oracle
+    evaluated (VAD net on its energy slots, gender net on its speech slots)."""
+    from inaspeechsegmenter_amd import segmenter as S
+    sig = np.ascontiguousarray(pcm_host[:nsec * FS])
+    got = seg.segment_signal(sig)
+    want = [(lab, a * .02, b * .02) for lab, a, b in det['lseg2']]
+    rows = S._window_rows(det['nframes'])
+    worst, nslots = 0.0, 0
+    for net_id, raw, lseg_in, inlabel in ((0, det['raw_vad'], det['lseg0'], 'energy'), (1, det['raw_gen'], det['lseg1'], 'speech')):
+        idx = [np.arange(a, b) for lab, a, b in lseg_in if lab == inlabel]
+        if not idx or raw is None:
+            continue
+        idx = np.concatenate(idx)
+        p, fin = seg.ctx.cnn_probs(net_id, rows[idx])
+        ok = fin & np.all(np.isfinite(raw), axis=1)
+        worst = max(worst, float(np.abs(p[ok] - raw[ok]).max()) if ok.any() else 0.0)
+        nslots += int(ok.sum())
+    return {"segments_equal": got == want, "segments": len(want), "max_abs_dprob": worst, "slots": nslots,
+            "sample_s": nsec, "what": "Segmenter.segment_signal on the cpu_baseline sample vs the oracle pipeline (labels and "
+                                      "boundaries), and iss_cnn_probs vs the oracle's network outputs on every slot it evaluated"}
+
+
+# ------------------------------------------------------------------------------ file workloads
+def write_wav(path, pcm):
+    import struct
+    with open(path, 'wb') as f:
+        f.write(b'RIFF' + struct.pack('<I', 36 + pcm.nbytes) + b'WAVEfmt ' + struct.pack('<IHHIIHH', 16, 1, 1, 16000, 32000, 2, 16)
+                + b'data' + struct.pack('<I', pcm.nbytes))
+        f.write(pcm.tobytes())
+
+
+def make_files(indices, minutes, dev, root):
+    """Synthetic WAV files (SURVEY 8(d) generator, seed 20250926 + file index) under `root`; returns their paths by index."""
+    os.makedirs(root, exist_ok=True)
+    n = int(minutes * 60 * FS)
+    paths = {}
+    for i in indices:
+        p = os.path.join(root, f'f{i:06d}.wav')
+        if not (os.path.exists(p) and os.path.getsize(p) == 44 + 2 * n):
+            write_wav(p, synth_recording(i, n, dev).cpu().numpy())
+        paths[i] = p
+    return paths, n
+
+
+def bench_files(args, torch, dev, local_rank, rank, world, kind):
+    """`batch` (configs[2], one GPU) and `archive` (configs[3] shape, file-parallel + one all-gather) workloads."""
+    from inaspeechsegmenter_amd import Segmenter, _native, sharding
+    from inaspeechsegmenter_amd.archive import segment_archive
+    seg = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models='synthetic', device=local_rank)
+    x3 = args.precision == 'bf16x3'
+    seg.ctx.set_precision(_native.PREC_BF16X3 if x3 else _native.PREC_F32)
+    comm = sharding.rccl_rendezvous(seg.ctx, rank, world) if world > 1 else None
+    minutes = args.file_minutes or (5.0 if kind == 'batch' else 3.0)
+    per_gpu = args.files_per_gpu or 128
+    nfiles = per_gpu * world
+    root = os.path.join(args.dir, f'{kind}_{minutes:g}min')
+    mine = [i for i in range(nfiles) if i % world == rank]           # = sharding.shard_files for equal sizes
+    paths, n = make_files(mine, minutes, dev, root)
+    lin = [os.path.join(root, f'f{i:06d}.wav') for i in range(nfiles)]
+    lout = [os.path.join(root, f'out_r{rank}', f'f{i:06d}.csv') for i in range(nfiles)]
+    sizes = [44 + 2 * n] * nfiles
+    hours = nfiles * minutes / 60.0
+
+    def step():
+        if kind == 'batch':
+            t, nb, avg, lmsg = seg.batch_process(lin, lout)
+            assert nb == nfiles, [m for m in lmsg if m[1] != 0][:3]
+            return nb
+        table, lmsg = segment_archive(seg, lin, lout, sizes=sizes, comm=comm)
+        assert len(table) == nfiles and all(m[1] == 0 for m in lmsg), (len(table), [m for m in lmsg if m[1] != 0][:3])
+        return sum(len(v) for v in table.values())
+
+    for _ in range(max(args.warmup, 1)):
+        nseg = step()
+
+    def barrier():
+        if comm:
+            comm.barrier()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nseg = step()
+    seg.ctx.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if comm:
+        dt = comm.max_over_ranks(dt)
+    if rank == 0:
+        value = args.steps * hours / dt
+        line = {
+            "metric": "hours-of-audio segmented/sec (smn+gender, 16 kHz mono)",
+            "value": value, "unit": "hours-of-audio/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (bf16x3 split-operand MFMA, f32 accumulate; f64 FFT)" if x3 else "f32 (f32 MFMA; f64 FFT)"),
+            "data": "synthetic", "x_realtime_per_gpu": value * 3600.0 / world,
+            "config": {"workload": (f"BASELINE.json configs[2]: {nfiles} x {minutes:g} min synthetic 16 kHz mono PCM16 WAV files in {args.dir} "
+                                    "through Segmenter.batch_process" if kind == 'batch' else
+                                    f"BASELINE.json configs[3] shape: {nfiles} x {minutes:g} min synthetic WAV files ({per_gpu} per GPU, weak scaling), "
+                                    "file-parallel through archive.segment_archive, one RCCL all-gather of the segment tables per step") +
+                                   "; reference semantics (VAD net on energy slots, gender net on speech slots); RIFF parse, H2D copy, device "
+                                   "features + CNNs, compiled Viterbi and CSV export are all inside the timed region",
+                       "files": nfiles, "files_per_gpu": per_gpu, "minutes_per_file": minutes, "audio_hours_per_step": hours,
+                       "ms_per_file_per_gpu": dt / args.steps / per_gpu * 1e3, "segments_per_step": nseg,
+                       "weights": "seeded stand-ins, (68,21,1)->3 and (68,24,1)->2, ~1.25 M params each (real Keras files are un-vendored release assets)",
+                       "parallelism": (f"file-parallel x{world}: files dealt by size (LPT), no data-path collective, ONE ncclAllGather of int32 segment "
+                                       "tables per step through the C-ABI (iss_allgather_segments)") if world > 1 else "single GPU"},
+        }
+        print(json.dumps(line))
+    barrier()
+    seg.close()
 
 
 def bench_vbx(args, torch, dev, local_rank, rank, world):
@@ -173,8 +321,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--minutes', type=float, default=60.0, help='length of each rank\'s recording')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', choices=['segmenter', 'vbx'], default='segmenter',
-                    help="segmenter = the metric's workload (default); vbx = BASELINE.json configs[4] (x-vector path)")
+    ap.add_argument('--workload', choices=['segmenter', 'batch', 'archive', 'vbx'], default=None,
+                    help="segmenter = the metric's workload (default for --gpus 1); archive = file-parallel configs[3] shape "
+                         "(default for --gpus > 1); batch = configs[2]; vbx = configs[4] (x-vector path)")
+    ap.add_argument('--files-per-gpu', type=int, default=0, help='batch / archive: files per GPU and step (default 128)')
+    ap.add_argument('--file-minutes', type=float, default=0.0, help='batch / archive: minutes per file (default 5 / 3)')
+    ap.add_argument('--dir', default='/dev/shm/iss_bench', help='batch / archive: where the synthetic WAV files live')
+    ap.add_argument('--no-f32-companion', action='store_true', help='skip the exact-f32 (ISS_PREC_F32) companion step')
     ap.add_argument('--workspace-mb', type=int, default=0, help='activation workspace cap (0 = library default)')
     ap.add_argument('--precision', choices=['bf16x3', 'f32'], default='bf16x3',
                     help='conv/dense GEMM arithmetic: split-bf16 MFMA (default) or exact-f32 MFMA')
@@ -193,8 +346,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if args.workload is None:
+        args.workload = 'segmenter' if world == 1 else 'archive'
+    if args.workload in ('batch', 'archive'):
+        if args.workload == 'batch' and world > 1:
+            raise SystemExit("--workload batch is the single-GPU configs[2]; use --workload archive for N > 1")
+        return bench_files(args, torch, dev, local_rank, rank, world, args.workload)
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
 
     from inaspeechsegmenter_amd import Segmenter, _native
@@ -262,13 +421,18 @@ def main():
     other_ms, other_launches, _ = seg.ctx.prof_get(2)
     seg.ctx.prof_enable(False)
     achieved_tf = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    traffic = None
+    # HBM traffic per conv launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own): read from the
+    # committed summary of the latest such passes and labelled as static; `traffic` applies the guide's gfx950 correction
+    # (FETCH_SIZE reports half of a wide coalesced read: fetch x 2 + write), `traffic_raw` is the counters' own sum
+    traffic = traffic_raw = None
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get('conv_hbm_bytes_per_launch_' + args.precision)
+            pj = json.load(open(pmc_path))
+            traffic_raw = pj.get('conv_hbm_bytes_per_launch_' + args.precision)
+            traffic = pj.get('conv_hbm_bytes_per_launch_corrected_' + args.precision, traffic_raw)
         except Exception:
-            traffic = None
+            traffic = traffic_raw = None
     sk_bytes = n * 2 + seg.ctx.T * 25 * 4                # PCM16 in + (24 mel + 1 loge) f32 out
     peak_tf = MFMA_BF16_PEAK_TF if x3 else MFMA_F32_PEAK_TF
     roofline = {"bound": "mfma",
@@ -277,7 +441,9 @@ def main():
                            "3x that, and the first layer, 1.9 % of them, is computed once per log-mel row instead of once per window)") if x3 else
                           "conv_igemm_kernel (conv2d/dense implicit GEMM, v_mfma_f32_32x32x2_f32)",
                 "achieved": achieved_tf, "peak": peak_tf, "unit": "TFLOP/s",
-                "frac": achieved_tf / peak_tf, "traffic": traffic,
+                "frac": achieved_tf / peak_tf, "traffic": traffic, "traffic_raw": traffic_raw,
+                "traffic_source": "static_from_profiles (profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  "this build on bench.py --minutes 20; launch-weighted mean over the conv GEMM launches)",
                 "mfma_executed_tflops": achieved_tf * (3 if x3 else 1),
                 "flops_per_launch": conv_flops / max(conv_launches, 1), "avg_launch_ms": conv_ms / max(conv_launches, 1),
                 "launches_per_step": conv_launches, "kernel_ms_per_step": conv_ms,
@@ -287,9 +453,28 @@ def main():
                               "kernel_ms_per_step": sk_ms, "algorithmic_bytes": sk_bytes},
                 "other_kernels_ms_per_step": other_ms}
 
-    cpu = None
+    # ---- exact-f32 companion (ISS_PREC_F32: v_mfma_f32_32x32x2_f32, bit-wise an fmaf chain), one timed dense step
+    f32c = None
+    if x3 and not args.no_f32_companion:
+        seg.ctx.set_precision(_native.PREC_F32)
+        step(True)
+        dt32, (lseg32, _) = timed(1, True)
+        seg.ctx.prof_enable(True)
+        seg.ctx.prof_reset()
+        step(True)
+        c_ms, c_n, c_fl = seg.ctx.prof_get(0)
+        seg.ctx.prof_enable(False)
+        seg.ctx.set_precision(_native.PREC_BF16X3)
+        tf32 = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
+        f32c = {"value": world * hours / dt32, "unit": "hours-of-audio/s", "ms_per_step": dt32 * 1e3, "achieved": tf32,
+                "peak": MFMA_F32_PEAK_TF, "frac": tf32 / MFMA_F32_PEAK_TF, "segments_equal_bf16x3": lseg32 == lseg,
+                "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact f32 products and accumulation)"}
+
+    cpu = par = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(seg, pcm[:min(n, 600 * FS)].cpu().numpy())
+        host = pcm[:min(n, 600 * FS)].cpu().numpy()
+        cpu, nsec, det = cpu_baseline(seg, host)
+        par = parity_check(seg, host, nsec, det)
 
     if world > 1:
         dist.barrier()
@@ -317,8 +502,11 @@ def main():
                                                "gender_slot_frac": (slots['female'] + slots['male']) / P}},
             "roofline": roofline,
         }
+        if f32c is not None:
+            line["precision_f32"] = f32c
         if cpu is not None:
             line["cpu_baseline"] = cpu
+            line["parity_check"] = par
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

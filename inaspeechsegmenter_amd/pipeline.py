@@ -232,7 +232,12 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
         except BaseException as exc:                               # noqa: B902  propagate to the caller's thread
             failure.append(exc)
 
-    ws = [_Worker(seg, seg.ctx if k == 0 else None) for k in range(max(1, workers))]
+    # device workers are kept with the Segmenter between calls (context creation, network upload and the first
+    # workspace allocation cost more than a 5-minute file)
+    cache = seg.__dict__.setdefault('_pipeline_workers', [])
+    while len(cache) < max(1, workers):
+        cache.append(_Worker(seg, seg.ctx if not cache else None))
+    ws = cache[:max(1, workers)]
     threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in ws]
     pk = threading.Thread(target=packer, daemon=True)
     pk.start()
@@ -241,10 +246,13 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
     for t in threads:
         t.join()
     pk.join()
-    for w in ws:
-        w.close()
     if failure:
         raise failure[0]
+
+
+def close_workers(seg):
+    for w in seg.__dict__.pop('_pipeline_workers', []):
+        w.close()
 
 
 def _slots(seg, ctx, mspec, loge, difflen):

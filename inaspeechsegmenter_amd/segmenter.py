@@ -284,6 +284,11 @@ class Segmenter:
         if detect_gender:
             self.gender = Gender(batch_size, self.ctx, models)
 
+    def close(self):
+        """Release the extra device contexts of the multi-file pipeline (the main context goes with the object)."""
+        from . import pipeline
+        pipeline.close_workers(self)
+
     def segment_slots(self, mspec, loge, difflen, dense=False):
         """The body of segmenter.py:250-275 in 20 ms slot units: [(label, start_slot, stop_slot)]."""
         lseg = []
