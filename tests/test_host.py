@@ -5,6 +5,7 @@ import io
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -319,3 +320,47 @@ def test_host_mirror_bookkeeping_equals_reference_lines(engine, nvad):
         assert [g[0] for g in got] == list(pin[f'{engine}_{tag}_labels']), tag
         assert np.array_equal(np.array([[a, b] for _, a, b in got], dtype=np.float64).reshape(-1, 2),
                               pin[f'{engine}_{tag}_bounds'].reshape(-1, 2)), tag
+
+
+def test_ffmpeg_decode_path_with_a_shim(tmp_path):
+    """io.py:56-79 through a stand-in `ffmpeg` executable (the image has none): the command line must be the reference's
+    (io.py:61-68: -i <media> -f wav -acodec pcm_s16le -ar 16000 -ac 1 [-ss %f] [-to %f] pipe:1), the WAV arrives on a pipe
+    (RIFF / data sizes unknown = 0xFFFFFFFF, an extra LIST chunk in front of the data) and a non-zero exit raises with stderr."""
+    import stat
+    import struct
+    import subprocess
+    pcm = (np.arange(48000) % 2000 - 1000).astype('<i2')
+    src = tmp_path / 'in.mp3'
+    src.write_bytes(pcm.tobytes())                          # the shim "decodes" raw PCM16
+    shim = tmp_path / 'ffmpeg'
+    shim.write_text(f'''#!{sys.executable}
+import struct, sys
+a = sys.argv[1:]
+open({str(tmp_path / "argv.txt")!r}, 'w').write('\\n'.join(a))
+if 'broken' in a[1]:
+    sys.stderr.write('Invalid data found when processing input'); sys.exit(1)
+pcm = open(a[1], 'rb').read()
+ss = float(a[a.index('-ss') + 1]) if '-ss' in a else 0.0
+to = float(a[a.index('-to') + 1]) if '-to' in a else len(pcm) / 32000.0
+pcm = pcm[int(ss * 16000) * 2:int(to * 16000) * 2]
+out = sys.stdout.buffer
+out.write(b'RIFF' + struct.pack('<I', 0xFFFFFFFF) + b'WAVEfmt ' + struct.pack('<IHHIIHH', 16, 1, 1, 16000, 32000, 2, 16))
+out.write(b'LIST' + struct.pack('<I', 26) + b'INFOISFT' + struct.pack('<I', 14) + b'Lavf58.76.100\\0')
+out.write(b'data' + struct.pack('<I', 0xFFFFFFFF) + pcm)
+''')
+    shim.chmod(shim.stat().st_mode | stat.S_IEXEC)
+    import sys as _sys  # noqa: F401
+    a = iss_io.decode_pcm(str(src), None, None, str(shim))
+    assert a.dtype == np.int16 and np.array_equal(a, pcm)
+    assert (tmp_path / 'argv.txt').read_text().split('\n') == ['-i', str(src), '-f', 'wav', '-acodec', 'pcm_s16le', '-ar', '16000',
+                                                                '-ac', '1', 'pipe:1']
+    b = iss_io.decode_pcm(str(src), 0.5, 2.25, str(shim))
+    assert np.array_equal(b, pcm[8000:36000])
+    assert (tmp_path / 'argv.txt').read_text().split('\n') == ['-i', str(src), '-f', 'wav', '-acodec', 'pcm_s16le', '-ar', '16000',
+                                                                '-ac', '1', '-ss', '0.500000', '-to', '2.250000', 'pipe:1']
+    f = iss_io.media2sig16kmono(str(src), 0.5, None, str(shim), 'float32')      # reference signature / float result
+    assert f.dtype == np.float32 and np.array_equal(f, (pcm[8000:] / 32768.0).astype(np.float32))
+    bad = tmp_path / 'broken.mp3'
+    bad.write_bytes(b'xx')
+    with pytest.raises(Exception, match='Invalid data'):
+        iss_io.decode_pcm(str(bad), None, None, str(shim))
