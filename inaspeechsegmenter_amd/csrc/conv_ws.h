@@ -397,8 +397,8 @@ void launch_ws_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, 
 }  // namespace issk
 
 // Filter shapes the weight-stationary kernel is instantiated for (cnn_ws.hip)
-#define ISS_WS_SHAPES_A(X) X(3, 3) X(5, 3)
-#define ISS_WS_SHAPES_B(X) X(3, 5) X(4, 4)
+#define ISS_WS_SHAPES_A(X) X(5, 3)
+#define ISS_WS_SHAPES_B(X) X(3, 3)
 #define ISS_WS_SHAPES(X) ISS_WS_SHAPES_A(X) ISS_WS_SHAPES_B(X)
 #define ISS_WS_DECL(KH_, KW_) void iss_ws_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused);
 ISS_WS_SHAPES(ISS_WS_DECL)
