@@ -858,7 +858,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         if (R1[ISS_C_BOFF] < 0 || (R1[ISS_C_PSOFF] >= 0) != (R1[ISS_C_PTOFF] >= 0) || R1[ISS_C_COUT] % 4 != 0 || n.wsum_off[r] < 0) return false;
         if (R2[ISS_C_OP] != ISS_OP_CONV || R2[ISS_C_INMODE] != 0 || R2[ISS_C_IN] != R1[ISS_C_OUT] || R2[ISS_C_RES] >= 0) return false;
         if (R2[ISS_C_CIN] != R1[ISS_C_COUT] || R2[ISS_C_CIN] % XBK != 0 || R2[ISS_C_H] != R1[ISS_C_HO] || R2[ISS_C_W] != R1[ISS_C_WO]) return false;
-        if (R2[ISS_C_KH] * R2[ISS_C_KW] < 8 || !fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW])) return false;   // (>= 12 on the first-generation kernel, see conv_row)
+        if (R2[ISS_C_KH] * R2[ISS_C_KW] < 8 || !fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW])) return false;   // (>= 12 unless the weight-stationary kernel takes it, see conv_row)
         if (R2[ISS_C_PT] != 0 || R2[ISS_C_PL] != 0 || (R2[ISS_C_HO] - 1) * R2[ISS_C_SH] + R2[ISS_C_KH] > R2[ISS_C_H] ||
             (R2[ISS_C_WO] - 1) * R2[ISS_C_SW] + R2[ISS_C_KW] > R2[ISS_C_W]) return false;
         // the footprint may touch two windows at most, and the x / W trick of the kernel needs a small W
@@ -919,16 +919,12 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         dim3 grid(a.nblk, a.nblk_n);
         const dim3 grid1(a.nblk * a.nblk_n);          // generic kernels: 1-D, XCD-aware (gemm_tile_of_block)
         double fl = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * a.Cin * (double)a.Cout * (double)a.M;
-        bool fp = false, fp2 = false;                  // LDS-footprint kernel usable: first / second generation
-        static const bool no_v2 = getenv("ISS_FP_V2") == nullptr;       // the 16-channel-chunk variant (conv_fp2.h) measured 3-5 % slower
-                                                                        // than the first-generation kernel: opt-in for A/B runs
+        bool fp = false;                               // LDS-footprint kernel usable
         if (x3 && a.mode == 0 && fp_shape_compiled(a.H_k, a.kw) && a.M < (1ll << 31)) {
             const long long key = ((long long)r << 32) | (unsigned)bc;
             auto it = n.fp_pix.find(key);
             if (it == n.fp_pix.end()) it = n.fp_pix.emplace(key, footprint_pixels(a)).first;
             fp = it->second <= FPIX;
-            fp2 = !no_v2 && it->second <= F2_PIX && a.H_k * a.kw >= 8;
-            fp = fp || fp2;
         }
         // weight-stationary kernel (conv_ws.h): the shared-first-layer convolution, 8..16 taps, one N tile of 64 channels
         bool ws = false;
@@ -945,7 +941,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         bool fused = false;
         if (pend >= 0) {
             const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
-            fused = fp && !padded && (fp2 || ws || a.H_k * a.kw >= 12) && d_winrow != nullptr &&
+            fused = fp && !padded && (ws || a.H_k * a.kw >= 12) && d_winrow != nullptr &&
                     ((long long)(rmax - rmin) + Rp[ISS_C_HO]) * Rp[ISS_C_WO] * Rp[ISS_C_COUT] < (1ll << 32);   // 32-bit offsets into R
         }
         if (!fused && (long long)bc * a.img_stride >= (1ll << 32)) fp = false;        // 32-bit offsets into the input batch
@@ -989,7 +985,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             ISS_WS_SHAPES(ISS_WS_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no weight-stationary kernel for %dx%d", a.H_k, a.kw); }
 #undef ISS_WS_CASE
         } else if (fp) {
-#define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr, fused, nh, fp2); else
+#define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr, fused, nh); else
             // 128 output channels per workgroup where the layer has them: one LDS footprint serves two 64-column halves
             static const bool no_nh2 = getenv("ISS_NO_NH2") != nullptr;
             const int nh = (!fused && !no_nh2 && issk::iss_fp_has_nh2(a.H_k, a.kw) && a.Cout % (2 * BN) == 0) ? 2 : 1;

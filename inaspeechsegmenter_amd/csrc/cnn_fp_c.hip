@@ -1,5 +1,5 @@
 // Instantiation unit of conv_x3_fp_kernel (conv_fp.h) for a subset of the filter shapes.
-#include "conv_fp2.h"
+#include "conv_fp.h"
 
 ISS_FP_DEFINE(3, 5)
 ISS_FP_DEFINE(5, 5)

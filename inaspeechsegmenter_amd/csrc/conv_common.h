@@ -123,7 +123,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // ACT: 0 none, 1 relu, -1 = read p.act at run time (sigmoid / tanh); PP: fused pool window size (1, 2, 4);
 // HAS_PS: post-activation scale/shift; HAS_RES: residual add.  The common combinations are compiled without any
 // per-element branch (the fully generic form, inlined 32 times per tile, was ~6000 ISA lines of mostly skipped code).
-// P: ConvArgs, or the EpiArgs subset the second-generation footprint kernel loads at the end of a tile (conv_fp2.h)
+// P: ConvArgs, or the EpiArgs subset the weight-stationary kernel loads at the end of a tile group (conv_ws.h)
 template <int ACT, int PP, bool HAS_PS, bool HAS_RES, class P>
 __device__ __forceinline__ void epilogue_impl(const P& p, const floatx16& acc, long long mrow0, int n, int lh) {
     if (n >= p.Cout) return;

@@ -465,12 +465,10 @@ inline bool iss_fp_has_nh2(int kh, int kw) { return kh == 3 && kw == 3; }
 // Filter shapes the footprint kernel is instantiated for (the tap loop is unrolled at compile time); other shapes
 // run on conv_x3_kernel.  One extern launcher per shape, defined in the cnn_fp_*.hip units.
 #define ISS_FP_SHAPES(X) X(3, 3) X(5, 3) X(3, 5) X(5, 5) X(2, 2) X(4, 4) X(1, 3) X(3, 1)
-#define ISS_FP_DECL(KH_, KW_) void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused, int nh, bool v2);
+#define ISS_FP_DECL(KH_, KW_) void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused, int nh);
 ISS_FP_SHAPES(ISS_FP_DECL)
 #undef ISS_FP_DECL
-// v2: the second-generation kernel of conv_fp2.h (shapes with >= 6 taps; the caller has checked its footprint capacity)
 #define ISS_FP_DEFINE(KH_, KW_)                                                                               \
-    void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused, int nh, bool v2) { \
-        if (v2) issk::launch_fp2_shape<KH_, KW_>(a, grid, st, padded, tr, fused, nh);                                 \
-        else issk::launch_fp_shape<KH_, KW_>(a, grid, st, padded, tr, fused, nh);                                     \
+    void iss_fp_launch_##KH_##x##KW_(const issk::ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused, int nh) { \
+        issk::launch_fp_shape<KH_, KW_>(a, grid, st, padded, tr, fused, nh);                                          \
     }

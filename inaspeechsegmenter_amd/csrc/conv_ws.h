@@ -1,7 +1,7 @@
 // conv_x3_ws_kernel: weight-stationary LDS-footprint bf16x3 implicit GEMM (8 <= kh*kw <= 16 taps, Cin % 16 == 0,
 // one 64-column N tile per workgroup).
 //
-// The footprint kernels of conv_fp.h / conv_fp2.h stream an 8 KB weight tile per 12 MFMAs and wave through LDS (LDS-DMA,
+// The footprint kernel of conv_fp.h streams an 8 KB weight tile per 12 MFMAs and wave through LDS (LDS-DMA,
 // a ring of stages, a counted vmcnt wait and a workgroup barrier per tile): for the 5x3 64->64 convolution that is 63 % of
 // a segmenter step the weights of one tile (245 KB) are 3.5 x its input footprint, and they are the SAME for every tile.
 // rocprofv3 counters (profiles/r01_pmc.md) showed those kernels at 47 % matrix-pipe occupancy with 30 % of the wave
@@ -17,11 +17,43 @@
 //
 // No weight ring, no vmcnt bookkeeping and no barrier inside a block: a wave's stream is ds_read_b128 + MFMA with
 // a conversion slice every other step.  512 threads = 8 waves (two per SIMD, decoupled between barriers) share one
-// footprint of 512 pixels (41 KB per buffer, 80-byte linear rows as in conv_fp2.h) and the weight block (60 KB for 5x3).
+// footprint of 512 pixels (41 KB per buffer) and the weight block (60 KB for 5x3).
+//
+// LDS layout.  Footprint rows are 80 bytes per pixel -- 16 channels hi (32 B) | 16 channels lo (32 B) | 16 B pad -- and
+// LINEAR: the A-fragment address of a tap is (lane base + tap offset), one v_add per step, and 16 consecutive pixels still
+// hit 16 different 16-byte bank groups (20 p mod 64 is a permutation of the multiples of 4).  Zero-padded taps read an
+// all-zero pixel kept behind each footprint (one v_cndmask on the address instead of zeroing eight fragment registers).
+// The 16-byte slots of a weight tile are permuted on the SOURCE side of the LDS-DMA (slot = 2 n + (h ^ ((n >> 3) & 1)) for
+// row n, k half h) so that the ds_read_b128 of the 16 lanes of a group are conflict-free.  Geometry and epilogue
+// parameters are read through an opaque copy of the kernel-argument pointer where they are needed instead of living in
+// SGPRs through the main loop (conv_x3_fp_kernel spills 136 SGPRs and 11 VGPRs of its 45-word argument block).
 #pragma once
-#include "conv_fp2.h"
+#include "conv_fp.h"
 
 namespace issk {
+
+constexpr int F2_ROW = 80;                        // bytes per footprint pixel: 16 ch hi (32 B) | 16 ch lo (32 B) | 16 B pad
+constexpr int F2_BST = 4096;                      // bytes of one weight stage: hi plane (64 rows x 16 k bf16 = 2 KB) | lo plane
+constexpr int F2_CH = 16;                         // channels per chunk (one k16 MFMA step)
+
+typedef const bf16x8 __attribute__((address_space(3)))* LdsR16;
+typedef bf16x4 __attribute__((address_space(3)))* LdsW8;
+typedef unsigned __attribute__((address_space(3)))* LdsW4;
+
+// geometry parameters (row decomposition of a tile): loaded from the kernel-argument segment once per tile
+struct GeoArgs {
+    int H, W, Hq, Wq, ph, pw, pp, sh, sw, pt_, pl_;
+    unsigned dv_mul[4];
+    int dv_sh[4];
+};
+typedef const ConvArgs __attribute__((address_space(4)))* KArg;
+
+// epilogue parameters, loaded from the kernel-argument segment when a tile is complete
+struct EpiArgs {
+    const float* bias; const float* ps; const float* pt; const float* res; float* out;
+    long long M; int Cout, act, pp, poolkind;
+};
+
 
 constexpr int WS_TM = 256;                         // GEMM rows per tile: 8 waves x 32
 constexpr int WS_G = 4;                            // tiles per group
@@ -54,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     int grp = (int)blockIdx.x;
     if (grp >= ngroups) return;
 
-    // ---- geometry (row decomposition parameters through the kernel-argument pointer, see conv_fp2.h)
+    // ---- geometry (row decomposition parameters through the kernel-argument pointer)
     auto geo_args = [&]() {
         KArg q = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(q));
@@ -126,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     // ---- weights of one 16-channel chunk: NT tiles of 4 KB = 4 NT pieces of 1 KB; wave w moves pieces w, w + 8, ...
     // piece i: tap i >> 2, plane (i >> 1) & 1 (hi / lo), half i & 1 (rows 0-31 / 32-63).  Lane l of a piece writes 16-byte
     // slot 64 half + l and fetches the (row n, k half h) that belongs there: n = 32 half + (l >> 1),
-    // h = (l & 1) ^ ((n >> 3) & 1)  (conv_fp2.h: conflict-free B reads).  Rows >= Cout read row 0 (never stored).
+    // h = (l & 1) ^ ((n >> 3) & 1)  (conflict-free B reads, see above).  Rows >= Cout read row 0 (never stored).
     unsigned boff[2];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -197,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     };
     auto convert_slice = [&](int q, int buf) {       // q, buf: compile-time
         float4 v = fv[q];
-        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(dbmask));    // not before this point (conv_fp2.h)
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(dbmask));    // not before this point: hipcc would hoist the conversion right behind the loads, i.e. an s_waitcnt for fresh loads in front of the MFMAs the loads hide behind
         if (FUSED) {
             const bool second = (dbmask >> q) & 1u;
             const float sc = second ? rs1 : rs0;
@@ -351,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
             run_block(2, acc20, acc21);
             run_block(3, acc30, acc31);
         }
-        // ---- group complete: epilogue parameters through the kernel-argument pointer (conv_fp2.h)
+        // ---- group complete: epilogue parameters through the kernel-argument pointer
         {
             KArg q = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(q));
