@@ -341,11 +341,16 @@ class Context:
         self._ck(self._L.iss_vbx_set_dither(self._h, _ptr(u, C.c_double), u.size), 'iss_vbx_set_dither')
         self._dither_n = u.size
 
-    def vbx_features_pcm16(self, pcm):
+    def vbx_features_pcm16(self, pcm, to_host=True):
+        """-> (T, 64) float32, or with to_host=False just T (the features stay on the device for iss_vbx_embed)."""
         s = np.ascontiguousarray(pcm, dtype=np.int16)
         T = (s.size + 320 - 400) // 160 + 1
-        out = np.empty((T, 64), dtype=np.float32)
         t = C.c_int32()
+        if not to_host:
+            self._ck(self._L.iss_vbx_features_pcm16(self._h, _ptr(s, C.c_int16), s.size, None, C.byref(t)), 'iss_vbx_features_pcm16')
+            assert t.value == T
+            return T
+        out = np.empty((T, 64), dtype=np.float32)
         self._ck(self._L.iss_vbx_features_pcm16(self._h, _ptr(s, C.c_int16), s.size, _ptr(out, C.c_float), C.byref(t)),
                  'iss_vbx_features_pcm16')
         assert t.value == T

@@ -33,6 +33,17 @@ def dither_stream(n, seed=3):
     return np.random.RandomState(seed).rand(n)
 
 
+class ResidentFeatures:
+    """Stand-in for the (T, 64) feature array when it is left on the device (`FeatureExtractor(..., to_host=False)`):
+    VBxExtractor only needs its length and identity, the windows are gathered on the device (iss_vbx_embed)."""
+
+    def __init__(self, nframes):
+        self.nframes = nframes
+
+    def __len__(self):
+        return self.nframes
+
+
 class FeatureExtractor:
     """get_features (vbx_segmenter.py:72-89) bound to one device context.  The features also stay resident on
     the device; `VBxExtractor` recognises the array it is handed back and gathers its windows there."""
@@ -47,7 +58,9 @@ class FeatureExtractor:
         if n > self.ctx._dither_n:
             self.ctx.vbx_set_dither(dither_stream(max(n, 2 * self.ctx._dither_n)))
 
-    def __call__(self, signal):
+    def __call__(self, signal, to_host=True):
+        """to_host=False (PCM16 input only): the (T, 64) array is not copied back (92 MB per audio-hour), a
+        `ResidentFeatures` handle is returned instead."""
         signal = np.asarray(signal)
         if signal.dtype == np.int16:                                  # PCM16 source: (signal/32768 * 2**15).astype(int) == pcm
             pcm = signal
@@ -59,6 +72,10 @@ class FeatureExtractor:
                 self.ctx._vbx_resident = fea
                 return fea
         self._ensure_dither(len(pcm))
+        if not to_host:
+            fea = ResidentFeatures(self.ctx.vbx_features_pcm16(pcm, to_host=False))
+            self.ctx._vbx_resident = fea
+            return fea
         fea = self.ctx.vbx_features_pcm16(pcm)
         self.ctx._vbx_resident = fea                                  # identity token for VBxExtractor
         return fea
@@ -118,7 +135,8 @@ class VBxExtractor:
         return self.get_embeddings(np.asarray(fea), [0], len(fea))[0]
 
     def __call__(self, basename, fea, duration):
-        fea = np.asarray(fea)
+        if not isinstance(fea, ResidentFeatures):
+            fea = np.asarray(fea)
         xvectors = []
         starts = list(range(0, len(fea) - WINLEN, STEP))
         start = starts[-1] if starts else 0

@@ -102,3 +102,15 @@ def test_pcm16_path_and_device_window_gather(ctx, extractor, golden_vbx):
     for n in (16000 * 3 + 777, 16000 * 4 + 99, 16000 * 5 + 1234):     # three more tail lengths: the two tail slots recycle
         f2 = fe(pcm[:n])
         assert len(extractor('u', f2, n / 16000.0)) == len(ovbx.window_list(len(f2)))
+
+
+def test_resident_features_handle(ctx, extractor, golden_vbx):
+    """FeatureExtractor(..., to_host=False): the (T, 64) array stays in HBM, the x-vectors are the same as with the copy."""
+    fe = V.FeatureExtractor(ctx)
+    pcm = golden_vbx['lamartine_pcm16']
+    fea = fe(pcm)
+    a = extractor('utt', fea, len(pcm) / 16000.0)
+    h = fe(pcm, to_host=False)
+    assert isinstance(h, V.ResidentFeatures) and len(h) == len(fea)
+    b = extractor('utt', h, len(pcm) / 16000.0)
+    assert [x[:2] for x in a] == [x[:2] for x in b] and all(np.array_equal(x[2], y[2]) for x, y in zip(a, b))
