@@ -144,20 +144,24 @@ class DnnSegmenter:
         """(n,C) float32 probabilities (+ finite mask) for the given slots of the resident mspec."""
         return self.ctx.cnn_probs(self.net_id, win_rows)
 
-    def __call__(self, mspec, lseg, difflen=0, dense=False, ctx=None):
+    def __call__(self, mspec, lseg, difflen=0, dense=False, ctx=None, allpred=None):
         """mspec: the RESIDENT mel spectrogram's frame count holder (`_Resident`) or a (T,24)
         array (uploaded first).  lseg: [(label, start, stop)] in 20 ms slots.  Returns the
         refined list, like segmenter.py:135-179.
         dense=True evaluates the network on EVERY slot of the file and then keeps the rows of
         the `inlabel` segments (same result; input-independent device work, used by bench.py).
-        ctx: another device context on which this network is loaded under the same id (pipeline workers)."""
+        ctx: another device context on which this network is loaded under the same id (pipeline workers).
+        allpred: probabilities of EVERY slot, already computed (Segmenter.segment_slots submits both networks
+        asynchronously in dense mode and smooths the first while the device evaluates the second)."""
         ctx = ctx or self.ctx
         nframes = _ensure_resident(ctx, mspec)
         rows = _window_rows(nframes, difflen)
         todo = [(start, stop) for lab, start, stop in lseg if lab == self.inlabel]
         if todo:
             idx = np.concatenate([np.arange(s, e) for s, e in todo])
-            if dense:
+            if allpred is not None:
+                rawpred = allpred[idx]
+            elif dense:
                 allpred, _finite = ctx.cnn_probs(self.net_id, rows)
                 rawpred = allpred[idx]
             else:
@@ -294,10 +298,34 @@ class Segmenter:
         lseg = []
         for lab, start, stop in _binidx2seglist(_energy_activity(loge, self.energy_ratio)[::2]):
             lseg.append(('noEnergy' if lab == 0 else 'energy', start, stop))
+        if dense and self.detect_gender:
+            # both networks on every slot, independent of each other: enqueue them back to back (iss_cnn_probs_async) and
+            # run the VAD Viterbi on the host while the device evaluates the gender network (the reference overlaps host
+            # and device work across files, segmenter.py:377-387; within one file its gender pass needs the VAD result)
+            ctx = self.ctx
+            rows = _window_rows(_ensure_resident(ctx, mspec), difflen)
+            t1, p1, _ = ctx.cnn_probs_async(self.vad.net_id, rows, *self._pinned_out(0, len(rows), len(self.vad.outlabels)))
+            t2, p2, _ = ctx.cnn_probs_async(self.gender.net_id, rows, *self._pinned_out(1, len(rows), len(self.gender.outlabels)))
+            ctx.wait(t1)
+            lseg = self.vad(mspec, lseg, difflen, allpred=p1)
+            ctx.wait(t2)
+            return self.gender(mspec, lseg, difflen, allpred=p2)
         lseg = self.vad(mspec, lseg, difflen, dense=dense)
         if self.detect_gender:
             lseg = self.gender(mspec, lseg, difflen, dense=dense)
         return lseg
+
+    def _pinned_out(self, k, n, c):
+        """Page-locked result arrays of the asynchronous dense path (grown on demand, one set per network)."""
+        cache = self.__dict__.setdefault('_pin_out', {})
+        cur = cache.get(k)
+        if cur is None or cur[0].shape[0] < n or cur[0].shape[1] != c:
+            if cur is not None:
+                self.ctx.pinned_free(cur[0]); self.ctx.pinned_free(cur[1])
+            cap = int(n * 1.1) + 64
+            cur = (self.ctx.pinned_empty((cap, c), np.float32), self.ctx.pinned_empty((cap,), np.uint8))
+            cache[k] = cur
+        return cur[0][:n], cur[1][:n]
 
     def segment_feats(self, mspec, loge, difflen, start_sec):
         """segmenter.py:250-276.  `mspec` may be a (T,24) array or the resident handle."""

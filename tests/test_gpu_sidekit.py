@@ -1,6 +1,7 @@
 """GPU parity: SIDEKIT front-end kernel (through the C ABI) vs the committed reference outputs
 and the oracle.  Tolerances: log-energy 2e-6 abs (float32 log differs by <= 1 ulp; partial sums
-are bit-identical), log-mel 1e-4 abs (float32 mel summation order differs from BLAS)."""
+are bit-identical), log-mel 2e-5 abs (float32 mel summation order differs from BLAS; measured 1.9e-6 on
+media/musanmix.wav, 90 % of the log-energies bit-identical)."""
 import os
 
 import numpy as np
@@ -12,7 +13,7 @@ from conftest import GOLDEN, read_wav_int16, synth_pcm
 pytestmark = pytest.mark.gpu
 
 LOGE_TOL = 2e-6
-MSPEC_TOL = 1e-4
+MSPEC_TOL = 2e-5
 
 
 def _run(ctx, sig):

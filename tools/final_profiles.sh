@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): the measurement set committed under profiles/ at the end of a round.
 #   gpurun --timeout 1500 -- 'bash tools/final_profiles.sh r01'
-R=${1:-r01}
+R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
@@ -17,7 +17,13 @@ python $ROOT/tools/pmc_summary.py $(find /tmp/p_w -name '*.db' | head -1) > $OUT
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace -d /tmp/p_s -o r -- $B > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py $(find /tmp/p_s -name '*.db' | head -1) > $OUT/pmc_sq.json
 python $ROOT/tools/pmc_report.py $OUT/pmc_fetch.json $OUT/pmc_write.json $OUT/pmc_sq.json $OUT/pmc_latest.json > $OUT/pmc_table.md
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM --kernel-trace -d /tmp/p_q1 -o r -- $B > /dev/null 2>&1
+python $ROOT/tools/pmc_summary.py $(find /tmp/p_q1 -name '*.db' | head -1) > $OUT/pmc_q1.json
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_VALU_MFMA_COEXEC_CYCLES SQ_IFETCH SQ_LDS_CMD_FIFO_FULL --kernel-trace -d /tmp/p_q2 -o r -- $B > /dev/null 2>&1
+python $ROOT/tools/pmc_summary.py $(find /tmp/p_q2 -name '*.db' | head -1) > $OUT/pmc_q2.json
 cd $ROOT
-python bench.py --workload vbx --no-cpu-baseline > $OUT/${R}_vbx_1h.json 2> $OUT/vbx.err
-python tools/batch_e2e.py > $OUT/${R}_batch_e2e.json 2> $OUT/e2e.err
-tail -c 600 $OUT/${R}_bench_final.json; echo; cat $OUT/pmc_table.md; tail -c 400 $OUT/${R}_vbx_1h.json; echo; cat $OUT/${R}_batch_e2e.json
+python bench.py --workload vbx > $OUT/${R}_vbx_1h.json 2> $OUT/vbx.err
+python bench.py --workload batch > $OUT/${R}_bench_batch.json 2> $OUT/batch.err
+python bench.py --workload archive > $OUT/${R}_bench_archive_1gpu.json 2> $OUT/archive.err
+python tests/topology_sweep.py --out $OUT/${R}_topology_sweep.json > $OUT/sweep.log 2>&1
+tail -c 600 $OUT/${R}_bench_final.json; echo; cat $OUT/pmc_table.md; tail -c 400 $OUT/${R}_vbx_1h.json; echo; tail -c 300 $OUT/${R}_bench_batch.json; tail -3 $OUT/sweep.log
