@@ -791,6 +791,12 @@ namespace {
 
 // Kernel shapes conv_x3_fp_kernel is instantiated for (the tap loop is unrolled at compile time);
 // other shapes run on conv_x3_kernel.
+// conv_x3_ws_kernel decomposes a flattened window pixel p < limit as p / W == (p * ceil(2^16 / W)) >> 16: exact iff
+// limit * (ceil(2^16 / W) * W - 2^16) < 2^16
+inline bool ws_recip_exact(int W, long long limit) {
+    const long long m = (65536 + W - 1) / W;
+    return limit * (m * W - 65536) < 65536 && limit * m < (1ll << 31);
+}
 inline bool ws_shape_compiled(int kh, int kw) {
 #define ISS_WS_HAS(KH_, KW_) if (kh == KH_ && kw == KW_) return true;
     ISS_WS_SHAPES(ISS_WS_HAS)
@@ -859,8 +865,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         if (R2[ISS_C_OP] != ISS_OP_CONV || R2[ISS_C_INMODE] != 0 || R2[ISS_C_IN] != R1[ISS_C_OUT] || R2[ISS_C_RES] >= 0) return false;
         if (R2[ISS_C_CIN] != R1[ISS_C_COUT] || R2[ISS_C_CIN] % XBK != 0 || R2[ISS_C_H] != R1[ISS_C_HO] || R2[ISS_C_W] != R1[ISS_C_WO]) return false;
         if (R2[ISS_C_KH] * R2[ISS_C_KW] < 8 || !fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW])) return false;   // (>= 12 unless the weight-stationary kernel takes it, see conv_row)
-        if (R2[ISS_C_PT] != 0 || R2[ISS_C_PL] != 0 || (R2[ISS_C_HO] - 1) * R2[ISS_C_SH] + R2[ISS_C_KH] > R2[ISS_C_H] ||
-            (R2[ISS_C_WO] - 1) * R2[ISS_C_SW] + R2[ISS_C_KW] > R2[ISS_C_W]) return false;
+        // (a zero-padded second conv is fused by the weight-stationary kernel only; conv_row decides)
         // the footprint may touch two windows at most, and the x / W trick of the kernel needs a small W
         if (R2[ISS_C_H] * R2[ISS_C_W] < FPIX + 32 || R2[ISS_C_W] > 128) return false;
         for (int q = r + 2; q < n.nrows; ++q) {                  // nobody else may read the first layer's output
@@ -930,7 +935,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         bool ws = false;
         static const bool no_ws = getenv("ISS_NO_WS") != nullptr;
         if (!no_ws && fp && pend >= 0 && a.H_k * a.kw >= 8 && a.H_k * a.kw <= WS_MAXNT && ws_shape_compiled(a.H_k, a.kw) &&
-            a.Cin % F2_CH == 0 && a.W <= 64 && a.H * a.W >= WS_PIX + 64) {
+            a.Cin % F2_CH == 0 && a.H * a.W >= WS_PIX + 64 + (a.pt_ + 1) * a.W && ws_recip_exact(a.W, a.H * a.W + WS_PIX + a.W)) {
             const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 62);
             auto it = n.fp_pix.find(key);
             if (it == n.fp_pix.end()) it = n.fp_pix.emplace(key, footprint_pixels(a, WS_TM)).first;
@@ -941,7 +946,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         bool fused = false;
         if (pend >= 0) {
             const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
-            fused = fp && !padded && (ws || a.H_k * a.kw >= 12) && d_winrow != nullptr &&
+            fused = fp && (ws || (!padded && a.H_k * a.kw >= 12)) && d_winrow != nullptr &&
                     ((long long)(rmax - rmin) + Rp[ISS_C_HO]) * Rp[ISS_C_WO] * Rp[ISS_C_COUT] < (1ll << 32);   // 32-bit offsets into R
         }
         if (!fused && (long long)bc * a.img_stride >= (1ll << 32)) fp = false;        // 32-bit offsets into the input batch

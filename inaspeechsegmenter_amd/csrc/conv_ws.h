@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
         int b, oy, ox;
         map_row32(ga, m0, b, oy, ox);
         u.p_lo = (b * ga.H + (oy * ga.sh - ga.pt_)) * ga.W + (ox * ga.sw - ga.pl_);
-        u.fy = oy * ga.sh; u.fx = ox * ga.sw; u.wb = b;
+        u.fy = oy * ga.sh - ga.pt_; u.fx = ox * ga.sw - ga.pl_; u.wb = b;     // (negative for the padding rows / pixels)
         const int ml = m0 + WS_TM - 1 < M - 1 ? m0 + WS_TM - 1 : M - 1;
         int b2, oy2, ox2;
         map_row32(ga, ml, b2, oy2, ox2);
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     unsigned dbmask = 0;
     float4 fsw = make_float4(0.f, 0.f, 0.f, 0.f), fbw = fsw;     // FUSED: weight sums / bias of this thread's 4 first-layer channels
     Win wx = {}, wpend = {};                         // windows of the footprint being built (settled) / of the one after it (pending)
-    const int magicW = (65536 + p.W - 1) / p.W;      // x / W == (x * magicW) >> 16 for x < 1024, W <= 64 (host-checked for FUSED)
+    const int magicW = (65536 + p.W - 1) / p.W;      // x / W == (x * magicW) >> 16 for x < 65536 / W (host-checked for FUSED)
     const unsigned cin4 = (unsigned)p.Cin * 4u, cg16 = (unsigned)cg * 16u;         // byte strides (32-bit offsets from a uniform base)
     auto fetch_block = [&](const TGeo& u, int c0) {  // all loads of one footprint chunk (FUSED: with wx = its windows' scalars)
         if (FUSED) {
@@ -199,10 +199,14 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
         for (int q = 0; q < WS_NFV; ++q) {
             const int qq = 128 * q < u.need ? q : 0; // unneeded slices re-load slice 0
             if (FUSED) {
-                int x = u.fx + prow + 128 * qq;
+                // pixel of the footprint inside its window, flattened (y * W + x).  With a zero-padded convolution the
+                // footprint starts up to pt rows / pl pixels BEFORE the window's first pixel: those positions are only ever
+                // read by masked taps (they fetch pixel 0 instead)
+                int x = u.fy * p.W + u.fx + prow + 128 * qq;
+                x = PADDED && x < 0 ? 0 : x;
                 const int dy = (x * magicW) >> 16;
                 x -= dy * p.W;
-                int y = u.fy + dy;
+                int y = dy;
                 const bool second = y >= p.H;
                 y -= second ? p.H : 0;
                 dbmask |= second ? 1u << q : 0u;
@@ -420,8 +424,9 @@ void launch_ws_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, 
 #define ISS_WS_LAUNCH(...) hipLaunchKernelGGL((conv_x3_ws_kernel<KH, KW, __VA_ARGS__>), grid, dim3(512), 0, st, a)
         // instantiated for the shared-first-layer convolution only (the dominant launch of the segmenter nets); the other
         // footprint layers stay on conv_x3_fp_kernel -- every instantiation costs minutes of compile time
-        (void)padded;
-        if (fused) { if (tr) ISS_WS_LAUNCH(false, true, true); else ISS_WS_LAUNCH(false, false, true); }
+        if (!fused) return;
+        if (padded) { if (tr) ISS_WS_LAUNCH(true, true, true); else ISS_WS_LAUNCH(true, false, true); }
+        else { if (tr) ISS_WS_LAUNCH(false, true, true); else ISS_WS_LAUNCH(false, false, true); }
 #undef ISS_WS_LAUNCH
     }
 }
