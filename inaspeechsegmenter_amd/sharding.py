@@ -6,8 +6,8 @@ because files are independent units (segmenter.py:314-327 loops over them with n
 Here: one process per GPU, files are dealt to ranks up front, every rank segments its own files,
 and ONE all-gather of a fixed-capacity int32 table collects all segment boundaries on every rank.
 On the GPU box the collective is `iss_allgather_segments` of the C-ABI (include/iss.h): ncclAllGather
-from librccl on the context's own stream -- no torch in that path (`RcclComm`; the 128-byte
-communicator id travels over a plain TCP socket, `rccl_rendezvous`).  `TorchComm` (torch.distributed,
+from librccl on the context's own stream -- no torch in the data path (`RcclComm`; the 128-byte
+communicator id travels through the launcher's key-value store or a plain TCP socket, `rccl_rendezvous`).  `TorchComm` (torch.distributed,
 "gloo") exists for the world_size-2 CPU tests and for callers that already run a process group.
 
 Segment table row = (file_id, label_id, start_slot, stop_slot) int32; times are slot * 0.02 s
@@ -102,14 +102,32 @@ class TorchComm:
         dist.barrier(self.group)
 
 
+_uid_round = [0]
+
+
 def exchange_unique_id(uid, rank, world, addr=None, port=None, timeout=120.0):
-    """Rank 0 hands `uid` (bytes) to the other ranks over TCP; returns the id on every rank.  addr / port default to
-    MASTER_ADDR (127.0.0.1) and ISS_RDV_PORT or MASTER_PORT + 1 (MASTER_PORT itself belongs to torchrun's store)."""
+    """Rank 0 hands `uid` (bytes) to the other ranks; returns the id on every rank.
+
+    Under `python -m torch.distributed.run` (TORCHELASTIC_USE_AGENT_STORE=True) the launcher's own key-value store at
+    MASTER_ADDR:MASTER_PORT carries it -- the channel the launcher provides for exactly this, no extra port.  Otherwise
+    (any other launcher that sets RANK / WORLD_SIZE) a plain TCP socket: addr / port default to MASTER_ADDR (127.0.0.1)
+    and ISS_RDV_PORT or MASTER_PORT + 1."""
     import os
     import socket
     import time
     if world == 1:
         return uid
+    if port is None and addr is None and os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '').lower() == 'true':
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        store = TCPStore(os.environ.get('MASTER_ADDR', '127.0.0.1'), int(os.environ['MASTER_PORT']), world, False,
+                         timedelta(seconds=timeout))
+        key = 'iss_rccl_unique_id_%d' % _uid_round[0]
+        _uid_round[0] += 1
+        if rank == 0:
+            store.set(key, bytes(uid))
+            return uid
+        return bytes(store.get(key))
     addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
     port = int(port or os.environ.get('ISS_RDV_PORT') or int(os.environ.get('MASTER_PORT', '29500')) + 1)
     if rank == 0:
@@ -136,7 +154,7 @@ def exchange_unique_id(uid, rank, world, addr=None, port=None, timeout=120.0):
             with socket.create_connection((addr, port), timeout=5.0) as conn:
                 conn.sendall(int(rank).to_bytes(4, 'little'))
                 buf = b''
-                while len(buf) < len(uid or b'\0' * 128):
+                while len(buf) < 128:
                     chunk = conn.recv(128 - len(buf))
                     if not chunk:
                         raise ConnectionError('rendezvous peer closed the connection')

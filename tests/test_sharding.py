@@ -129,3 +129,25 @@ def test_rccl_allgather_single_rank():
     comm.barrier()
     ctx.comm_destroy()
     ctx.close()
+
+
+def test_unique_id_exchange_through_the_launcher_store(tmp_path):
+    """Under `python -m torch.distributed.run` (how the driver starts the N-GPU bench) the communicator id travels through
+    the launcher's own key-value store: two ranks, two rounds."""
+    import subprocess
+    import sys
+    script = tmp_path / 'rdv.py'
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from inaspeechsegmenter_amd import sharding as sh
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+assert os.environ.get('TORCHELASTIC_USE_AGENT_STORE') == 'True'
+a = sh.exchange_unique_id(bytes(range(128)) if rank == 0 else None, rank, world)
+b = sh.exchange_unique_id(bytes(reversed(range(128))) if rank == 0 else None, rank, world)
+assert a == bytes(range(128)) and b == bytes(reversed(range(128)))
+print('rank', rank, 'ok')
+''')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(_free_port()), str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'rank 0 ok' in r.stdout and 'rank 1 ok' in r.stdout, r.stdout + r.stderr
