@@ -111,8 +111,9 @@ def segment_archive(segment_file, linput, loutput=None, output_format='csv', siz
 
 
 class JobList:
-    """The job-table half of the reference's Pyro job server (scripts/ina_speech_segmenter_pyro_server.py:34-68,
-    pinned by run_test.py:166-172) without the RPC layer: a CSV with columns `source_path, dest_path` is
+    """The job-table half of the reference's Pyro job server without the RPC layer -- deliberately a line-for-line mirror of
+    `GenderJobServer` (scripts/ina_speech_segmenter_pyro_server.py:33-66) minus its prints and the Pyro4 decorators, because
+    its behaviour IS the compatibility contract (pinned by the reference's own run_test.py:166-172 on media/pyroserver_test.csv): a CSV with columns `source_path, dest_path` is
     stripped, de-duplicated and shuffled, and handed out in chunks of `nbjobs` (20 by default).  On one node the
     chunks feed `segment_archive`; the Pyro daemon itself (network job dispatch) is out of scope."""
 

@@ -295,20 +295,25 @@ class Segmenter:
 
     def segment_slots(self, mspec, loge, difflen, dense=False):
         """The body of segmenter.py:250-275 in 20 ms slot units: [(label, start_slot, stop_slot)]."""
-        lseg = []
-        for lab, start, stop in _binidx2seglist(_energy_activity(loge, self.energy_ratio)[::2]):
-            lseg.append(('noEnergy' if lab == 0 else 'energy', start, stop))
+        pending = None
         if dense and self.detect_gender:
-            # both networks on every slot, independent of each other: enqueue them back to back (iss_cnn_probs_async) and
-            # run the VAD Viterbi on the host while the device evaluates the gender network (the reference overlaps host
-            # and device work across files, segmenter.py:377-387; within one file its gender pass needs the VAD result)
+            # both networks on every slot, independent of each other and of the energy detector: enqueue them back to back
+            # (iss_cnn_probs_async) BEFORE the host starts on the energy Viterbi, and smooth the VAD output while the device
+            # evaluates the gender network (the reference overlaps host and device work across files, segmenter.py:377-387;
+            # within one file its gender pass needs the VAD result)
             ctx = self.ctx
             rows = _window_rows(_ensure_resident(ctx, mspec), difflen)
             t1, p1, _ = ctx.cnn_probs_async(self.vad.net_id, rows, *self._pinned_out(0, len(rows), len(self.vad.outlabels)))
             t2, p2, _ = ctx.cnn_probs_async(self.gender.net_id, rows, *self._pinned_out(1, len(rows), len(self.gender.outlabels)))
-            ctx.wait(t1)
+            pending = (t1, p1, t2, p2)
+        lseg = []
+        for lab, start, stop in _binidx2seglist(_energy_activity(loge, self.energy_ratio)[::2]):
+            lseg.append(('noEnergy' if lab == 0 else 'energy', start, stop))
+        if pending is not None:
+            t1, p1, t2, p2 = pending
+            self.ctx.wait(t1)
             lseg = self.vad(mspec, lseg, difflen, allpred=p1)
-            ctx.wait(t2)
+            self.ctx.wait(t2)
             return self.gender(mspec, lseg, difflen, allpred=p2)
         lseg = self.vad(mspec, lseg, difflen, dense=dense)
         if self.detect_gender:

@@ -7,9 +7,9 @@ OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $ROOT/bench.py > $OUT/${R}_bench_final.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o r -- python $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>/dev/null
-python $ROOT/tools/rocprof_summary.py $(find /tmp/p_stats -name '*.db' | head -1) $OUT/${R}_bench_kernel_stats_final.md "python bench.py --no-cpu-baseline (default steps)" > /dev/null
-B="python $ROOT/bench.py --minutes 20 --steps 1 --warmup 0 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o r -- python $ROOT/bench.py --no-cpu-baseline --no-f32-companion > $OUT/bench_under_rocprof.json 2>/dev/null
+python $ROOT/tools/rocprof_summary.py $(find /tmp/p_stats -name '*.db' | head -1) $OUT/${R}_bench_kernel_stats_final.md "python bench.py --no-cpu-baseline --no-f32-companion (default steps)" > /dev/null
+B="python $ROOT/bench.py --minutes 20 --steps 1 --warmup 0 --no-cpu-baseline --no-f32-companion"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o r -- $B > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py $(find /tmp/p_f -name '*.db' | head -1) > $OUT/pmc_fetch.json
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o r -- $B > /dev/null 2>&1

@@ -32,7 +32,8 @@ def main():
                 d['wait_inst_frac'] = s.get('SQ_WAIT_INST_ANY', 0.0) / s['SQ_WAVE_CYCLES']
                 d['active_inst_frac'] = s.get('SQ_ACTIVE_INST_ANY', 0.0) / s['SQ_WAVE_CYCLES']
         per[k] = d
-    conv = [v for k, v in per.items() if k.startswith(('conv_x3', 'issk::conv_x3', 'conv1_patch', 'conv_igemm'))
+    # bf16x3 mode: the conv_x3* kernels (conv_igemm_kernel launches belong to the exact-f32 companion step of bench.py)
+    conv = [v for k, v in per.items() if k.startswith(('conv_x3', 'issk::conv_x3', 'conv1_patch'))
             and 'FETCH_SIZE_bytes' in v and 'WRITE_SIZE_bytes' in v]
     n = sum(v['launches'] for v in conv)
     traffic = sum(v['launches'] * (v['FETCH_SIZE_bytes'] + v['WRITE_SIZE_bytes']) for v in conv) / max(n, 1)
