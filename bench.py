@@ -216,7 +216,7 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
 
     def step():
         if kind == 'batch':
-            t, nb, avg, lmsg = seg.batch_process(lin, lout)
+            t, nb, avg, lmsg = seg.batch_process(lin, lout, batch_files=args.batch_files, workers=args.workers)
             assert nb == nfiles, [m for m in lmsg if m[1] != 0][:3]
             return nb
         table, lmsg = segment_archive(seg, lin, lout, sizes=sizes, comm=comm)
@@ -373,6 +373,8 @@ def main():
     ap.add_argument('--file-minutes', type=float, default=0.0, help='batch / archive: minutes per file (default 5 / 3)')
     ap.add_argument('--dir', default='/dev/shm/iss_bench', help='batch / archive: where the synthetic WAV files live')
     ap.add_argument('--no-f32-companion', action='store_true', help='skip the exact-f32 (ISS_PREC_F32) companion step')
+    ap.add_argument('--batch-files', type=int, default=32, help='batch / archive: files per device pass (super-batch)')
+    ap.add_argument('--workers', type=int, default=2, help='batch / archive: device contexts alternating super-batches')
     ap.add_argument('--workspace-mb', type=int, default=0, help='activation workspace cap (0 = library default)')
     ap.add_argument('--precision', choices=['bf16x3', 'f32'], default='bf16x3',
                     help='conv/dense GEMM arithmetic: split-bf16 MFMA (default) or exact-f32 MFMA')

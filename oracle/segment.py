@@ -5,6 +5,11 @@ cannot be imported here (the module pulls in tensorflow and skimage):
 _energy_activity 69-73, _get_patches 76-88, _binidx2seglist 91-108,
 DnnSegmenter.__call__ 135-179, Segmenter.segment_feats 250-276.
 The network itself is a callable `predict(batch(N,68,h,1) f32) -> (N,C) f32`.
+
+Pinned: tests/golden/ref_segmenter_pin.py executes the reference's own lines (ast-extracted, under the interpreter that
+has skimage) on the committed feature fixtures with a bit-reproducible stand-in predictor; make_golden.py and
+tests/test_oracle_golden.py assert that this file reproduces its patches bit for bit and its segments exactly
+(tests/golden/segmenter_pin.npz).
 """
 import numpy as np
 from numpy.lib.stride_tricks import sliding_window_view
