@@ -206,7 +206,15 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
     minutes = args.file_minutes or (5.0 if kind == 'batch' else 3.0)
     per_gpu = args.files_per_gpu or 128
     nfiles = per_gpu * world
-    root = os.path.join(args.dir, f'{kind}_{minutes:g}min')
+    try:
+        os.makedirs(args.dir, exist_ok=True)
+        base = args.dir if os.access(args.dir, os.W_OK) else None
+    except OSError:
+        base = None
+    if base is None:                                 # no writable /dev/shm: any local directory will do (page cache)
+        import tempfile
+        base = os.path.join(tempfile.gettempdir(), 'iss_bench')
+    root = os.path.join(base, f'{kind}_{minutes:g}min')
     mine = [i for i in range(nfiles) if i % world == rank]           # = sharding.shard_files for equal sizes
     paths, n = make_files(mine, minutes, dev, root)
     lin = [os.path.join(root, f'f{i:06d}.wav') for i in range(nfiles)]
