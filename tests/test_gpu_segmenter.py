@@ -163,3 +163,52 @@ def test_device_resident_pcm_entry_equals_host_path(seg):
     assert [(l, a * .02, b * .02) for l, a, b in slots_ref] == host
     with pytest.raises(ValueError):
         seg.segment_device_pcm(t.data_ptr(), 400 + 160 * 60)          # < 68 frames: use segment_signal
+
+
+def _wav(path, data, fmt_tag=1, bits=16):
+    import struct
+    raw = data.tobytes()
+    with open(path, 'wb') as f:
+        f.write(b'RIFF' + struct.pack('<I', 36 + len(raw)) + b'WAVEfmt ' +
+                struct.pack('<IHHIIHH', 16, fmt_tag, 1, 16000, 16000 * bits // 8, bits // 8, bits) + b'data' + struct.pack('<I', len(raw)) + raw)
+
+
+def test_pipeline_mixed_batch_equals_single_calls(seg, tmp_path):
+    """The super-batch path of pipeline.process_files: files of very different lengths (none a multiple of 160 samples)
+    packed into one device pass, several passes per call (batch_files=3), a 0.5 s file (< 68 frames: single-file path with
+    the mel padding of segmenter.py:61-65), a float32 WAV (single-file path), silence, an undecodable and a missing file --
+    every CSV byte-identical to the per-file call, errors reported per file, with one and with two device workers."""
+    specs = [('a', synth_pcm(11, 16000 * 31 + 77)), ('b', synth_pcm(12, 16000 * 7 + 3)), ('short', synth_pcm(13, 16000)[4000:12000]),
+             ('c', synth_pcm(14, 16000 * 95 + 159)), ('sil', np.zeros(16000 * 4 + 5, np.int16)), ('d', synth_pcm(15, 16000 * 12 + 1)),
+             ('e', synth_pcm(16, 16000 * 3 + 80))]
+    lin = []
+    for name, pcm in specs:
+        _wav(tmp_path / f'{name}.wav', pcm)
+        lin.append(str(tmp_path / f'{name}.wav'))
+    fl = (synth_pcm(17, 16000 * 9 + 41) / 32768.0).astype('<f4')
+    _wav(tmp_path / 'float.wav', fl, fmt_tag=3, bits=32)
+    lin.insert(3, str(tmp_path / 'float.wav'))
+    (tmp_path / 'junk.wav').write_bytes(b'not a wav file at all')
+    lin.insert(5, str(tmp_path / 'junk.wav'))
+    lin.append(str(tmp_path / 'missing.wav'))
+    for workers in (1, 2):
+        lout = [str(tmp_path / f'out{workers}' / (os.path.basename(p)[:-4] + '.csv')) for p in lin]
+        t, nb, avg, lmsg = seg.batch_process(lin, lout, batch_files=3, workers=workers)
+        codes = [m[1] for m in lmsg]
+        assert [m[0] for m in lmsg] == lout                                   # input order
+        assert codes == [0, 0, 0, 0, 0, 2, 0, 0, 0, 2] and nb == 8, lmsg
+        assert all(m[2].startswith('error: ') for m in lmsg if m[1] == 2)
+        for src, dst, code in zip(lin, lout, codes):
+            if code == 0:
+                ref = str(tmp_path / 'ref.csv')
+                with __import__('warnings').catch_warnings():
+                    __import__('warnings').simplefilter('ignore')
+                    seg2csv(seg(src), ref)
+                assert filecmp.cmp(dst, ref, shallow=False), (workers, src)
+    # and the archive driver on the same list (single process: the table holds every good file)
+    from inaspeechsegmenter_amd import archive
+    table, lmsg = archive.segment_archive(seg, lin, None)
+    assert sorted(table) == [0, 1, 2, 3, 4, 6, 7, 8] and [m[1] for m in lmsg] == codes
+    with __import__('warnings').catch_warnings():
+        __import__('warnings').simplefilter('ignore')
+        assert table[2] == seg(lin[2]) and table[6] == seg(lin[6])
