@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libiss_hip.so')
+LIB_PATH = os.environ.get('ISS_LIB') or os.path.join(_HERE, 'libiss_hip.so')      # ISS_LIB: another build of the library (A/B runs)
 
 PROG_COLS = 32
 OP_CONV, OP_POOL, OP_SOFTMAX, OP_STATPOOL = 1, 2, 3, 4

@@ -359,7 +359,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                     const AFr& ac = a[v & 1];
                     const BFr& bc = b[v & 1];
                     // (measured: all six reads in front of the six MFMAs -- one s_waitcnt per step -- is 8 % SLOWER than
-                    // spreading them between the pairs: 44 % vs 50 % matrix-pipe occupancy)
+                    // spreading them between the pairs: 44 % vs 50 % matrix-pipe occupancy; s_setprio 3 around the MFMA pairs, which
+                    // pays in conv_x3_fp_kernel, costs 1.5-2 % here -- same-box A/B through ISS_LIB)
                     __builtin_amdgcn_sched_barrier(0);
                     mfma2(0, ac, bc, c0acc, c1acc);
                     __builtin_amdgcn_sched_barrier(0);
