@@ -55,14 +55,14 @@ struct EpiArgs {
 };
 
 
-constexpr int WS_TM = 256;                         // GEMM rows per tile: 8 waves x 32
-constexpr int WS_G = 4;                            // tiles per group
-constexpr int WS_PIX = 512;                        // footprint capacity in pixels (host-validated per launch)
+constexpr int WS_TM = 512;                         // GEMM rows per tile: 8 waves x 64 (two 32-row blocks per wave)
+constexpr int WS_G = 2;                            // tiles per group
+constexpr int WS_PIX = 896;                        // footprint capacity in pixels (host-validated per launch)
 constexpr int WS_ZERO = WS_PIX * F2_ROW;           // byte offset of the all-zero pixel behind a footprint
-constexpr int WS_BUF = (WS_PIX + 1) * F2_ROW;      // bytes of one footprint buffer (41 040)
-constexpr int WS_NFV = WS_PIX / 128;               // 128-pixel slices per footprint (4): 512 threads x 4 channels each
+constexpr int WS_BUF = (WS_PIX + 1) * F2_ROW;      // bytes of the footprint buffer (71 760)
+constexpr int WS_NFV = WS_PIX / 128;               // 128-pixel slices per footprint (7): 512 threads x 4 channels each
 constexpr int WS_MAXNT = 16;                       // taps: NT x 4 KB of weights + two footprints must fit 160 KB of LDS
-constexpr int ws_lds_bytes(int nt) { return 2 * WS_BUF + nt * F2_BST; }
+constexpr int ws_lds_bytes(int nt) { return WS_BUF + nt * F2_BST; }
 
 template <int KH, int KW, bool PADDED, bool TR, bool FUSED>
 __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
@@ -112,9 +112,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
         u.need = (b2 * ga.H + (oy2 * ga.sh - ga.pt_ + KH - 1)) * ga.W + (ox2 * ga.sw - ga.pl_ + KW - 1) - u.p_lo + 1;
         return u;
     };
-    auto geo_lane = [&](const GeoArgs& ga, int tile, const TGeo& u, int& lanepix, unsigned& vmask) {   // lanepix: see read_a (lpb)
+    auto geo_lane = [&](const GeoArgs& ga, int tile, int rb, const TGeo& u, int& lanepix, unsigned& vmask) {   // lanepix: see read_a
         const int m0 = clamp_tile(tile) * WS_TM;
-        const int m = m0 + wv * 32 + li;
+        const int m = m0 + (wv * 2 + rb) * 32 + li;
         int b, oy, ox;
         map_row32(ga, m < M ? m : m0, b, oy, ox);
         const int iy0 = oy * ga.sh - ga.pt_, ix0 = ox * ga.sw - ga.pl_;
@@ -231,9 +231,14 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { t0[i] = fmaf(sw[i], mr0, bw[i]); t1[i] = fmaf(sw[i], mr1, bw[i]); }
     };
-    auto convert_slice = [&](int q, int buf) {       // q, buf: compile-time
+    // The next footprint is converted BEHIND the MFMAs of the current block but kept in registers (bf16 hi / lo of the
+    // thread's 4 channels: 2 + 2 VGPRs per slice, taking over the 4 registers of the slice's f32 values); it is written into
+    // the (single) LDS footprint at the block boundary, between two barriers.  Two footprints of 896 pixels would not fit
+    // beside the resident weights.
+    bf16x4 cvh[WS_NFV], cvl[WS_NFV];
+    auto convert_slice = [&](int q) {                // q: compile-time
         float4 v = fv[q];
-        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(dbmask));    // not before this point: hipcc would hoist the conversion right behind the loads, i.e. an s_waitcnt for fresh loads in front of the MFMAs the loads hide behind
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(dbmask));    // not before this point (see fetch_block)
         if (FUSED) {
             const bool second = (dbmask >> q) & 1u;
             const float sc = second ? rs1 : rs0;
@@ -241,16 +246,20 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                             fmaf(v.z, sc, second ? t1[2] : t0[2]), fmaf(v.w, sc, second ? t1[3] : t0[3]));
             v.x = fmaxf(v.x, f_lob); v.y = fmaxf(v.y, f_lob); v.z = fmaxf(v.z, f_lob); v.w = fmaxf(v.w, f_lob);
         }
-        bf16x4 h, l;
-        split4(v, h, l);
-        const unsigned dst = sF_base + (unsigned)(buf * WS_BUF + (prow + 128 * q) * F2_ROW + cg * 8);
-        *(LdsW8)(dst) = h;
-        *(LdsW8)(dst + 32) = l;
+        split4(v, cvh[q], cvl[q]);
+    };
+    auto write_footprint = [&]() {
+#pragma unroll
+        for (int q = 0; q < WS_NFV; ++q) {
+            const unsigned dst = sF_base + (unsigned)((prow + 128 * q) * F2_ROW + cg * 8);
+            *(LdsW8)(dst) = cvh[q];
+            *(LdsW8)(dst + 32) = cvl[q];
+        }
     };
 
     // ---- fragments
     struct AFr { bf16x8 h, l; };
-    struct BFr { bf16x8 b0h, b0l, b1h, b1l; };
+    struct BH { bf16x8 b0, b1; };                    // hi (or lo) fragments of the two 32-column blocks
     // lpb: lane base of a tile = sF_base + lanepix * 80 + lh * 16 (per tile, kept in one register); the tap offset
     // (ky * W + kx) * 80 is wave-uniform and added per step.  The opaque copy keeps hipcc from materialising all KH * KW
     // addresses of a tile at once (15 address registers per tile drove the first build of this kernel into scratch).
@@ -258,58 +267,62 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     const unsigned row_step = (unsigned)((p.W - (KW - 1)) * F2_ROW);    // from the last tap of a filter row to the first of the next
     // `cur` walks the taps: + 80 bytes within a filter row, + row_step at the end of one (a loop-carried value, so hipcc
     // cannot materialise all KH * KW addresses of a tile at once)
-    auto read_a = [&](AFr& f, unsigned cur, unsigned vmask, int buf, int tap) {          // buf, tap: compile-time
+    auto read_a = [&](AFr& f, unsigned cur, unsigned vmask, int tap) {                   // tap: compile-time
         unsigned a = cur;
         if (PADDED) a = (vmask >> tap) & 1u ? a : zbase;
-        f.h = *(LdsR16)(a + (unsigned)(buf * WS_BUF));
-        f.l = *(LdsR16)(a + (unsigned)(buf * WS_BUF + 32));
+        f.h = *(LdsR16)(a);
+        f.l = *(LdsR16)(a + 32);
     };
     auto next_tap = [&](unsigned cur, int tap) {     // address of tap + 1
         asm volatile("" : "+v"(cur));
         return cur + ((tap + 1) % KW == 0 ? row_step : (unsigned)F2_ROW);
     };
-    auto read_b = [&](BFr& f, int tap) {
+    auto read_bh = [&](BH& f, int tap) {             // hi plane of the tap's weight tile
         const unsigned a = bread + (unsigned)(tap * F2_BST);
-        f.b0h = *(LdsR16)(a);
-        f.b1h = *(LdsR16)(a + 1024);
-        f.b0l = *(LdsR16)(a + 2048);
-        f.b1l = *(LdsR16)(a + 3072);
+        f.b0 = *(LdsR16)(a);
+        f.b1 = *(LdsR16)(a + 1024);
     };
-    // the six MFMAs of a step as three pairs (the two accumulators alternate): a.l * b.h, a.h * b.l, a.h * b.h
-    auto mfma2 = [&](int k, const AFr& a, const BFr& b, floatx16& c0, floatx16& c1) {       // k: compile-time
-        const bf16x8& av = k == 0 ? a.l : a.h;
-        const bf16x8& b0 = k == 1 ? b.b0l : b.b0h;
-        const bf16x8& b1 = k == 1 ? b.b1l : b.b1h;
+    auto read_bl = [&](BH& f, int tap) {             // lo plane
+        const unsigned a = bread + (unsigned)(tap * F2_BST);
+        f.b0 = *(LdsR16)(a + 2048);
+        f.b1 = *(LdsR16)(a + 3072);
+    };
+    // one MFMA pair: A vector x the two column blocks of a weight plane, into the two accumulators of a row block
+    auto mfma2 = [&](const bf16x8& av, const BH& b, floatx16& c0, floatx16& c1) {
         if (TR) {                                        // C^T: rows = channels, columns = pixels (epilogue_tr)
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, av, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, av, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.b0, av, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.b1, av, c1, 0, 0, 0);
         } else {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b.b0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b.b1, c1, 0, 0, 0);
         }
     };
 
     // accumulators of the group's four tiles: named variables, not an array (an array that is passed by reference into the
     // pooled epilogue ended up in scratch memory)
-    static_assert(WS_G == 4, "");
-    floatx16 acc00, acc01, acc10, acc11, acc20, acc21, acc30, acc31;
+    static_assert(WS_G == 2, "");
+    floatx16 acc000, acc001, acc010, acc011, acc100, acc101, acc110, acc111;      // acc<tile><row block><column block>
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc00[i] = 0.f; acc01[i] = 0.f; acc10[i] = 0.f; acc11[i] = 0.f; acc20[i] = 0.f; acc21[i] = 0.f; acc30[i] = 0.f; acc31[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { acc000[i] = 0.f; acc001[i] = 0.f; acc010[i] = 0.f; acc011[i] = 0.f; acc100[i] = 0.f; acc101[i] = 0.f; acc110[i] = 0.f; acc111[i] = 0.f; }
 
     // conversion schedule inside a block of NT steps: loads at step 0, constants at step CS - 1, slice q at step CS + q * CSTRIDE
-    constexpr int CS = NT >= 12 ? 7 : 4;
-    constexpr int CSTRIDE = (NT - 1 - CS) / WS_NFV >= 1 ? (NT - 1 - CS) / WS_NFV : 1;
+    constexpr int CS = NT >= 12 ? 7 : 2;
+    constexpr int CSTRIDE = (NT - CS) / WS_NFV >= 1 ? (NT - CS) / WS_NFV : 1;
     static_assert(CS + (WS_NFV - 1) * CSTRIDE <= NT - 1, "");
 
     // ---- prologue: zero pixels; geometry of the first group; its first footprint converted serially
-    if (tid < 2 * (F2_ROW / 4)) *(LdsW4)(sF_base + (unsigned)((tid / (F2_ROW / 4)) * WS_BUF + WS_ZERO + (tid % (F2_ROW / 4)) * 4)) = 0u;
+    if (tid < F2_ROW / 4) *(LdsW4)(sF_base + (unsigned)(WS_ZERO + tid * 4)) = 0u;
     TGeo ug[WS_G + 2];                               // the group's tiles + the next group's first two tiles
-    int lanepix[WS_G];
-    unsigned vmask[WS_G];
+    int lanepix[WS_G][2];
+    unsigned vmask[WS_G][2];
     auto group_geometry = [&](int g0) {
         const GeoArgs ga = geo_args();
 #pragma unroll
-        for (int t = 0; t < WS_G; ++t) { ug[t] = geo_uniform(ga, g0 * WS_G + t); geo_lane(ga, g0 * WS_G + t, ug[t], lanepix[t], vmask[t]); }
+        for (int t = 0; t < WS_G; ++t) {
+            ug[t] = geo_uniform(ga, g0 * WS_G + t);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) geo_lane(ga, g0 * WS_G + t, rb, ug[t], lanepix[t][rb], vmask[t][rb]);
+        }
     };
     group_geometry(grp);
     ug[WS_G] = ug[0]; ug[WS_G + 1] = ug[1];
@@ -317,7 +330,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     fetch_block(ug[0], 0);
     conv_consts();
 #pragma unroll
-    for (int q = 0; q < WS_NFV; ++q) convert_slice(q, 0);
+    for (int q = 0; q < WS_NFV; ++q) convert_slice(q);
+    write_footprint();
 
     const int nchunk = p.Cin / F2_CH;
     const int gstep = (int)gridDim.x;
@@ -339,54 +353,58 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
             wait_vmcnt<0>();
             __syncthreads();
             // one block = one tile x one chunk: t and the accumulators are compile-time constants after inlining
-            auto run_block = [&](const int t, floatx16& c0acc, floatx16& c1acc) __attribute__((always_inline)) {
+            auto run_block = [&](const int t, floatx16& c00, floatx16& c01, floatx16& c10, floatx16& c11) __attribute__((always_inline)) {
                 // the footprint this block builds (for the block after it) and the one after that (whose windows it loads)
                 const TGeo un = t + 1 < WS_G ? ug[t + 1] : (last_chunk ? ug[WS_G] : ug[0]);
                 const TGeo un2 = t + 2 < WS_G ? ug[t + 2] : (last_chunk ? ug[t + 2] : ug[t + 2 - WS_G]);
                 const int nc0 = t + 1 < WS_G ? c0 : (last_chunk ? 0 : c0 + F2_CH);
-                const int buf = t & 1, nbuf = (t + 1) & 1;
-                // Fragments are double-buffered by hand and the order is PINNED (sched_barrier): left alone, hipcc sinks every
-                // ds_read to just in front of its MFMA to save registers, and the waves then sit in s_waitcnt lgkmcnt for
-                // half of their cycles (rocprofv3: 48 % of the wave cycles parked).  Per step: the reads of step v + 1 and the
-                // conversion work are spread between the three MFMA pairs of step v.
-                AFr a[2];
-                BFr b[2];
-                unsigned cur = (unsigned)lanepix[t];
-                read_a(a[0], cur, vmask[t], buf, 0);
-                read_b(b[0], 0);
+                // Per step: 12 MFMAs on two row blocks x two column blocks, in three groups ordered a.l * b.h, a.h * b.h,
+                // a.h * b.l, and 8 fragment reads: the A fragments of step v + 1 (double-buffered) behind the first group, its
+                // hi weights behind the second (the hi registers are free by then), its lo weights behind the third.  The order
+                // is PINNED (sched_barrier): left alone, hipcc sinks every ds_read to just in front of its MFMA.
+                AFr a[2][2];
+                BH bh, bl;
+                unsigned cur[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) { cur[rb] = (unsigned)lanepix[t][rb]; read_a(a[0][rb], cur[rb], vmask[t][rb], 0); }
+                read_bh(bh, 0);
+                read_bl(bl, 0);
 #pragma unroll
                 for (int v = 0; v < NT; ++v) {
-                    const AFr& ac = a[v & 1];
-                    const BFr& bc = b[v & 1];
-                    // (measured: all six reads in front of the six MFMAs -- one s_waitcnt per step -- is 8 % SLOWER than
-                    // spreading them between the pairs: 44 % vs 50 % matrix-pipe occupancy; s_setprio 3 around the MFMA pairs, which
-                    // pays in conv_x3_fp_kernel, costs 1.5-2 % here -- same-box A/B through ISS_LIB)
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma2(0, ac, bc, c0acc, c1acc);
+                    mfma2(a[v & 1][0].l, bh, c00, c01);
+                    mfma2(a[v & 1][1].l, bh, c10, c11);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (v + 1 < NT) { cur = next_tap(cur, v); read_a(a[(v + 1) & 1], cur, vmask[t], buf, v + 1); }
+                    if (v + 1 < NT) {
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) { cur[rb] = next_tap(cur[rb], v); read_a(a[(v + 1) & 1][rb], cur[rb], vmask[t][rb], v + 1); }
+                    }
                     if (v == 0) {
                         if (FUSED) { wx = settle(wpend); wpend = windows_of(un2.wb); }
                         fetch_block(un, nc0);
                     }
                     if (v == CS - 1) conv_consts();
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma2(1, ac, bc, c0acc, c1acc);
+                    mfma2(a[v & 1][0].h, bh, c00, c01);
+                    mfma2(a[v & 1][1].h, bh, c10, c11);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (v + 1 < NT) read_b(b[(v + 1) & 1], v + 1);
+                    if (v + 1 < NT) read_bh(bh, v + 1);
 #pragma unroll
                     for (int q = 0; q < WS_NFV; ++q)
-                        if (v == CS + q * CSTRIDE) convert_slice(q, nbuf);
+                        if (v == CS + q * CSTRIDE) convert_slice(q);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma2(2, ac, bc, c0acc, c1acc);
+                    mfma2(a[v & 1][0].h, bl, c00, c01);
+                    mfma2(a[v & 1][1].h, bl, c10, c11);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (v + 1 < NT) read_bl(bl, v + 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                     // every wave has read its last fragments of this footprint
+                write_footprint();
                 __syncthreads();
             };
-            run_block(0, acc00, acc01);
-            run_block(1, acc10, acc11);
-            run_block(2, acc20, acc21);
-            run_block(3, acc30, acc31);
+            run_block(0, acc000, acc001, acc010, acc011);
+            run_block(1, acc100, acc101, acc110, acc111);
         }
         // ---- group complete: epilogue parameters through the kernel-argument pointer
         {
@@ -395,22 +413,21 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
             EpiArgs e;
             e.bias = q->bias; e.ps = q->ps; e.pt = q->pt; e.res = q->res; e.out = q->out;
             e.M = q->M; e.Cout = q->Cout; e.act = q->act; e.pp = q->pp; e.poolkind = q->poolkind;
-            auto finish = [&](const int t, floatx16& c0acc, floatx16& c1acc) __attribute__((always_inline)) {
+            auto finish = [&](const int t, const int rb, floatx16& c0acc, floatx16& c1acc) __attribute__((always_inline)) {
                 const int tile = grp * WS_G + t;
+                const long long row0 = (long long)tile * WS_TM + (wv * 2 + rb) * 32;
                 if (tile < ntiles) {
-                    if (TR) epilogue_tr(e, c0acc, c1acc, (long long)tile * WS_TM + wv * 32 + li, n0, lh);
+                    if (TR) epilogue_tr(e, c0acc, c1acc, row0 + li, n0, lh);
                     else {
-                        epilogue_tile(e, c0acc, (long long)tile * WS_TM + wv * 32, n0 + li, lh);
-                        epilogue_tile(e, c1acc, (long long)tile * WS_TM + wv * 32, n0 + 32 + li, lh);
+                        epilogue_tile(e, c0acc, row0, n0 + li, lh);
+                        epilogue_tile(e, c1acc, row0, n0 + 32 + li, lh);
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { c0acc[i] = 0.f; c1acc[i] = 0.f; }
             };
-            finish(0, acc00, acc01);
-            finish(1, acc10, acc11);
-            finish(2, acc20, acc21);
-            finish(3, acc30, acc31);
+            finish(0, 0, acc000, acc001); finish(0, 1, acc010, acc011);
+            finish(1, 0, acc100, acc101); finish(1, 1, acc110, acc111);
         }
         if (!last_group) {
             group_geometry(grp + gstep);
