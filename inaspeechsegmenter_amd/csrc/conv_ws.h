@@ -248,12 +248,16 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
         }
         split4(v, cvh[q], cvl[q]);
     };
+    const unsigned fwrite = sF_base + (unsigned)(prow * F2_ROW + cg * 8);
     auto write_footprint = [&]() {
+        unsigned b = fwrite;
+        asm volatile("" : "+v"(b));                  // opaque base: one address register, the slices are immediates (< 64 KB)
+        const LdsW8 pb = (LdsW8)(b);
+        static_assert((WS_NFV - 1) * 128 * F2_ROW + 32 < 65536, "");
 #pragma unroll
         for (int q = 0; q < WS_NFV; ++q) {
-            const unsigned dst = sF_base + (unsigned)((prow + 128 * q) * F2_ROW + cg * 8);
-            *(LdsW8)(dst) = cvh[q];
-            *(LdsW8)(dst + 32) = cvl[q];
+            pb[q * (128 * F2_ROW / 8)] = cvh[q];
+            pb[q * (128 * F2_ROW / 8) + 4] = cvl[q];
         }
     };
 
