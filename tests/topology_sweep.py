@@ -43,7 +43,7 @@ def main():
         for net, (layers, shp) in sorted(TP.nets(name).items()):
             comp = KM.compile_layers(layers, shp)
             ctx.cnn_load(5, comp)
-            ctx.cnn_probs(5, rows[:20000])                              # warm up (allocations, code objects)
+            ctx.cnn_probs(5, rows)                                      # warm up at full size (code objects, workspace growth)
             ctx.synchronize()
             t0 = time.perf_counter()
             probs, fin = ctx.cnn_probs(5, rows)
