@@ -248,8 +248,34 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
     dt = time.perf_counter() - t0
     if comm:
         dt = comm.max_over_ranks(dt)
+    # roofline of the conv/dense GEMM launches, live: HIP events on the library's streams around every launch of ONE extra
+    # step (all ranks run it -- the step holds the collective; rank 0's device contexts are read)
+    ctxs = [w.ctx for w in seg.__dict__.get('_pipeline_workers', [])] or [seg.ctx]
+    for c in ctxs:
+        c.prof_enable(True)
+        c.prof_reset()
+    step()
+    conv_ms = conv_fl = 0.0
+    conv_n = 0
+    for c in ctxs:
+        ms, nl, fl = c.prof_get(0)
+        conv_ms += ms; conv_n += nl; conv_fl += fl
+        c.prof_enable(False)
     if rank == 0:
         value = args.steps * hours / dt
+        peak_tf = MFMA_BF16_PEAK_TF if x3 else MFMA_F32_PEAK_TF
+        step_s = dt / args.steps
+        ach = conv_fl / step_s / 1e12                # whole-step figure: the two device contexts' launches overlap on the GPU,
+        ach_ev = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0     # so per-launch event durations are stretched
+        roofline = {"bound": "mfma", "kernel": "conv/dense implicit-GEMM launches of rank 0's device contexts (see the segmenter workload's line)",
+                    "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf, "traffic": None,
+                    "launches_per_step": conv_n, "flops_per_launch": conv_fl / max(conv_n, 1),
+                    "event_based": {"achieved": ach_ev, "frac": ach_ev / peak_tf, "kernel_ms_per_step": conv_ms,
+                                    "avg_launch_ms": conv_ms / max(conv_n, 1)},
+                    "note": "achieved = algorithmic flops of rank 0's GEMM launches in one step / the step's WALL time (decode, copies, "
+                            "host Viterbi and export included): launches of the two device contexts run concurrently, so the sum of "
+                            "their HIP-event durations (event_based) counts shared time twice; the segmenter workload's line has the "
+                            "kernel-only figure.  Reference semantics: VAD net on energy slots, gender net on speech slots"}
         line = {
             "metric": "hours-of-audio segmented/sec (smn+gender, 16 kHz mono)",
             "value": value, "unit": "hours-of-audio/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
@@ -267,6 +293,7 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
                        "weights": "seeded stand-ins, (68,21,1)->3 and (68,24,1)->2, ~1.25 M params each (real Keras files are un-vendored release assets)",
                        "parallelism": (f"file-parallel x{world}: files dealt by size (LPT), no data-path collective, ONE ncclAllGather of int32 segment "
                                        "tables per step through the C-ABI (iss_allgather_segments)") if world > 1 else "single GPU"},
+            "roofline": roofline,
         }
         print(json.dumps(line))
     barrier()
