@@ -216,7 +216,22 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
         base = os.path.join(tempfile.gettempdir(), 'iss_bench')
     root = os.path.join(base, f'{kind}_{minutes:g}min')
     mine = [i for i in range(nfiles) if i % world == rank]           # = sharding.shard_files for equal sizes
-    paths, n = make_files(mine, minutes, dev, root)
+    try:
+        paths, n = make_files(mine, minutes, dev, root)
+    except OSError as exc:                           # e.g. a /dev/shm too small for this rank's share: use the local disk
+        import shutil
+        import tempfile
+        shutil.rmtree(root, ignore_errors=True) if world == 1 else None
+        for i in mine:
+            try:
+                os.remove(os.path.join(root, f'f{i:06d}.wav'))
+            except OSError:
+                pass
+        print(f'[bench] {root}: {exc}; falling back to {tempfile.gettempdir()}', file=sys.stderr)
+        root = os.path.join(tempfile.gettempdir(), 'iss_bench', f'{kind}_{minutes:g}min')
+        paths, n = make_files(mine, minutes, dev, root)
+    if comm:
+        comm.barrier()                               # every rank's files exist before anybody's first step
     lin = [os.path.join(root, f'f{i:06d}.wav') for i in range(nfiles)]
     lout = [os.path.join(root, f'out_r{rank}', f'f{i:06d}.csv') for i in range(nfiles)]
     sizes = [44 + 2 * n] * nfiles

@@ -995,7 +995,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             static const bool no_nh2 = getenv("ISS_NO_NH2") != nullptr;
             const int nh = (!fused && !no_nh2 && issk::iss_fp_has_nh2(a.H_k, a.kw) && a.Cout % (2 * BN) == 0) ? 2 : 1;
             const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y / nh);     // persistent: 2 workgroups per CU
-            const bool tr = a.pp == 1 && a.Cout % 4 == 0;                   // float4 epilogue on transposed accumulators
+            static const bool no_tr = getenv("ISS_NO_TR") != nullptr;       // diagnostic: row-major epilogue everywhere
+            const bool tr = !no_tr && a.pp == 1 && a.Cout % 4 == 0;         // float4 epilogue on transposed accumulators
             ISS_FP_SHAPES(ISS_FP_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no footprint kernel for %dx%d", a.H_k, a.kw); }
 #undef ISS_FP_CASE
         } else if (x3 && patch && a.H_k * a.kw <= XBK && a.M < (1ll << 31)) {
