@@ -62,7 +62,7 @@ struct iss_ctx {
 
     // CNN engine
     IssNet nets[ISS_MAX_NETS];
-    uint64_t ws_limit = 6ull << 30;
+    uint64_t ws_limit = 12ull << 30;
     int precision = ISS_PREC_BF16X3;
     std::vector<DevBuf> act;              // activation buffers (grown on demand)
     DevBuf d_winrow, d_stats, d_finite, d_out, d_in;
