@@ -18,7 +18,6 @@ Two device workers with a context each (own stream, own workspace) alternate sup
 phases (Viterbi, bookkeeping) the other's kernels run.  Results are identical to per-file processing: every frame and
 every 20 ms slot is computed from the same samples by the same kernels (tests/test_gpu_segmenter.py).
 """
-import os
 import queue
 import sys
 import threading

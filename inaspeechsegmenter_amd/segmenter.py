@@ -14,13 +14,9 @@ The 68-frame patches of `_get_patches` (segmenter.py:76-88) are never materialis
 host only builds the int32 list "first mel row of the window feeding slot i".
 """
 import os
-import sys
 import time
-import random
 import shutil
 import warnings
-import threading
-import queue
 
 import numpy as np
 
