@@ -58,6 +58,10 @@ def run(comp, x):
             out = y[:, :, :ho, :wo].permute(0, 2, 3, 1)
         elif op == N.OP_SOFTMAX:
             out = torch.softmax(src, dim=-1)
+        elif op == N.OP_STATPOOL:                    # mean || std over W (time) per (h, c), torch's (c, h) flatten order
+            mean = src.mean(dim=2)                   # (N, H, C)
+            std = torch.sqrt((src * src).mean(dim=2) - mean * mean + 1e-10)
+            out = torch.cat((mean.permute(0, 2, 1).reshape(len(src), -1), std.permute(0, 2, 1).reshape(len(src), -1)), 1)
         else:
             raise NotImplementedError(op)
         bufs[int(R[N.C_OUT])] = out.contiguous()

@@ -36,3 +36,17 @@ def test_channel_padding_is_transparent():
     x = np.random.default_rng(0).normal(0, 1, (2,) + shp).astype(np.float32)
     assert np.abs(prog_interp.run(a, x) - prog_interp.run(b, x)).max() < 1e-12
     assert a.flops_per_sample == b.flops_per_sample and a.out_dim == b.out_dim == 3
+
+
+def test_resnet101_lowering_equals_oracle():
+    """keras_model.compile_resnet101 (BatchNorm folding, residual wiring with in-place adds, stride-2 shortcuts, statistics
+    pooling order, embedding layer) executed on CPU against the torch restatement of resnet.py:115-130 (oracle/vbx.py)."""
+    from oracle import vbx as ovbx
+    params = KM.synthetic_resnet101(3)
+    comp = KM.compile_resnet101(params)
+    x = np.random.default_rng(5).normal(0, 1, (2, 64, 144)).astype(np.float32)
+    ref = ovbx.resnet101_forward(params, x)
+    got = prog_interp.run(comp, x[..., None])
+    assert got.shape == ref.shape == (2, 256)
+    assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
