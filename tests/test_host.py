@@ -6,13 +6,14 @@ import json
 import os
 import re
 import sys
+import warnings
 
 import numpy as np
 import pytest
 
 from inaspeechsegmenter_amd import _native, tables, segmenter as S, keras_model as KM
 from inaspeechsegmenter_amd import export_funcs, io as iss_io
-from oracle import segment as oseg, viterbi as ovit, vbx as ovbx, keras_cnn as ocnn
+from oracle import segment as oseg, sidekit as osk, viterbi as ovit, vbx as ovbx, keras_cnn as ocnn
 from conftest import GOLDEN, ROOT
 
 
@@ -364,3 +365,119 @@ out.write(b'data' + struct.pack('<I', 0xFFFFFFFF) + pcm)
     bad.write_bytes(b'xx')
     with pytest.raises(Exception, match='Invalid data'):
         iss_io.decode_pcm(str(bad), None, None, str(shim))
+
+
+class _FakeDevice(_FakeCtx):
+    """_FakeCtx + the signal half of the context API: `sidekit()` runs the oracle's feature path on whatever PCM16 was
+    handed over, the way the device does (frame t = samples [160 t, 160 t + 400) of the buffer)."""
+    device = 0
+
+    def pinned_empty(self, shape, dtype):
+        return np.empty(shape, dtype)
+
+    def pinned_free(self, a):
+        pass
+
+    def cnn_load(self, net_id, compiled):
+        pass
+
+    def set_signal(self, sig):
+        assert sig.dtype == np.int16
+        self.sig = np.array(sig, copy=True)
+
+    def sidekit(self):
+        with np.errstate(divide='ignore'):
+            self.loge, self.mspec = osk.mfcc_mspec((self.sig / 32768.0).astype(np.float32))
+        self.mspec = self.mspec.astype(np.float32)
+        return len(self.loge)
+
+    def get_loge(self):
+        return self.loge.copy()
+
+    def get_mspec(self):
+        return self.mspec.copy()
+
+
+def _write_wav(path, pcm):
+    import struct
+    pcm = np.asarray(pcm, dtype='<i2')
+    with open(path, 'wb') as f:
+        f.write(b'RIFF' + struct.pack('<I', 36 + pcm.nbytes) + b'WAVEfmt ' + struct.pack('<IHHIIHH', 16, 1, 1, 16000, 32000, 2, 16) +
+                b'data' + struct.pack('<I', pcm.nbytes))
+        f.write(pcm.tobytes())
+
+
+def test_super_batch_pipeline_equals_per_file_calls_with_fake_device(tmp_path):
+    """pipeline.process_files on a fake device: files of uneven lengths (none a multiple of 160 samples) laid end to end in one
+    buffer, ONE feature pass, ONE network call per net for all files, per-file Viterbi -- must give exactly what the per-file
+    path gives on the same fake device (offset / frame / window-row / span bookkeeping of pipeline._Worker.run), a medium too
+    short for the super-batch takes the single-file path, an undecodable one is a per-file error, results keep their index."""
+    from inaspeechsegmenter_amd import pipeline
+
+    def content_predict(nclass, salt):                               # depends on the window's values only (fake_predict.py
+        def predict(batch):                                          # also mixes in the row index: no good across batchings)
+            x = np.asarray(batch)
+            q = np.floor(np.where(np.isfinite(x), x, 0).astype(np.float64) * 64.0).astype(np.int64)
+            pref = ((q[:, 20:44, :, 0].sum(axis=(1, 2)) + salt * 1000) // 700) % nclass
+            out = np.full((len(x), nclass), 0.002 / (nclass - 1))
+            out[np.arange(len(x)), pref] = 0.998
+            return out.astype(np.float32)
+        return predict
+
+    fake = _FakeDevice({0: content_predict(3, 1), 1: content_predict(2, 2)}, {0: 21, 1: 24})
+    seg = object.__new__(S.Segmenter)
+    seg.energy_ratio, seg.detect_gender, seg.ctx, seg.ffmpeg = 0.03, True, fake, None
+    seg.vad, seg.gender = object.__new__(S.SpeechMusicNoise), object.__new__(S.Gender)
+    seg.vad.ctx = seg.gender.ctx = fake
+    seg.vad.compiled = seg.gender.compiled = None
+    rng = np.random.default_rng(11)
+
+    def medium(nsamp, seed):
+        r = np.random.default_rng(seed)
+        t = np.arange(nsamp) / 16000.0
+        x = np.zeros(nsamp)
+        pos = 0
+        while pos < nsamp:                                           # silence / noise / harmonic / chord stretches
+            n = int(r.uniform(0.4, 1.5) * 16000)
+            kind = r.integers(0, 4)
+            tt = t[pos:pos + n]
+            if kind == 1:
+                x[pos:pos + n] = r.normal(0, 0.03, len(tt))
+            elif kind == 2:
+                x[pos:pos + n] = 0.1 * sum(np.sin(2 * np.pi * 140 * k * tt) / k for k in range(1, 12)) * (1 + 0.5 * np.sin(2 * np.pi * 4 * tt))
+            elif kind == 3:
+                x[pos:pos + n] = 0.08 * sum(np.sin(2 * np.pi * f * tt) for f in (262, 330, 392))
+            pos += n
+        return np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+
+    lengths = [70001, 123457, 40333, 9000, 98765, 160 * 300 + 1]   # 9000 samples: < 68 frames -> single-file path
+    paths = []
+    for i, n in enumerate(lengths):
+        p = tmp_path / f'm{i}.wav'
+        _write_wav(p, medium(n, 100 + i))
+        paths.append(str(p))
+    bad = tmp_path / 'broken.wav'
+    bad.write_bytes(b'not a wav file')
+    paths.insert(2, str(bad))
+
+    got = {}
+
+    def on_result(i, src, lseg, err):
+        assert i not in got and src == paths[i]
+        got[i] = (lseg, err)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pipeline.process_files(seg, paths, on_result, batch_files=3, workers=1, decode_threads=2)
+        assert sorted(got) == list(range(len(paths)))
+        assert got[2][0] is None and got[2][1].startswith('error')
+        for i, p in enumerate(paths):
+            if i == 2:
+                continue
+            from inaspeechsegmenter_amd.io import decode_pcm
+            mspec, loge, difflen = S._sig2feats(fake, decode_pcm(p, None, None, None), p)
+            want = seg.segment_feats(mspec, loge, difflen, 0)
+            assert got[i][1] is None
+            assert got[i][0] == want, (i, got[i][0][:4], want[:4])
+    assert len({lab for lseg, _ in got.values() if lseg for lab, _, _ in lseg}) >= 3      # the inputs exercise several labels
+
