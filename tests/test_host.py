@@ -481,3 +481,48 @@ def test_super_batch_pipeline_equals_per_file_calls_with_fake_device(tmp_path):
             assert got[i][0] == want, (i, got[i][0][:4], want[:4])
     assert len({lab for lseg, _ in got.values() if lseg for lab, _, _ in lseg}) >= 3      # the inputs exercise several labels
 
+
+def test_batch_process_contract_with_fake_device(tmp_path):
+    """segmenter.py:297-335 through the product's batch_process + pipeline on a fake device: return tuple, message codes
+    (0 ok / 1 already exists / 2 error) in INPUT order, output directories created, skipifexist, both exporters, unknown format
+    (run_test.py:107-134 are the reference's checks of the same contract)."""
+    import filecmp
+
+    def predict3(batch):
+        x = np.asarray(batch)
+        out = np.full((len(x), 3), 0.001, np.float32)
+        out[np.arange(len(x)), (np.nan_to_num(x[:, 30, 5, 0]) > 0).astype(int)] = 0.998
+        return out
+
+    def predict2(batch):
+        x = np.asarray(batch)
+        out = np.full((len(x), 2), 0.002, np.float32)
+        out[np.arange(len(x)), (np.nan_to_num(x[:, 10, 3, 0]) > 0).astype(int)] = 0.998
+        return out
+
+    fake = _FakeDevice({0: predict3, 1: predict2}, {0: 21, 1: 24})
+    seg = object.__new__(S.Segmenter)
+    seg.energy_ratio, seg.detect_gender, seg.ctx, seg.ffmpeg = 0.03, True, fake, None
+    seg.vad, seg.gender = object.__new__(S.SpeechMusicNoise), object.__new__(S.Gender)
+    seg.vad.ctx = seg.gender.ctx = fake
+    seg.vad.compiled = seg.gender.compiled = None
+    src = os.path.join(GOLDEN, 'musanmix.wav')
+    lout = [str(tmp_path / 'a' / 'b' / '1.csv'), str(tmp_path / '2.csv'), str(tmp_path / '3.csv'), str(tmp_path / '4.TextGrid')]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        t, nb, avg, lmsg = seg.batch_process([src, os.path.join(GOLDEN, 'doesnotexist.wav'), src], lout[:3], workers=1)
+        assert nb == 2 and t > 0 and abs(avg - t / 2) < 1e-9
+        assert [m[0] for m in lmsg] == lout[:3] and [m[1] for m in lmsg] == [0, 2, 0]
+        assert lmsg[1][2].startswith('error: ') and lmsg[0][2].startswith('ok ')
+        assert filecmp.cmp(lout[0], lout[2], shallow=False) and not os.path.exists(lout[1])
+        ref = tmp_path / 'ref.csv'
+        export_funcs.seg2csv(seg.segment_signal(iss_io.decode_pcm(src, None, None, None)), str(ref))
+        assert filecmp.cmp(lout[0], str(ref), shallow=False)
+        t, nb, avg, lmsg = seg.batch_process([src, src], [lout[0], lout[2]], skipifexist=True, workers=1)
+        assert nb == 0 and avg == -1 and [m[1:] for m in lmsg] == [(1, 'already exists')] * 2
+        t, nb, avg, lmsg = seg.batch_process([src], [lout[3]], output_format='textgrid', workers=1)
+        assert nb == 1 and open(lout[3]).read().startswith('File type = "ooTextFile"')
+        with pytest.raises(NotImplementedError):
+            seg.batch_process([src], [lout[0]], output_format='json', workers=1)
+    seg.close()
+
