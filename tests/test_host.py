@@ -526,3 +526,30 @@ def test_batch_process_contract_with_fake_device(tmp_path):
             seg.batch_process([src], [lout[0]], output_format='json', workers=1)
     seg.close()
 
+
+def test_pipeline_device_failure_propagates(tmp_path):
+    """A device failure (NativeError) inside a worker is not a per-file error: process_files re-raises it in the caller's
+    thread (the reference lets predict() exceptions propagate, segmenter.py:314-327), and batch_process does not swallow it."""
+    from inaspeechsegmenter_amd import pipeline
+
+    class Broken(_FakeDevice):
+        def cnn_probs(self, net_id, win_rows):
+            raise _native.NativeError('iss_cnn_probs: out of memory (simulated)')
+
+    fake = Broken({}, {0: 21, 1: 24})
+    seg = object.__new__(S.Segmenter)
+    seg.energy_ratio, seg.detect_gender, seg.ctx, seg.ffmpeg = 0.03, True, fake, None
+    seg.vad, seg.gender = object.__new__(S.SpeechMusicNoise), object.__new__(S.Gender)
+    seg.vad.ctx = seg.gender.ctx = fake
+    seg.vad.compiled = seg.gender.compiled = None
+    src = os.path.join(GOLDEN, 'musanmix.wav')
+    seen = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with pytest.raises(_native.NativeError, match='simulated'):
+            pipeline.process_files(seg, [src, src], lambda *a: seen.append(a), workers=1)
+        assert seen == []
+        with pytest.raises(_native.NativeError, match='simulated'):
+            seg.batch_process([src], [str(tmp_path / 'o.csv')], workers=1)
+    assert not os.path.exists(tmp_path / 'o.csv')
+
