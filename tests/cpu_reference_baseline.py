@@ -20,7 +20,7 @@ import warnings
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # tests/ -> repo root
 sys.path.insert(0, ROOT)
 REF = '/root/reference/inaSpeechSegmenter'
 FS = 16000

@@ -553,3 +553,35 @@ def test_pipeline_device_failure_propagates(tmp_path):
             seg.batch_process([src], [str(tmp_path / 'o.csv')], workers=1)
     assert not os.path.exists(tmp_path / 'o.csv')
 
+
+def test_oracle_is_only_used_as_the_checker():
+    """oracle/ is test infrastructure: nothing in the product package, the scripts or the tools may import it; bench.py only
+    inside its cpu_baseline / parity legs and __graft_entry__ only inside smoke()."""
+    import ast
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+
+        def is_oracle(n):
+            if not isinstance(n, (ast.Import, ast.ImportFrom)):
+                return False
+            names = [a.name for a in n.names] if isinstance(n, ast.Import) else [n.module or '']
+            return any(x == 'oracle' or x.startswith('oracle.') for x in names)
+
+        inside = {}
+        for fn in ast.walk(tree):
+            if isinstance(fn, (ast.FunctionDef, ast.AsyncFunctionDef)):
+                for n in ast.walk(fn):
+                    if is_oracle(n):
+                        inside[n.lineno] = fn.name            # (the innermost def wins: ast.walk reaches it last)
+        hits = [(inside.get(n.lineno, '<module>'), n.lineno) for n in ast.walk(tree) if is_oracle(n)]
+        return hits
+
+    for d in ('inaspeechsegmenter_amd', 'scripts', 'tools'):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if f.endswith('.py'):
+                    assert oracle_imports(os.path.join(dirpath, f)) == [], (dirpath, f)
+    assert {fn for fn, _ in oracle_imports(os.path.join(ROOT, 'bench.py'))} <= {'cpu_baseline', 'bench_vbx', 'parity_check'}
+    assert {fn for fn, _ in oracle_imports(os.path.join(ROOT, '__graft_entry__.py'))} <= {'smoke'}
+
