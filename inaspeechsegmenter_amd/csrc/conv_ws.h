@@ -7,22 +7,27 @@
 // rocprofv3 counters (profiles/r01_pmc.md) showed those kernels at 47 % matrix-pipe occupancy with 30 % of the wave
 // cycles parked at barriers / waits and 39 % issue-stalled.  Here the loop nest is turned around:
 //
-//   for each group of G = 4 tiles (256 rows each; their 4 x 2 accumulators stay in registers: 128 VGPRs)
+//   for each group of G = 2 tiles (512 rows each: 8 waves x 64 rows x 64 channels; 2 x 4 accumulators = 128 VGPRs)
 //     for each 16-channel chunk c
-//       load the weights of ALL taps of chunk c into LDS once (NT x 4 KB, LDS-DMA)            <- once per 4 tiles
+//       load the weights of ALL taps of chunk c into LDS once (NT x 4 KB, LDS-DMA)            <- once per 2 tiles
 //       for each tile t of the group                                                          <- one "block"
-//         NT steps of 6 MFMAs: A fragments from the tile's LDS footprint, B fragments from the resident weights;
-//         behind them, the footprint of the NEXT block is fetched, split into bf16 hi / lo and written into the
-//         other footprint buffer; one barrier at the end of the block (90 MFMAs per wave for a 5x3 filter).
+//         NT steps of 12 MFMAs in three pinned groups (a.lo x b.hi, a.hi x b.hi, a.hi x b.lo on 2 row x 2 column blocks):
+//         A fragments from the tile's LDS footprint (double-buffered in registers), B fragments from the resident weights
+//         (single-buffered: the hi plane of step v + 1 is read behind the second group of step v, the lo plane behind the
+//         third) -- 8 ds_read_b128 per 12 MFMAs; behind them the footprint of the NEXT block is fetched, split into bf16
+//         hi / lo and kept in the registers of the f32 values it replaces; at the end of the block: barrier, the footprint
+//         is written (14 ds_write_b64 per thread), barrier (180 MFMAs per wave and block for a 5x3 filter).
 //
-// No weight ring, no vmcnt bookkeeping and no barrier inside a block: a wave's stream is ds_read_b128 + MFMA with
-// a conversion slice every other step.  512 threads = 8 waves (two per SIMD, decoupled between barriers) share one
-// footprint of 512 pixels (41 KB per buffer) and the weight block (60 KB for 5x3).
+// No weight ring, no vmcnt bookkeeping and no barrier inside a block: a wave's stream is ds_read_b128 + MFMA with a
+// conversion slice per step in the second half of the block.  512 threads = 8 waves (two per SIMD, decoupled between the
+// block boundaries) share ONE footprint of 896 pixels (72 KB; two of them do not fit beside the weights) and the weight
+// block (60 KB for 5x3).  The 32-row-per-wave predecessor (four 256-row tiles per group, two 512-pixel footprints, one
+// barrier per block) needed 12 fragment reads per 12 MFMAs and ran 8-10 % slower.
 //
 // LDS layout.  Footprint rows are 80 bytes per pixel -- 16 channels hi (32 B) | 16 channels lo (32 B) | 16 B pad -- and
 // LINEAR: the A-fragment address of a tap is (lane base + tap offset), one v_add per step, and 16 consecutive pixels still
 // hit 16 different 16-byte bank groups (20 p mod 64 is a permutation of the multiples of 4).  Zero-padded taps read an
-// all-zero pixel kept behind each footprint (one v_cndmask on the address instead of zeroing eight fragment registers).
+// all-zero pixel kept behind the footprint (one v_cndmask on the address instead of zeroing eight fragment registers).
 // The 16-byte slots of a weight tile are permuted on the SOURCE side of the LDS-DMA (slot = 2 n + (h ^ ((n >> 3) & 1)) for
 // row n, k half h) so that the ds_read_b128 of the 16 lanes of a group are conflict-free.  Geometry and epilogue
 // parameters are read through an opaque copy of the kernel-argument pointer where they are needed instead of living in
@@ -61,7 +66,7 @@ constexpr int WS_PIX = 896;                        // footprint capacity in pixe
 constexpr int WS_ZERO = WS_PIX * F2_ROW;           // byte offset of the all-zero pixel behind a footprint
 constexpr int WS_BUF = (WS_PIX + 1) * F2_ROW;      // bytes of the footprint buffer (71 760)
 constexpr int WS_NFV = WS_PIX / 128;               // 128-pixel slices per footprint (7): 512 threads x 4 channels each
-constexpr int WS_MAXNT = 16;                       // taps: NT x 4 KB of weights + two footprints must fit 160 KB of LDS
+constexpr int WS_MAXNT = 16;                       // taps: NT x 4 KB of weights + the footprint must fit 160 KB of LDS
 constexpr int ws_lds_bytes(int nt) { return WS_BUF + nt * F2_BST; }
 
 template <int KH, int KW, bool PADDED, bool TR, bool FUSED>
