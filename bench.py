@@ -51,26 +51,35 @@ MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 
 
 # ------------------------------------------------------------------------------ synthetic audio
-def synth_recording(file_index, n_samples, device):
-    """SURVEY.md 8(d): concatenation of U(2,20) s segments; kinds: exact silence 10 %, Gaussian
-    noise -30 dBFS 20 %, voiced (<= 30 harmonics of f0 in {110,200} Hz, 1/k roll-off, 4 Hz AM,
-    -20 dBFS) 40 %, music (3-5 sustained sines with slow tremolo, -18 dBFS) 30 %.  Returns a torch
-    int16 tensor on `device`.  The plan (kinds, durations, frequencies) comes from numpy's
-    default_rng(20250926 + file_index); the noise samples from a torch generator with the same seed."""
-    import torch
+def synth_plan(file_index, n_samples):
+    """SURVEY.md 8(d) plan of one recording: [(kind, start, n, f0, chord[:nch], trem)] with kind 0 silence / 1 noise /
+    2 voiced / 3 music, from numpy's default_rng(20250926 + file_index) (durations U(2,20) s, kinds 10/20/40/30 %)."""
     rng = np.random.default_rng(20250926 + file_index)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(20250926 + file_index)
-    out = torch.zeros(n_samples, dtype=torch.float32, device=device)
-    pos = 0
+    plan, pos = [], 0
     while pos < n_samples:
         dur = int(rng.uniform(2.0, 20.0) * FS)
-        kind = rng.choice(4, p=[0.1, 0.2, 0.4, 0.3])
+        kind = int(rng.choice(4, p=[0.1, 0.2, 0.4, 0.3]))
         f0 = float(rng.choice([110.0, 200.0]))
         nch = int(rng.integers(3, 6))
         chord = rng.uniform(130.0, 1000.0, size=5)
         trem = float(rng.uniform(0.2, 1.0))
         n = min(dur, n_samples - pos)
+        plan.append((kind, pos, n, f0, [float(f) for f in chord[:nch]], trem))
+        pos += n
+    return plan
+
+
+def synth_recording(file_index, n_samples, device):
+    """SURVEY.md 8(d): concatenation of U(2,20) s segments; kinds: exact silence 10 %, Gaussian
+    noise -30 dBFS 20 %, voiced (<= 30 harmonics of f0 in {110,200} Hz, 1/k roll-off, 4 Hz AM,
+    -20 dBFS) 40 %, music (3-5 sustained sines with slow tremolo, -18 dBFS) 30 %.  Returns a torch
+    int16 tensor on `device`.  The plan (kinds, durations, frequencies) comes from `synth_plan`; the noise samples from a
+    torch generator on `device` with the same seed (CPU and GPU generators give different, equally distributed samples)."""
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(20250926 + file_index)
+    out = torch.zeros(n_samples, dtype=torch.float32, device=device)
+    for kind, pos, n, f0, chord, trem in synth_plan(file_index, n_samples):
         if kind == 1:
             out[pos:pos + n] = torch.randn(n, generator=gen, device=device, dtype=torch.float32) * 10 ** (-30 / 20)
         elif kind >= 2:
@@ -84,14 +93,36 @@ def synth_recording(file_index, n_samples, device):
                 level = 10 ** (-20 / 20)
             else:
                 x = torch.zeros(n, device=device)
-                for f in chord[:nch]:
+                for f in chord:
                     x += torch.sin(2 * np.pi * float(f) * t)
                 x *= 0.8 + 0.2 * torch.sin(2 * np.pi * trem * t)
                 level = 10 ** (-18 / 20)
             x *= level / torch.sqrt(torch.mean(x * x) + 1e-20)
             out[pos:pos + n] = x
-        pos += n
     return torch.clamp(torch.round(out * 32768.0), -32768, 32767).to(torch.int16)
+
+
+# ------------------------------------------------------------------------------ per-kernel roofline
+GEMM_CLASSES = ((3, 'conv_x3_ws_kernel'), (4, 'conv_x3_fp_kernel'), (5, 'conv_x3_pw_kernel'), (6, 'conv_x3_kernel'),
+                (7, 'conv1_patch_x3_kernel'), (8, 'conv_igemm_kernel'))     # include/iss.h ISS_PROF_*
+
+
+def gemm_kernel_table(ctxs, peak_tf):
+    """HIP-event time, launches and algorithmic flops of every GEMM kernel class (iss_prof_get kinds 3..8) summed over the
+    given contexts -> ([{kernel, ms_per_step, launches, flops, achieved, frac}], the entry with the most time)."""
+    rows = []
+    for kind, name in GEMM_CLASSES:
+        ms = fl = 0.0
+        nl = 0
+        for c in ctxs:
+            a, b, d = c.prof_get(kind)
+            ms += a; nl += b; fl += d
+        if nl:
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            rows.append({"kernel": name, "ms_per_step": ms, "launches": nl, "flops": fl, "avg_launch_ms": ms / nl,
+                         "achieved": tf, "frac": tf / peak_tf})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows, (rows[0] if rows else None)
 
 
 # ------------------------------------------------------------------------------ CPU baseline
@@ -150,27 +181,72 @@ def cpu_baseline(seg, pcm_host, target_s=15.0):
     return out, nsec, det
 
 
+def cnn_driven_boundaries(lseg):
+    """Boundaries of a final segmentation that a NETWORK decided: adjacent segments neither of which is `noEnergy` (every
+    boundary of the energy detector has `noEnergy` on one side; the VAD / gender Viterbi passes run inside `energy` /
+    `speech` segments, segmenter.py:156-178)."""
+    return sum(1 for x, y in zip(lseg, lseg[1:]) if x[0] != 'noEnergy' and y[0] != 'noEnergy' and x[2] == y[1])
+
+
+def viterbi_min_margin(logp, trans):
+    """Score of the best path minus the score of the best path that passes through a DIFFERENT state at some slot,
+    minimised over the slots (max-sum forward / backward, uniform initial log(1/K) like pyannote_viterbi.py:166-167):
+    how far the emissions are from changing any label of the segment."""
+    T, K = logp.shape
+    if T == 0 or K < 2:
+        return float('inf')
+    e = np.asarray(logp, np.float64)
+    a = np.empty((T, K))
+    b = np.zeros((T, K))
+    a[0] = e[0] + np.log(1.0 / K)
+    for t in range(1, T):
+        a[t] = e[t] + (a[t - 1][:, None] + trans).max(0)
+    for t in range(T - 2, -1, -1):
+        b[t] = (trans + (e[t + 1] + b[t + 1])[None, :]).max(1)
+    through = a + b                                     # best path constrained to state s at slot t
+    best = through.max(1)
+    srt = np.sort(through, axis=1)
+    return float((srt[:, -1] - srt[:, -2]).min()) if np.isfinite(best).all() else 0.0
+
+
 def parity_check(seg, pcm_host, nsec, det):
-    """GPU vs oracle on the cpu_baseline sample: identical segments, and max |p_gpu - p_oracle| over every slot the oracle
-    evaluated (VAD net on its energy slots, gender net on its speech slots)."""
+    """GPU vs oracle on the cpu_baseline sample: identical segments; max |p_gpu - p_oracle| and the number of slots whose
+    arg-max class differs, over every slot the oracle evaluated (VAD net on its energy slots, gender net on its speech
+    slots); and what makes `segments_equal` mean something: how many boundaries the networks decided, how the slots spread
+    over the classes, and the smallest Viterbi path margin of an evaluated segment."""
     from inaspeechsegmenter_amd import segmenter as S
     sig = np.ascontiguousarray(pcm_host[:nsec * FS])
     got = seg.segment_signal(sig)
     want = [(lab, a * .02, b * .02) for lab, a, b in det['lseg2']]
     rows = S._window_rows(det['nframes'])
-    worst, nslots = 0.0, 0
-    for net_id, raw, lseg_in, inlabel in ((0, det['raw_vad'], det['lseg0'], 'energy'), (1, det['raw_gen'], det['lseg1'], 'speech')):
-        idx = [np.arange(a, b) for lab, a, b in lseg_in if lab == inlabel]
-        if not idx or raw is None:
+    worst, nslots, mism, margin = 0.0, 0, 0, float('inf')
+    classes = {}
+    for net, raw, lseg_in in ((seg.vad, det['raw_vad'], det['lseg0']), (seg.gender, det['raw_gen'], det['lseg1'])):
+        spans = [(a, b) for lab, a, b in lseg_in if lab == net.inlabel]
+        if not spans or raw is None:
             continue
-        idx = np.concatenate(idx)
-        p, fin = seg.ctx.cnn_probs(net_id, rows[idx])
+        idx = np.concatenate([np.arange(a, b) for a, b in spans])
+        p, fin = seg.ctx.cnn_probs(net.net_id, rows[idx])
         ok = fin & np.all(np.isfinite(raw), axis=1)
         worst = max(worst, float(np.abs(p[ok] - raw[ok]).max()) if ok.any() else 0.0)
+        mism += int((p[ok].argmax(1) != raw[ok].argmax(1)).sum())
         nslots += int(ok.sum())
-    return {"segments_equal": got == want, "segments": len(want), "max_abs_dprob": worst, "slots": nslots,
-            "sample_s": nsec, "what": "Segmenter.segment_signal on the cpu_baseline sample vs the oracle pipeline (labels and "
-                                      "boundaries), and iss_cnn_probs vs the oracle's network outputs on every slot it evaluated"}
+        hist = np.bincount(raw[ok].argmax(1), minlength=len(net.outlabels)) / max(int(ok.sum()), 1)
+        classes.update({lab: round(float(h), 4) for lab, h in zip(net.outlabels, hist)})
+        trans = S.diag_trans_exp(net.viterbi_arg, len(net.outlabels))
+        pos = 0
+        for a, b in spans:
+            with np.errstate(divide='ignore'):
+                margin = min(margin, viterbi_min_margin(np.log(p[pos:pos + b - a]), trans))
+            pos += b - a
+    return {"segments_equal": got == want, "segments": len(want), "cnn_driven_boundaries": cnn_driven_boundaries(det['lseg2']),
+            "classes_present": classes, "argmax_mismatch_slots": mism, "max_abs_dprob": worst, "slots": nslots,
+            "min_viterbi_path_margin_nats": margin, "sample_s": nsec,
+            "what": "Segmenter.segment_signal on the cpu_baseline sample vs the oracle pipeline (labels and boundaries); "
+                    "iss_cnn_probs vs the oracle's network outputs on every slot it evaluated (max |dp|, slots whose arg-max "
+                    "differs); cnn_driven_boundaries = boundaries between two non-noEnergy segments (decided by a network, not by "
+                    "the energy detector); classes_present = share of the evaluated slots each class wins (oracle); margin = best "
+                    "Viterbi path score minus the best path that differs at some slot, smallest over the evaluated segments"}
 
 
 # ------------------------------------------------------------------------------ file workloads
@@ -252,15 +328,26 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
     def barrier():
         if comm:
             comm.barrier()
+    def host_mem():
+        """resident set of this process (MB) and bytes in use under the files' mount (MB): must stay flat across steps"""
+        try:
+            import psutil
+            import shutil
+            return round(psutil.Process().memory_info().rss / 2 ** 20, 1), round(shutil.disk_usage(root).used / 2 ** 20, 1)
+        except Exception:                                   # noqa: BLE001
+            return None, None
     barrier()
     torch.cuda.synchronize()
+    mem_trace = [host_mem()]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nseg = step()
+        mem_trace.append(host_mem())
     seg.ctx.synchronize()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if comm:
         dt = comm.max_over_ranks(dt)
     # roofline of the conv/dense GEMM launches, live: HIP events on the library's streams around every launch of ONE extra
@@ -275,7 +362,21 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
     for c in ctxs:
         ms, nl, fl = c.prof_get(0)
         conv_ms += ms; conv_n += nl; conv_fl += fl
+    ktab, kdom = gemm_kernel_table(ctxs, MFMA_BF16_PEAK_TF if x3 else MFMA_F32_PEAK_TF)
+    for c in ctxs:
         c.prof_enable(False)
+    # audit trail of the multi-GPU run: what RCCL reports for the communicator, and the spread of the ranks' own step times
+    rccl = None
+    dt_min = dt_max = dt_local
+    if comm:
+        info = comm.info()
+        dt_max = comm.max_over_ranks(dt_local)
+        dt_min = -comm.max_over_ranks(-dt_local)
+        ranks_ok = int(round(-comm.max_over_ranks(-float(info['world'] == world and info['rank'] == rank))))     # min over ranks
+        rccl = {"world": info['world'], "ranks_seen": info['world'], "rank0_user_rank": info['rank'], "version": info['version'],
+                "lib": info['lib'], "every_rank_agrees": bool(ranks_ok),
+                "what": "ncclCommCount / ncclCommUserRank / ncclGetVersion of rank 0's communicator (iss_comm_info) and the path of "
+                        "the librccl it was bound from; the collective of every step is ncclAllGather through iss_allgather_segments"}
     if rank == 0:
         value = args.steps * hours / dt
         peak_tf = MFMA_BF16_PEAK_TF if x3 else MFMA_F32_PEAK_TF
@@ -287,6 +388,7 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
                     "launches_per_step": conv_n, "flops_per_launch": conv_fl / max(conv_n, 1),
                     "event_based": {"achieved": ach_ev, "frac": ach_ev / peak_tf, "kernel_ms_per_step": conv_ms,
                                     "avg_launch_ms": conv_ms / max(conv_n, 1)},
+                    "dominant": kdom, "kernels": ktab,
                     "note": "achieved = algorithmic flops of rank 0's GEMM launches in one step / the step's WALL time (decode, copies, "
                             "host Viterbi and export included): launches of the two device contexts run concurrently, so the sum of "
                             "their HIP-event durations (event_based) counts shared time twice; the segmenter workload's line has the "
@@ -305,11 +407,20 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
                                    "features + CNNs, compiled Viterbi and CSV export are all inside the timed region",
                        "files": nfiles, "files_per_gpu": per_gpu, "minutes_per_file": minutes, "audio_hours_per_step": hours,
                        "ms_per_file_per_gpu": dt / args.steps / per_gpu * 1e3, "segments_per_step": nseg,
-                       "weights": "seeded stand-ins, (68,21,1)->3 and (68,24,1)->2, ~1.25 M params each (real Keras files are un-vendored release assets)",
+                       "weights": "seeded stand-ins, (68,21,1)->3 and (68,24,1)->2, ~1.25 M params each, last layer calibrated "
+                                  "(tests/golden/make_standin_heads.py); the real Keras files are un-vendored release assets",
                        "parallelism": (f"file-parallel x{world}: files dealt by size (LPT), no data-path collective, ONE ncclAllGather of int32 segment "
                                        "tables per step through the C-ABI (iss_allgather_segments)") if world > 1 else "single GPU"},
             "roofline": roofline,
+            "host_memory": {"rss_mb_after_warmup_then_each_step": [m[0] for m in mem_trace],
+                            "files_mount_used_mb": [m[1] for m in mem_trace],
+                            "what": "rank 0's resident set and the space in use under the WAV / CSV directory, sampled after the "
+                                    "warm-up and after every timed step (a leak in the pinned buffers, queues or exporters would show)"},
+            "ranks": {"ms_per_step_min": dt_min / args.steps * 1e3, "ms_per_step_max": dt_max / args.steps * 1e3,
+                      "what": "each rank's own wall time for the timed steps (barrier to barrier), min / max over the ranks"},
         }
+        if rccl is not None:
+            line["rccl"] = rccl
         print(json.dumps(line))
     barrier()
     seg.close()
@@ -516,6 +627,7 @@ def main():
     conv_ms, conv_launches, conv_flops = seg.ctx.prof_get(0)
     sk_ms, sk_launches, _ = seg.ctx.prof_get(1)
     other_ms, other_launches, _ = seg.ctx.prof_get(2)
+    ktab, kdom = gemm_kernel_table([seg.ctx], MFMA_BF16_PEAK_TF if x3 else MFMA_F32_PEAK_TF)
     seg.ctx.prof_enable(False)
     achieved_tf = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     # HBM traffic per conv launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own): read from the
@@ -533,10 +645,13 @@ def main():
     sk_bytes = n * 2 + seg.ctx.T * 25 * 4                # PCM16 in + (24 mel + 1 loge) f32 out
     peak_tf = MFMA_BF16_PEAK_TF if x3 else MFMA_F32_PEAK_TF
     roofline = {"bound": "mfma",
-                "kernel": ("conv_x3_fp_kernel / conv_x3_kernel (conv2d/dense implicit GEMM, 3 x v_mfma_f32_32x32x16_bf16 per k-step on "
-                           "bf16 hi/lo operand splits; `achieved` counts the reference's ALGORITHMIC flops: the matrix pipe executes "
-                           "3x that, and the first layer, 1.9 % of them, is computed once per log-mel row instead of once per window)") if x3 else
+                "kernel": ("all conv2d/dense implicit-GEMM launches: conv_x3_ws_kernel (second conv of both nets, shared first layer), "
+                           "conv_x3_fp_kernel (3x3 layers), conv_x3_pw_kernel / conv_x3_kernel (dense head); 3 x v_mfma_f32_32x32x16_bf16 per "
+                           "k-step on bf16 hi/lo operand splits; `achieved` counts the reference's ALGORITHMIC flops: the matrix pipe "
+                           "executes 3x that, and the first layer, 1.9 % of them, is computed once per log-mel row instead of once per "
+                           "window; `dominant` is the kernel with the most time, with its own flops and fraction") if x3 else
                           "conv_igemm_kernel (conv2d/dense implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                "dominant": kdom, "kernels": ktab,
                 "achieved": achieved_tf, "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": achieved_tf / peak_tf, "traffic": traffic, "traffic_raw": traffic_raw,
                 "traffic_source": "static_from_profiles (profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
@@ -589,10 +704,12 @@ def main():
                                    "resident in HBM) through smn VAD + gender (the metric's nets; configs[1] itself lists smn only), "
                                    "dense mode: both CNNs on 100% of the 20 ms slots",
                        "audio_hours_per_step_per_gpu": hours, "slots_per_step_per_gpu": P,
-                       "weights": "seeded stand-ins, (68,21,1)->3 and (68,24,1)->2, ~1.25 M params each (real Keras files are un-vendored release assets)",
+                       "weights": "seeded stand-ins, (68,21,1)->3 and (68,24,1)->2, ~1.25 M params each, last layer calibrated on the generator's "
+                                  "ground truth and the reference's musanmix goldens (tests/golden/make_standin_heads.py); the real "
+                                  "Keras files are un-vendored release assets",
                        "vad_flops_per_slot": vad_f, "gender_flops_per_slot": gen_f,
                        "parallelism": f"file-parallel x{world}, one all-gather of segment tables per step" if world > 1 else "single GPU",
-                       "segments": len(lseg), "label_slots": slots,
+                       "segments": len(lseg), "label_slots": slots, "cnn_driven_boundaries": cnn_driven_boundaries(lseg),
                        "reference_semantics": {"value": world * hours / dt_ref, "unit": "hours-of-audio/s",
                                                "ms_per_step": dt_ref * 1e3,
                                                "vad_slot_frac": 1.0 - slots['noEnergy'] / P,

@@ -70,6 +70,7 @@ def lib():
         'iss_comm_destroy': (C.c_int, [vp]),
         'iss_allgather_segments': (C.c_int, [vp, pi32, i32, i32, pi32, pi32]),
         'iss_comm_allreduce_max': (C.c_int, [vp, pd]),
+        'iss_comm_info': (C.c_int, [vp, pi32, pi32, pi32, C.c_char_p, i32]),
         'iss_sidekit': (C.c_int, [vp, pi32]),
         'iss_get_loge': (C.c_int, [vp, pf]),
         'iss_get_mspec': (C.c_int, [vp, pf]),
@@ -139,6 +140,8 @@ class Context:
         self._dither_n = 0          # length of the dither stream cached on the device (vbx)
         self._pinned = {}           # data address -> hipHostMalloc pointer of pinned_empty() arrays
         self.comm_rank, self.comm_world = 0, 1
+        self.precision = None       # last value given to set_precision / set_workspace_limit (None = library default)
+        self.workspace_limit = None
 
     def close(self):
         if getattr(self, '_h', None):
@@ -279,15 +282,26 @@ class Context:
         self.comm_rank, self.comm_world = 0, 1
 
     def allgather_segments(self, rows, capacity):
-        """rows: (k,4) int32 of this rank -> ((world, capacity, 4) int32, counts (world,)); rank r's first
-        min(counts[r], capacity) rows are valid."""
-        rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
+        """rows: (k,4) int32 of this rank, or None = "my local work failed" -> ((world, capacity, 4) int32, counts (world,));
+        rank r's first min(counts[r], capacity) rows are valid, counts[r] == -1 marks a rank that reported failure."""
         world = self.comm_world
         out = np.zeros((world, capacity, 4), dtype=np.int32)
         counts = np.zeros(world, dtype=np.int32)
-        self._ck(self._L.iss_allgather_segments(self._h, _ptr(rows, C.c_int32), rows.shape[0], int(capacity),
+        if rows is None:
+            rows, n = np.zeros((1, 4), np.int32), -1
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
+            n = rows.shape[0]
+        self._ck(self._L.iss_allgather_segments(self._h, _ptr(rows, C.c_int32), n, int(capacity),
                                                 _ptr(out, C.c_int32), _ptr(counts, C.c_int32)), 'iss_allgather_segments')
         return out, counts
+
+    def comm_info(self):
+        """{'world', 'rank', 'version', 'lib'} as RCCL itself reports them for this context's communicator."""
+        w, r, v = C.c_int32(), C.c_int32(), C.c_int32()
+        buf = C.create_string_buffer(512)
+        self._ck(self._L.iss_comm_info(self._h, C.byref(w), C.byref(r), C.byref(v), buf, 512), 'iss_comm_info')
+        return {'world': w.value, 'rank': r.value, 'version': v.value, 'lib': buf.value.decode(errors='replace')}
 
     def comm_allreduce_max(self, value):
         v = C.c_double(float(value))
@@ -309,9 +323,19 @@ class Context:
     def set_precision(self, mode):
         """PREC_BF16X3 (default: split-bf16 MFMA, float32-class results) or PREC_F32 (exact f32 MFMA)."""
         self._ck(self._L.iss_set_precision(self._h, int(mode)), 'iss_set_precision')
+        self.precision = int(mode)
 
     def set_workspace_limit(self, nbytes):
         self._ck(self._L.iss_set_workspace_limit(self._h, int(nbytes)), 'iss_set_workspace_limit')
+        self.workspace_limit = int(nbytes)
+
+    def mirror_settings(self, other):
+        """Give this context the arithmetic mode, workspace cap and profiling state of `other` (the extra device
+        contexts of the multi-file pipeline follow the Segmenter's own context)."""
+        if getattr(other, 'precision', None) is not None and other.precision != getattr(self, 'precision', None):
+            self.set_precision(other.precision)
+        if getattr(other, 'workspace_limit', None) is not None and other.workspace_limit != getattr(self, 'workspace_limit', None):
+            self.set_workspace_limit(other.workspace_limit)
 
     def synchronize(self):
         self._ck(self._L.iss_synchronize(self._h), 'iss_synchronize')

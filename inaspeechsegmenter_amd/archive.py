@@ -47,6 +47,29 @@ def segment_archive(segment_file, linput, loutput=None, output_format='csv', siz
     if sizes is None:
         sizes = [os.path.getsize(f) if os.path.exists(f) else 0 for f in linput]
     mine = sharding.shard_files(sizes, world)[rank]
+    # A collective cannot lose a participant: if this rank's local work fails (device error, unwritable output) it still
+    # takes part in the all-gather, flagged, so that every other rank raises `sharding.RankFailure` instead of waiting
+    # for it; then the original exception is re-raised here.  (A rank that is gone altogether is caught by the
+    # communicator's timeout: ISS_COMM_TIMEOUT_S on RCCL, the process group's timeout on torch.distributed.)
+    cap = capacity or max(1024, 64 * (len(linput) // world + 1))      # the same on every rank, failing or not
+    try:
+        local, lmsg = _segment_share(segment_file, linput, loutput, fexport, mine, skipifexist)
+    except BaseException:
+        if comm:
+            try:
+                comm.allgather(None, cap)
+            except Exception:                                  # noqa: BLE001  the original failure is the one to report
+                pass
+        raise
+    if comm:
+        allrows = comm.allgather(local, cap)
+    else:
+        allrows = local
+    return sharding.unpack_segments(allrows), lmsg
+
+
+def _segment_share(segment_file, linput, loutput, fexport, mine, skipifexist):
+    """This rank's files -> ((k,4) int32 segment rows, lmsg)."""
     rows, lmsg = [], []
     if hasattr(segment_file, 'batch_process') and hasattr(segment_file, 'ctx'):
         # a Segmenter: this rank's share runs through the multi-file pipeline (super-batches, two device contexts)
@@ -63,18 +86,18 @@ def segment_archive(segment_file, linput, loutput=None, output_format='csv', siz
                 d = os.path.dirname(dst)
                 if d and not os.path.isdir(d):
                     os.makedirs(d, exist_ok=True)
-        t0 = time.time()
         got = {}
 
-        def on_result(k, src, lseg, err):
+        def on_result(k, src, lseg, err, secs=0.0):
             dst = loutput[mine[k]] if loutput is not None else None
             if lseg is None:
                 msgs[k] = (dst, 2, err)
                 return
+            b = time.time()
             if dst is not None:
                 fexport(lseg, dst)
             got[k] = sharding.pack_segments(mine[k], [(lab, int(round(s / .02)), int(round(e / .02))) for lab, s, e in lseg])
-            msgs[k] = (dst, 0, 'ok ' + str(time.time() - t0))
+            msgs[k] = (dst, 0, 'ok ' + str(secs + time.time() - b))      # per-file time, segmenter.py:322-327
 
         pipeline.process_files(seg, [linput[i] for i in mine], on_result, skip=skip)
         rows = [got[k] for k in sorted(got)]
@@ -102,12 +125,7 @@ def segment_archive(segment_file, linput, loutput=None, output_format='csv', siz
         rows.append(sharding.pack_segments(i, slots))
         lmsg.append((dst, 0, 'ok ' + str(time.time() - b)))
     local = np.concatenate(rows, axis=0) if rows else np.zeros((0, 4), np.int32)
-    if comm:
-        cap = capacity or max(1024, 64 * (len(linput) // world + 1))
-        allrows = comm.allgather(local, cap)
-    else:
-        allrows = local
-    return sharding.unpack_segments(allrows), lmsg
+    return local, lmsg
 
 
 class JobList:

@@ -982,6 +982,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         ws = ws && fused;
         iss_prof_begin(c, 0, fl);
+        iss_prof_tag(c, ws ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
         if (ws) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);         // persistent: one 512-thread workgroup per CU
@@ -1001,6 +1002,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
 #undef ISS_FP_CASE
         } else if (x3 && patch && a.H_k * a.kw <= XBK && a.M < (1ll << 31)) {
             const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent, no barriers: 2 workgroups per CU
+            iss_prof_tag(c, ISS_PROF_PATCH1);
             // blob offsets are multiples of 8 floats, so the float4 loads of bias / scale / shift are aligned
             if (a.pp == 1 && a.Cout % 4 == 0 && !a.res) hipLaunchKernelGGL(conv1_patch_x3_kernel<true>, pgrid, dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL(conv1_patch_x3_kernel<false>, pgrid, dim3(256), 0, c->stream, a);
@@ -1015,6 +1017,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             static const bool no_pw = getenv("ISS_NO_PW") != nullptr;
             const bool pointwise = !no_pw && a.mode == 0 && tr && a.H_k == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt_ == 0 &&
                                    a.pl_ == 0 && R[ISS_C_HO] == a.H && R[ISS_C_WO] == a.W && a.Kpad == a.Cin;
+            if (pointwise) iss_prof_tag(c, ISS_PROF_PW);
             if (pointwise) hipLaunchKernelGGL(conv_x3_pw_kernel, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), dim3(256), 0, c->stream, a);
             else
             if (ntn == 4) hipLaunchKernelGGL((conv_x3_kernel<0, true, 4>), gridw, dim3(256), 0, c->stream, a);

@@ -6,8 +6,11 @@
 // workers (scripts/ina_speech_segmenter_pyro_client.py:64-74); SURVEY.md section 8(e) defines this exchange.
 #include "iss_internal.h"
 #include <dlfcn.h>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 namespace {
 
@@ -23,6 +26,12 @@ struct Rccl {
     int (*GetUniqueId)(NcclUniqueId*) = nullptr;
     int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommAbort)(NcclComm) = nullptr;
+    int (*CommCount)(const NcclComm, int*) = nullptr;
+    int (*CommUserRank)(const NcclComm, int*) = nullptr;
+    int (*CommGetAsyncError)(NcclComm, int*) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    std::string path;
     int (*AllGather)(const void*, void*, size_t, int, NcclComm, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -47,11 +56,41 @@ bool load_rccl() {
     ISS_SYM(GetUniqueId, "ncclGetUniqueId")
     ISS_SYM(CommInitRank, "ncclCommInitRank")
     ISS_SYM(CommDestroy, "ncclCommDestroy")
+    ISS_SYM(CommAbort, "ncclCommAbort")
+    ISS_SYM(CommCount, "ncclCommCount")
+    ISS_SYM(CommUserRank, "ncclCommUserRank")
+    ISS_SYM(CommGetAsyncError, "ncclCommGetAsyncError")
+    ISS_SYM(GetVersion, "ncclGetVersion")
     ISS_SYM(AllGather, "ncclAllGather")
     ISS_SYM(AllReduce, "ncclAllReduce")
     ISS_SYM(GetErrorString, "ncclGetErrorString")
 #undef ISS_SYM
+    Dl_info info;
+    if (dladdr((void*)g_rccl.AllGather, &info) && info.dli_fname) g_rccl.path = info.dli_fname;
     return true;
+}
+
+// Wait for the collective(s) enqueued on the context's stream.  A peer that died before reaching the collective would
+// leave hipStreamSynchronize blocked forever: poll instead, watch the communicator's asynchronous error state, and after
+// ISS_COMM_TIMEOUT_S seconds (default 1800) abort the communicator (ncclCommAbort) so that THIS rank fails loudly too.
+int wait_collective(iss_ctx* c, const char* what) {
+    static const double limit = [] { const char* e = getenv("ISS_COMM_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 1800.0; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return ISS_OK;
+        if (q != hipErrorNotReady) return iss_fail(c, ISS_EHIP, "%s: hipStreamQuery failed: %s", what, hipGetErrorString(q));
+        int aerr = NCCL_SUCCESS;
+        const bool bad = g_rccl.CommGetAsyncError((NcclComm)c->comm, &aerr) != NCCL_SUCCESS || aerr != NCCL_SUCCESS;
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (bad || waited > limit) {
+            (void)g_rccl.CommAbort((NcclComm)c->comm);
+            c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+            if (bad) return iss_fail(c, ISS_EHIP, "%s: RCCL reported an asynchronous error (%s); communicator aborted", what, g_rccl.GetErrorString(aerr));
+            return iss_fail(c, ISS_ETIMEOUT, "%s: no completion after %.0f s (ISS_COMM_TIMEOUT_S): a peer rank is gone or stuck; communicator aborted", what, waited);
+        }
+        if (spin < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
 }
 
 #define ISS_NCCL(c, call)                                                                        \
@@ -99,7 +138,7 @@ extern "C" int iss_comm_destroy(iss_ctx* c) {
 
 extern "C" int iss_allgather_segments(iss_ctx* c, const int32_t* local_rows, int32_t n_local, int32_t capacity,
                                       int32_t* all_rows, int32_t* counts) {
-    if (!c || n_local < 0 || capacity < 1 || (n_local > 0 && !local_rows) || !all_rows || !counts)
+    if (!c || n_local < -1 || capacity < 1 || (n_local > 0 && !local_rows) || !all_rows || !counts)
         return iss_fail(c, ISS_EINVAL, "iss_allgather_segments: bad argument");
     if (!c->comm) return iss_fail(c, ISS_ESTATE, "iss_allgather_segments: call iss_comm_init first");
     ISS_HIP(c, hipSetDevice(c->device));
@@ -110,7 +149,7 @@ extern "C" int iss_allgather_segments(iss_ctx* c, const int32_t* local_rows, int
     if ((rc = iss_reserve(c, c->comm_recv, slab * 4 * world))) return rc;
     // header row (n_rows, capacity, rank, 0) + the first min(n_local, capacity) rows, through a pinned staging buffer
     std::vector<int32_t> buf(slab, 0);
-    buf[0] = n_local; buf[1] = capacity; buf[2] = c->comm_rank;
+    buf[0] = n_local; buf[1] = capacity; buf[2] = c->comm_rank;     // n_local == -1: "my local work failed" (see iss.h)
     const int k = n_local < capacity ? n_local : capacity;
     if (k > 0) memcpy(&buf[4], local_rows, (size_t)k * 16);
     void* pinned; int slot;
@@ -118,15 +157,16 @@ extern "C" int iss_allgather_segments(iss_ctx* c, const int32_t* local_rows, int
     ISS_HIP(c, hipMemcpyAsync(c->comm_send.p, pinned, slab * 4, hipMemcpyHostToDevice, c->stream));
     iss_stage_mark(c, slot);
     ISS_NCCL(c, g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, slab, NCCL_INT32, (NcclComm)c->comm, c->stream));
+    if ((rc = wait_collective(c, "iss_allgather_segments"))) return rc;      // (before the read-back: a copy into pageable memory blocks)
     std::vector<int32_t> got(slab * world);
     ISS_HIP(c, hipMemcpyAsync(got.data(), c->comm_recv.p, slab * 4 * world, hipMemcpyDeviceToHost, c->stream));
     ISS_HIP(c, hipStreamSynchronize(c->stream));
     for (int r = 0; r < world; ++r) {
         const int32_t* s = &got[(size_t)r * slab];
         if (s[1] != capacity || s[2] != r) return iss_fail(c, ISS_ESTATE, "iss_allgather_segments: rank %d sent capacity %d / rank %d (expected %d / %d)", r, s[1], s[2], capacity, r);
-        counts[r] = s[0];
+        counts[r] = s[0];                                         // -1: rank r reports that its local work failed
         const int kk = s[0] < capacity ? s[0] : capacity;
-        memcpy(all_rows + (size_t)r * capacity * 4, s + 4, (size_t)kk * 16);
+        if (kk > 0) memcpy(all_rows + (size_t)r * capacity * 4, s + 4, (size_t)kk * 16);
     }
     return ISS_OK;
 }
@@ -140,7 +180,22 @@ extern "C" int iss_comm_allreduce_max(iss_ctx* c, double* value) {
     ISS_HIP(c, hipMemcpyAsync(c->comm_send.p, value, 8, hipMemcpyHostToDevice, c->stream));
     ISS_HIP(c, hipStreamSynchronize(c->stream));
     ISS_NCCL(c, g_rccl.AllReduce(c->comm_send.p, (char*)c->comm_send.p + 16, 1, NCCL_FLOAT64, NCCL_MAX, (NcclComm)c->comm, c->stream));
+    if ((rc = wait_collective(c, "iss_comm_allreduce_max"))) return rc;
     ISS_HIP(c, hipMemcpyAsync(value, (char*)c->comm_send.p + 16, 8, hipMemcpyDeviceToHost, c->stream));
     ISS_HIP(c, hipStreamSynchronize(c->stream));
+    return ISS_OK;
+}
+
+extern "C" int iss_comm_info(iss_ctx* c, int32_t* world, int32_t* rank, int32_t* version, char* lib_path, int32_t lib_path_len) {
+    if (!c) return ISS_EINVAL;
+    if (!c->comm) return iss_fail(c, ISS_ESTATE, "iss_comm_info: call iss_comm_init first");
+    int n = 0, r = 0, v = 0;
+    ISS_NCCL(c, g_rccl.CommCount((NcclComm)c->comm, &n));      // what RCCL itself says, not what iss_comm_init was told
+    ISS_NCCL(c, g_rccl.CommUserRank((NcclComm)c->comm, &r));
+    (void)g_rccl.GetVersion(&v);
+    if (world) *world = n;
+    if (rank) *rank = r;
+    if (version) *version = v;
+    if (lib_path && lib_path_len > 0) { strncpy(lib_path, g_rccl.path.c_str(), (size_t)lib_path_len - 1); lib_path[lib_path_len - 1] = 0; }
     return ISS_OK;
 }

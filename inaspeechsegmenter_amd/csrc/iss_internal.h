@@ -92,10 +92,10 @@ struct iss_ctx {
 
     // profiling
     bool prof = false;
-    double prof_ms[3] = {0, 0, 0};
-    int64_t prof_launch[3] = {0, 0, 0};
-    double prof_flops[3] = {0, 0, 0};
-    struct Pending { hipEvent_t a, b; int kind; double flops; };
+    double prof_ms[ISS_PROF_KINDS] = {};
+    int64_t prof_launch[ISS_PROF_KINDS] = {};
+    double prof_flops[ISS_PROF_KINDS] = {};
+    struct Pending { hipEvent_t a, b; int kind; int sub; double flops; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_pool;
 };
@@ -115,6 +115,7 @@ void iss_stage_mark(iss_ctx* c, int slot);                                      
 
 // profiling brackets: record events around a kernel class when enabled
 void iss_prof_begin(iss_ctx* c, int kind, double flops);
+void iss_prof_tag(iss_ctx* c, int sub);      // kernel class (ISS_PROF_* >= 3) of the launch bracketed last: counted there too
 void iss_prof_end(iss_ctx* c);
 void iss_prof_collect(iss_ctx* c);
 

@@ -15,7 +15,8 @@
 //   3. Hann window in float64 (:223,231), 512-point real FFT in float64 as one 256-point
 //      complex radix-4 DIF FFT held in LDS + real-input untangle, twiddles staged in LDS
 //   4. |X|^2 in float64, stored as float32 (:233)
-//   5. 24 triangular mel filters (454 non-zeros, LDS-resident rows), log (:334)
+//   5. 24 triangular mel filters (454 non-zeros, LDS-resident rows, float32 FMA chains), log (:334); the log-energy and
+//      the 24 bands share ONE float64 log call (lane 24 carries the energy)
 // float64 is deliberate: the reference's FFT is float64 (window promotes) and the labels
 // hinge on `loge > threshold`; this stage is ~4 GFLOP per audio-hour, nowhere near a bound.
 #include "iss_internal.h"
@@ -97,22 +98,27 @@ __global__ __launch_bounds__(256) void sidekit_kernel(const SampleT* __restrict_
         wave_sync();
 
         // ---- 2. log-energy in numpy's pairwise order (sidekit_mfcc.py:226) -------------------
+        // all 13 values of a lane's strided chain are read first (independent LDS reads), then summed in order; the sum
+        // of squares is broadcast and its logarithm is taken in stage 5 by lane 24, in the SAME f64 log call as the 24
+        // mel bands (the kernel is f64-VALU-issue-bound: one ~80-instruction log per frame instead of two)
+        float esum = 0.f;
         if (live) {
             const int l = lane & 31, blk = l >> 3, j = l & 7;
             const int start = (blk == 0) ? 0 : (blk == 1) ? 96 : (blk == 2) ? 200 : 296;
-            const int len = (blk & 1) ? 104 : 96;
-            float v = y[start + j];
-            float acc = __fmul_rn(v, v);
-            for (int i = 8; i < len; i += 8) {
-                v = y[start + i + j];
-                acc = __fadd_rn(acc, __fmul_rn(v, v));
-            }
+            const bool longer = blk & 1;                              // 104 values instead of 96
+            float v[13];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) v[i] = y[start + 8 * (i < 12 || longer ? i : 11) + j];
+            float acc = __fmul_rn(v[0], v[0]);
+#pragma unroll
+            for (int i = 1; i < 12; ++i) acc = __fadd_rn(acc, __fmul_rn(v[i], v[i]));
+            if (longer) acc = __fadd_rn(acc, __fmul_rn(v[12], v[12]));
             acc = __fadd_rn(acc, __shfl_xor(acc, 1));
             acc = __fadd_rn(acc, __shfl_xor(acc, 2));
             acc = __fadd_rn(acc, __shfl_xor(acc, 4));
             acc = __fadd_rn(acc, __shfl_xor(acc, 8));
             acc = __fadd_rn(acc, __shfl_xor(acc, 16));
-            if (lane == 0) loge[t] = (float)log((double)acc);
+            esum = __shfl(acc, 0);
         }
 
         // ---- 3. Hann (f64) + first radix-4 stage straight from y -----------------------------
@@ -146,25 +152,30 @@ __global__ __launch_bounds__(256) void sidekit_kernel(const SampleT* __restrict_
         }
         wave_sync();
 
-        // ---- 5. mel bank + log (sidekit_mfcc.py:334) ----------------------------------------
-        if (live && lane < 24) {
-            // up to 48 bins per filter: four independent float64 chains over 8-bin groups keep 16 LDS reads in
-            // flight instead of one dependent read+FMA per bin (this loop was the latency chain of the kernel)
-            const int lo = s_lim[lane * 3], nb = s_lim[lane * 3 + 1], off = s_lim[lane * 3 + 2];
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            int i = 0;
-            for (; i + 8 <= nb; i += 8) {
-                float sp[8], w[8];
+        // ---- 5. mel bank + log (sidekit_mfcc.py:334), and the frame's log-energy ---------------
+        if (live && lane < 25) {
+            // lanes 0..23: one mel band each (up to 48 bins): the reference's `spec @ fbank.T` is a float32 product
+            // (sgemm), so four independent float32 FMA chains over 8-bin groups (16 LDS reads in flight; accumulating in
+            // float64 cost two v_cvt_f64_f32 per bin at the f64 issue rate).  Lane 24: the sum of squares of stage 2.
+            // One float64 log for all 25 lanes: correctly rounded float32 results, like the reference's np.log on float32.
+            float arg = esum;
+            if (lane < 24) {
+                const int lo = s_lim[lane * 3], nb = s_lim[lane * 3 + 1], off = s_lim[lane * 3 + 2];
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                int i = 0;
+                for (; i + 8 <= nb; i += 8) {
+                    float sp[8], w[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { sp[q] = spec[lo + i + q]; w[q] = s_melw[off + i + q]; }
-                a0 += (double)sp[0] * (double)w[0]; a1 += (double)sp[1] * (double)w[1];
-                a2 += (double)sp[2] * (double)w[2]; a3 += (double)sp[3] * (double)w[3];
-                a0 += (double)sp[4] * (double)w[4]; a1 += (double)sp[5] * (double)w[5];
-                a2 += (double)sp[6] * (double)w[6]; a3 += (double)sp[7] * (double)w[7];
+                    for (int q = 0; q < 8; ++q) { sp[q] = spec[lo + i + q]; w[q] = s_melw[off + i + q]; }
+                    a0 = fmaf(sp[0], w[0], a0); a1 = fmaf(sp[1], w[1], a1); a2 = fmaf(sp[2], w[2], a2); a3 = fmaf(sp[3], w[3], a3);
+                    a0 = fmaf(sp[4], w[4], a0); a1 = fmaf(sp[5], w[5], a1); a2 = fmaf(sp[6], w[6], a2); a3 = fmaf(sp[7], w[7], a3);
+                }
+                for (; i < nb; ++i) a0 = fmaf(spec[lo + i], s_melw[off + i], a0);
+                arg = (a0 + a1) + (a2 + a3);
             }
-            for (; i < nb; ++i) a0 += (double)spec[lo + i] * (double)s_melw[off + i];
-            const double acc = (a0 + a1) + (a2 + a3);
-            mspec[(size_t)t * 24 + lane] = (float)log((double)(float)acc);
+            const float r = (float)log((double)arg);
+            if (lane < 24) mspec[(size_t)t * 24 + lane] = r;
+            else loge[t] = r;
         }
         wave_sync();
     }

@@ -134,19 +134,51 @@ __global__ __launch_bounds__(256) void vbx_fbank_kernel(const SampleT* __restric
 }
 
 // f[0] = 0, f[t+1] = f[t] + x[t]   (np.r_[zeros, np.cumsum(x, 0)], features_vbx.py:145)
+// np.cumsum's order is sequential in time, so the sum is ONE dependent chain of f64 adds per channel: one wavefront
+// (lane = channel).  What must not sit on that chain is memory latency: rows are fetched in register blocks of 32, the
+// block after the current one is always in flight (two named blocks, loop unrolled by two, no branch between a block's
+// loads and the adds that hide them), so a row costs its v_add_f64 + store issue instead of 1/8 of an HBM round trip
+// (the round-2 kernel: 8 loads, wait, 8 adds -- 62 ns per row, 22 ms per audio-hour, 87 % of the feature stage).
 __global__ __launch_bounds__(64) void vbx_cumsum_kernel(const double* __restrict__ fb, int T, double* __restrict__ f) {
+    constexpr int B = 32;
     const int lane = threadIdx.x;
     double acc = 0.0;
     f[lane] = 0.0;
     int t = 0;
-    for (; t + 8 <= T; t += 8) {
+    const double* src = fb + lane;
+    double* dst = f + 64 + lane;
+    if (T >= 2 * B) {
+        double va[B], vb[B];
+        const long long last = (long long)(T - B) * 64;              // first row of the last whole block that exists
+#pragma unroll
+        for (int q = 0; q < B; ++q) va[q] = src[(size_t)q * 64];
+        // invariant at the top: va = rows [t, t + B), and t + 2 B <= T
+        while (true) {
+#pragma unroll
+            for (int q = 0; q < B; ++q) vb[q] = src[(size_t)(t + B + q) * 64];
+#pragma unroll
+            for (int q = 0; q < B; ++q) { acc = __dadd_rn(acc, va[q]); dst[(size_t)(t + q) * 64] = acc; }
+            const bool more = t + 4 * B <= T;
+            {   // rows [t + 2 B, t + 3 B) for the next round (clamped to rows that exist: read, not used, on the last one)
+                long long o = (long long)(t + 2 * B) * 64;
+                o = o < last ? o : last;
+#pragma unroll
+                for (int q = 0; q < B; ++q) va[q] = src[o + q * 64];
+            }
+#pragma unroll
+            for (int q = 0; q < B; ++q) { acc = __dadd_rn(acc, vb[q]); dst[(size_t)(t + B + q) * 64] = acc; }
+            t += 2 * B;
+            if (!more) break;
+        }
+    }
+    for (; t + 8 <= T; t += 8) {                                     // < 4 B rows left
         double v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = fb[(size_t)(t + q) * 64 + lane];
+        for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(t + q) * 64];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { acc = __dadd_rn(acc, v[q]); f[(size_t)(t + q + 1) * 64 + lane] = acc; }
+        for (int q = 0; q < 8; ++q) { acc = __dadd_rn(acc, v[q]); dst[(size_t)(t + q) * 64] = acc; }
     }
-    for (; t < T; ++t) { acc = __dadd_rn(acc, fb[(size_t)t * 64 + lane]); f[(size_t)(t + 1) * 64 + lane] = acc; }
+    for (; t < T; ++t) { acc = __dadd_rn(acc, src[(size_t)t * 64]); dst[(size_t)t * 64] = acc; }
 }
 
 __global__ void vbx_cmn_kernel(const double* __restrict__ fb, const double* __restrict__ f, int T, int LC, int win_len,

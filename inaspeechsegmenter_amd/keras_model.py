@@ -523,11 +523,30 @@ def compile_resnet101(params, feat_dim=64, frames=144, eps=1e-5, window_input=Fa
 
 
 # ------------------------------------------------------------------------------ synthetic nets
-def synthetic_ina_like(nmel, nclasses, seed=0):
+_STANDIN_HEADS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'standin_heads.npz')
+# (nmel, nclasses, seed) of the three networks Segmenter(models='synthetic') builds -> key in standin_heads.npz
+_STANDIN_KEYS = {(21, 3, 1): 'smn', (21, 2, 1): 'sm', (24, 2, 2): 'gender'}
+
+
+def standin_head(nmel, nclasses, seed):
+    """(W (128, C), b (C,)) of the calibrated last layer for the stand-ins Segmenter(models='synthetic') uses, or None.
+    Fitted once on the CPU oracle by tests/golden/make_standin_heads.py (ridge least squares on the bench generator's ground
+    truth and on the labels of the reference's golden CSVs for media/musanmix.wav) so that the stand-ins DECIDE: a random
+    head answers one class on > 99.8 % of all slots, which turns every label test into a test of the energy detector."""
+    key = _STANDIN_KEYS.get((nmel, nclasses, seed))
+    if key is None or not os.path.exists(_STANDIN_HEADS):
+        return None
+    z = np.load(_STANDIN_HEADS)
+    return np.asarray(z[key + '_W'], np.float32), np.asarray(z[key + '_b'], np.float32)
+
+
+def synthetic_ina_like(nmel, nclasses, seed=0, head='auto'):
     """A seeded stand-in for the un-vendored Keras CNNs: same I/O contract
     ((68,nmel,1) -> nclasses softmax, segmenter.py:146-163,184-204) and the ~1.25 M
     parameter budget the reference quotes (Dockerfile:18), topology chosen here:
-    4 x [conv-BN-relu] with two max-pools, two dense layers, softmax."""
+    4 x [conv-BN-relu] with two max-pools, two dense layers, softmax.
+    head: 'auto' -> the calibrated last layer of `standin_head` when one exists for (nmel, nclasses, seed), else the seeded
+    random one; None -> always the random one; (W, b) -> that one."""
     rng = np.random.default_rng(seed)
 
     def conv(kh, kw, cin, cout):
@@ -553,6 +572,12 @@ def synthetic_ina_like(nmel, nclasses, seed=0):
     L += [dict(type='maxpool', pool=(2, 1), strides=(2, 1), padding='valid')]; h = h // 2
     L += [dict(type='flatten'), dense(h * w * 128, 192, 'linear'), bn(192), relu, dict(type='dropout'),
           dense(192, 128, 'relu'), dense(128, nclasses, 'softmax')]
+    if isinstance(head, str) and head == 'auto':
+        head = standin_head(nmel, nclasses, seed)
+    if head is not None:
+        W, b = head
+        assert W.shape == (128, nclasses) and b.shape == (nclasses,)
+        L[-1] = dict(type='dense', W=np.asarray(W, np.float32), b=np.asarray(b, np.float32), activation='softmax')
     return L, (68, nmel, 1)
 
 

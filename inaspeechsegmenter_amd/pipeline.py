@@ -43,7 +43,27 @@ class _Batch:
         return sum(-(-s.size // FRAME_HOP) * FRAME_HOP for s in self.sigs)
 
 
-def _decode_stage(items, ffmpeg, nbtry, trydelay, out_q, nthreads):
+class _AudioBudget:
+    """Bounds the decoded-but-not-yet-packed audio by DURATION (the item count of the queue says nothing about memory:
+    a 2 h file is 230 MB of PCM16).  A decode thread that holds a decoded signal waits until the signals queued in front
+    of it fit the budget again; a single signal larger than the budget passes when nothing else is queued."""
+
+    def __init__(self, max_samples):
+        self.max, self.held, self.cv = int(max_samples), 0, threading.Condition()
+
+    def acquire(self, n):
+        with self.cv:
+            while self.held > 0 and self.held + n > self.max:
+                self.cv.wait(0.5)
+            self.held += n
+
+    def release(self, n):
+        with self.cv:
+            self.held -= n
+            self.cv.notify_all()
+
+
+def _decode_stage(items, ffmpeg, nbtry, trydelay, out_q, nthreads, budget=None):
     """items: [(index, src)].  Puts (index, src, sig | None, errtext | None) on out_q in completion order, then None."""
     import random
     in_q = queue.Queue()
@@ -65,6 +85,8 @@ def _decode_stage(items, ffmpeg, nbtry, trydelay, out_q, nthreads):
                     err = 'error: ' + str(sys.exc_info()[0])
                     if itry != nbtry:
                         time.sleep(random.random() * trydelay)
+            if budget is not None and sig is not None:
+                budget.acquire(sig.size)
             out_q.put((i, src, sig, err))
 
     ths = [threading.Thread(target=work, daemon=True) for _ in range(max(1, nthreads))]
@@ -106,6 +128,12 @@ class _Worker:
                 self.ctx.pinned_free(self.pin)
             self.pin = self.ctx.pinned_empty((int(nsamples * 1.25) + 4096,), np.int16)
         return self.pin
+
+    def sync_settings(self):
+        """Arithmetic mode and workspace cap follow the Segmenter's own context (they may have changed since this
+        worker was created: the workers are cached between calls)."""
+        if self.owned:
+            self.ctx.mirror_settings(self.seg.ctx)
 
     def run(self, batch):
         """-> [ [(label, start_slot, stop_slot)] per file of the batch ]"""
@@ -166,13 +194,17 @@ class _Worker:
 
 def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch_files=32, batch_seconds=3 * 3600,
                   workers=2, decode_threads=4):
-    """Segment `linput` with the networks of `seg`; on_result(index, src, lseg | None, errtext | None) is called from the
-    worker threads (serialised by a lock) as results become available, lseg = [(label, start_sec, stop_sec)].
-    skip: set of indices not to process.  Device failures (NativeError) propagate to the caller."""
+    """Segment `linput` with the networks of `seg`; on_result(index, src, lseg | None, errtext | None, secs) is called from
+    the worker threads (serialised by a lock) as results become available, lseg = [(label, start_sec, stop_sec)], secs =
+    this file's share of the processing time of its device pass (the pass's wall time / its files: what the reference's
+    per-file 'ok <secs>' message reports, segmenter.py:322-327, when files are processed one by one).
+    skip: set of indices not to process.  Device failures (NativeError) and exceptions raised by on_result (unwritable
+    outputs) propagate to the caller: the first one is re-raised here once every stage has drained."""
     from . import segmenter as S
     items = [(i, src) for i, src in enumerate(linput) if not (skip and i in skip)]
     dec_q = queue.Queue(maxsize=4 * batch_files)
-    _decode_stage(items, seg.ffmpeg, nbtry, trydelay, dec_q, decode_threads)
+    budget = _AudioBudget(2 * batch_seconds * 16000)        # decoded audio waiting for the packer: <= 2 super-batches
+    _decode_stage(items, seg.ffmpeg, nbtry, trydelay, dec_q, decode_threads, budget)
     batch_q = queue.Queue(maxsize=max(2, workers))
     lock = threading.Lock()
     failure = []
@@ -185,9 +217,16 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
                 if it is None:
                     break
                 i, src, sig, err = it
+                if sig is not None:
+                    budget.release(sig.size)
+                if failure:                                        # a worker failed: drain the decoders, pack nothing more
+                    continue
                 if sig is None:
-                    with lock:
-                        on_result(i, src, None, err)
+                    try:
+                        with lock:
+                            on_result(i, src, None, err, 0.0)
+                    except BaseException as exc:                   # noqa: B902
+                        failure.append(exc)
                     continue
                 if sig.dtype != np.int16 or sig.size < MIN_SAMPLES:
                     batch_q.put(('single', i, src, sig))
@@ -203,13 +242,17 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
                 batch_q.put(None)
 
     def work(w):
-        try:
-            while True:
-                job = batch_q.get()
-                if job is None:
-                    return
-                if failure:
-                    continue
+        # A failure (device error, or an exception out of on_result) is recorded and the loop KEEPS consuming batch_q until
+        # the packer's end marker: a worker that simply returned would leave the packer blocked on the bounded queue (and
+        # the decode threads behind it) with nobody left to drain it, and process_files would hang instead of raising.
+        while True:
+            job = batch_q.get()
+            if job is None:
+                return
+            if failure:
+                continue
+            try:
+                t0 = time.time()
                 if job[0] == 'single':
                     _, i, src, sig = job
                     try:
@@ -221,15 +264,16 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
                     except ValueError as exc:                      # too short to analyse: a per-file error
                         res = (None, 'error: %s %s' % (type(exc), exc))
                     with lock:
-                        on_result(i, src, res[0], res[1])
+                        on_result(i, src, res[0], res[1], time.time() - t0)
                     continue
                 b = job[1]
                 lsegs = w.run(b)
+                share = (time.time() - t0) / max(len(b.idx), 1)
                 with lock:
                     for i, src, lseg in zip(b.idx, b.names, lsegs):
-                        on_result(i, src, [(lab, a * .02, c * .02) for lab, a, c in lseg], None)
-        except BaseException as exc:                               # noqa: B902  propagate to the caller's thread
-            failure.append(exc)
+                        on_result(i, src, [(lab, a * .02, c * .02) for lab, a, c in lseg], None, share)
+            except BaseException as exc:                           # noqa: B902  propagate to the caller's thread
+                failure.append(exc)
 
     # device workers are kept with the Segmenter between calls (context creation, network upload and the first
     # workspace allocation cost more than a 5-minute file)
@@ -237,6 +281,8 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
     while len(cache) < max(1, workers):
         cache.append(_Worker(seg, seg.ctx if not cache else None))
     ws = cache[:max(1, workers)]
+    for w in ws:
+        w.sync_settings()
     threads = [threading.Thread(target=work, args=(w,), daemon=True) for w in ws]
     pk = threading.Thread(target=packer, daemon=True)
     pk.start()

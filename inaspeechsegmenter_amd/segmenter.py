@@ -386,13 +386,16 @@ class Segmenter:
                 if dname and not os.path.isdir(dname):
                     os.makedirs(dname, exist_ok=True)
 
-        def on_result(i, src, lseg, err):
+        def on_result(i, src, lseg, err, secs=0.0):
             dst = loutput[i]
             if lseg is None:
                 msgs[i] = (dst, 2, err)
             else:
+                b = time.time()
                 fexport(lseg, dst)
-                msgs[i] = (dst, 0, 'ok ' + str(time.time() - t_batch_start))
+                # per-file processing time as in segmenter.py:322-327 (networks + smoothing + export, features excluded
+                # there; here: this file's share of its device pass + its export)
+                msgs[i] = (dst, 0, 'ok ' + str(secs + time.time() - b))
             done[0] += 1
             if verbose:
                 print('%d/%d' % (done[0] + len(skip), len(linput)), [msgs[i]])

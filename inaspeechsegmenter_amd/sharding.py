@@ -52,8 +52,19 @@ def unpack_segments(rows, start_sec=0):
     return out
 
 
+class RankFailure(RuntimeError):
+    """Some rank reported that its local work failed (header count -1): every rank raises, none keeps a partial table."""
+
+
+def _check_counts(counts):
+    bad = [r for r, n in enumerate(counts) if int(n) < 0]
+    if bad:
+        raise RankFailure('rank(s) %s failed before the all-gather of the segment tables; no table was assembled' % bad)
+
+
 def _merge_gathered(parts, counts, capacity, regather):
     """parts[r]: (capacity,4) rows of rank r, counts[r] = rows it has; one larger gather if someone overflowed."""
+    _check_counts(counts)
     need = int(max(counts))
     if need > capacity:                      # rare: some rank had more rows than agreed -> one bigger gather
         parts, counts = regather(need)
@@ -68,9 +79,14 @@ class RcclComm:
         self.ctx, self.rank, self.world = ctx, ctx.comm_rank, ctx.comm_world
 
     def allgather(self, rows, capacity):
-        rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
+        """rows = None: this rank's local work failed -- it still takes part so that the others learn about it."""
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
         first = self.ctx.allgather_segments(rows, int(capacity))
         return _merge_gathered(first[0], first[1], int(capacity), lambda cap: self.ctx.allgather_segments(rows, cap))
+
+    def info(self):
+        return self.ctx.comm_info()
 
     def max_over_ranks(self, value):
         return self.ctx.comm_allreduce_max(value)
@@ -122,7 +138,9 @@ def exchange_unique_id(uid, rank, world, addr=None, port=None, timeout=120.0):
         from torch.distributed import TCPStore
         store = TCPStore(os.environ.get('MASTER_ADDR', '127.0.0.1'), int(os.environ['MASTER_PORT']), world, False,
                          timedelta(seconds=timeout))
-        key = 'iss_rccl_unique_id_%d' % _uid_round[0]
+        # the agent's store outlives worker restarts: key the id by the restart count as well, or a restarted rank > 0
+        # could read the previous incarnation's id before rank 0 has published the new one
+        key = 'iss_rccl_unique_id_r%s_%d' % (os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), _uid_round[0])
         _uid_round[0] += 1
         if rank == 0:
             store.set(key, bytes(uid))
@@ -142,7 +160,15 @@ def exchange_unique_id(uid, rank, world, addr=None, port=None, timeout=120.0):
                 conn, _ = srv.accept()
                 with conn:
                     conn.settimeout(timeout)
-                    r = int.from_bytes(conn.recv(4), 'little')
+                    hdr = b''
+                    while len(hdr) < 4:                            # a 4-byte read may come back short
+                        chunk = conn.recv(4 - len(hdr))
+                        if not chunk:
+                            break
+                        hdr += chunk
+                    r = int.from_bytes(hdr, 'little') if len(hdr) == 4 else -1
+                    if not 0 < r < world:                          # not one of ours: no id for it
+                        continue
                     conn.sendall(uid)
                     seen.add(r)
         finally:
@@ -179,7 +205,8 @@ def allgather_segment_tables(rows, capacity=4096, device=None, group=None):
     rank) back as one (K,4) int32 array.  One collective when every k <= capacity."""
     import torch
     import torch.distributed as dist
-    rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
+    failed = rows is None                    # this rank's local work failed: header count -1, no rows
+    rows = np.zeros((0, 4), np.int32) if failed else np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     backend = dist.get_backend(group)
@@ -188,7 +215,7 @@ def allgather_segment_tables(rows, capacity=4096, device=None, group=None):
 
     def gather(cap):
         buf = np.zeros((cap + 1, 4), dtype=np.int32)
-        buf[0] = (len(rows), cap, rank, 0)
+        buf[0] = (-1 if failed else len(rows), cap, rank, 0)
         k = min(len(rows), cap)
         buf[1:1 + k] = rows[:k]
         send = torch.from_numpy(buf).to(device)
@@ -197,6 +224,7 @@ def allgather_segment_tables(rows, capacity=4096, device=None, group=None):
         return recv.cpu().numpy().reshape(world, cap + 1, 4)
 
     got = gather(int(capacity))
+    _check_counts(got[:, 0, 0])
     need = int(got[:, 0, 0].max())
     if need > capacity:                      # rare: some rank had more rows than agreed -> one bigger gather
         got = gather(need)

@@ -33,6 +33,7 @@ extern "C" {
 #define ISS_EHIP     -3   /* a HIP runtime call failed (text in last_error)     */
 #define ISS_ESTATE   -4   /* call order violated (e.g. features before signal)  */
 #define ISS_ENOMEM   -5
+#define ISS_ETIMEOUT -6   /* a collective did not complete (peer rank gone): communicator aborted */
 
 typedef struct iss_ctx iss_ctx;
 
@@ -204,16 +205,33 @@ int iss_comm_init(iss_ctx* ctx, const uint8_t id[ISS_COMM_ID_BYTES], int32_t ran
 int iss_comm_destroy(iss_ctx* ctx);
 /* local_rows: (n_local,4) int32.  all_rows: (world*capacity,4) int32, rank r's rows start at
  * r*capacity; counts[r] = rows rank r HAS (may exceed capacity: then only the first
- * `capacity` arrived and the caller repeats the call with capacity >= max(counts)).     */
+ * `capacity` arrived and the caller repeats the call with capacity >= max(counts)).
+ * Failure handling (the reference's Pyro workers fail independently, scripts/ina_speech_segmenter_pyro_client.py:64-74;
+ * a collective cannot): a rank whose local work failed still takes part with n_local = -1, every rank then sees
+ * counts[r] == -1 and raises; a rank that is GONE makes the others wait ISS_COMM_TIMEOUT_S seconds (environment,
+ * default 1800), after which the communicator is aborted (ncclCommAbort) and the call returns ISS_ETIMEOUT.          */
 int iss_allgather_segments(iss_ctx* ctx, const int32_t* local_rows, int32_t n_local, int32_t capacity,
                            int32_t* all_rows, int32_t* counts /* world */);
 /* max over ranks of a double (bench timing) and a barrier, on the same communicator */
 int iss_comm_allreduce_max(iss_ctx* ctx, double* value);
+/* what RCCL itself reports for the communicator: ncclCommCount / ncclCommUserRank / ncclGetVersion and the path of
+ * the librccl that was bound (audit trail of the multi-GPU bench line) */
+int iss_comm_info(iss_ctx* ctx, int32_t* world, int32_t* rank, int32_t* version, char* lib_path, int32_t lib_path_len);
 
 /* ------------------------------------------------------------ profiling hooks */
-/* Accumulated device time (ms, hipEvent-timed on the context's stream) and launch
- * count of the dominant kernel classes since the last reset.  kind: 0 = conv/dense
- * implicit-GEMM kernels, 1 = sidekit front end, 2 = everything else.             */
+/* Accumulated device time (ms, hipEvent-timed on the context's stream), launch count and algorithmic flops of the
+ * kernel classes since the last reset.  kind: 0 = all conv/dense implicit-GEMM kernels, 1 = sidekit / vbx fbank front
+ * end, 2 = everything else; 3.. = the GEMM kernels one by one (each launch counted in 0 AND in its own class).       */
+#define ISS_PROF_GEMM      0
+#define ISS_PROF_FRONTEND  1
+#define ISS_PROF_OTHER     2
+#define ISS_PROF_WS        3   /* conv_x3_ws_kernel   (weight-stationary footprint kernel) */
+#define ISS_PROF_FP        4   /* conv_x3_fp_kernel   (streaming-weights footprint kernel) */
+#define ISS_PROF_PW        5   /* conv_x3_pw_kernel   (1x1 / dense persistent GEMM) */
+#define ISS_PROF_GATHER    6   /* conv_x3_kernel      (generic gather GEMM) */
+#define ISS_PROF_PATCH1    7   /* conv1_patch_x3_kernel (per-window first layer) */
+#define ISS_PROF_F32       8   /* conv_igemm_kernel   (exact-f32 MFMA mode) */
+#define ISS_PROF_KINDS     9
 int iss_prof_enable(iss_ctx* ctx, int on);
 int iss_prof_get(iss_ctx* ctx, int kind, double* ms, int64_t* launches, double* flops);
 int iss_prof_reset(iss_ctx* ctx);

@@ -109,3 +109,60 @@ def test_joblist_matches_reference_server_semantics():
     assert a.lsource == b.lsource and a.get_njobs('', 3)[0] == b.lsource[:3] and a.has_more_jobs()
     pairs = dict(zip(*archive.JobList(os.path.join(GOLDEN, 'pyroserver_test.csv'), shuffle=False).get_njobs('')))
     assert pairs['my_source_1'] == 'my_dest_1' and pairs['/my_/source_4'] == 'my_dest_4'
+
+
+def _failing_worker(rank, port, lin, lout, q, mode):
+    """Rank 1 fails before the all-gather: 'raise' = its local work throws (it still takes part, flagged);
+    'die' = the process is gone (the survivors hit the process group's timeout)."""
+    from datetime import timedelta
+    import torch.distributed as dist
+    from inaspeechsegmenter_amd import _native, sharding
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=2, timeout=timedelta(seconds=8))
+
+    def seg(path):
+        if rank == 1:
+            if mode == 'die':
+                os._exit(7)
+            raise _native.NativeError('device fault on rank 1 (simulated)')     # not a per-file error: propagates
+        return _fake_segment(path)
+    try:
+        archive.segment_archive(seg, lin, lout)
+        q.put((rank, 'no error'))
+    except sharding.RankFailure as e:
+        q.put((rank, 'RankFailure: %s' % e))
+    except _native.NativeError as e:
+        q.put((rank, 'NativeError: %s' % e))
+    except Exception as e:                                     # gloo: connection closed by peer / timed out
+        q.put((rank, 'comm error: %s' % type(e).__name__))
+    q.close()
+    q.join_thread()                                            # flush the result before leaving without teardown
+    os._exit(0)                                                # no orderly process-group teardown with a dead peer
+
+
+@pytest.mark.parametrize('mode', ['raise', 'die'])
+def test_rank_failure_is_loud_on_every_rank(tmp_path, mode):
+    """SURVEY 8(e) hardening: a rank that fails (or disappears) before the all-gather must not leave the others waiting
+    (the reference's Pyro workers fail independently, ina_speech_segmenter_pyro_client.py:64-74; a collective cannot)."""
+    import time
+    import torch.multiprocessing as mp
+    lin, lout = _files(tmp_path)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, port, lin, lout, q, mode)) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    want = 2 if mode == 'raise' else 1
+    res = dict(q.get(timeout=90) for _ in range(want))
+    for p in procs:
+        p.join(timeout=30)
+    assert time.time() - t0 < 90
+    if mode == 'raise':
+        assert res[1].startswith('NativeError') and 'simulated' in res[1]      # the failing rank reports ITS error
+        assert res[0].startswith('RankFailure') and '[1]' in res[0]            # the other one learns who failed
+    else:
+        assert procs[1].exitcode == 7
+        assert res[0].startswith('comm error') or res[0].startswith('RankFailure'), res

@@ -54,6 +54,47 @@ def test_musanmix_identical_to_oracle_pipeline(seg):
     assert seg.segment_signal(pcm) == _oracle_segmentation(seg, pcm)
 
 
+def test_musanmix_reference_golden_csv_byte_identical(seg, tmp_path):
+    """run_test.py:90-105 test_processingresult shape: the CSV written for media/musanmix.wav equals the reference's golden
+    file byte for byte -- labels the NETWORKS decide (music, noise, noise, male, male, male) included.  The stand-in networks
+    were calibrated on the CPU oracle to reproduce these labels (tests/golden/make_standin_heads.py); what this test adds is
+    that the GPU engine makes the same decisions with them: a kernel bug that moved the probabilities would change rows."""
+    out = tmp_path / 'musanmix.csv'
+    seg2csv(seg(os.path.join(GOLDEN, 'musanmix.wav')), str(out))
+    assert filecmp.cmp(str(out), os.path.join(GOLDEN, 'musanmix-smn-gender.csv'), shallow=False), open(out).read()
+
+
+def test_networks_decide(seg):
+    """Guard against a degenerate stand-in: on musanmix every VAD class wins > 10 % of the evaluated slots, on the
+    generator's recording every class of both networks wins >= 15 % and >= 3 boundaries are CNN-driven; the GPU's arg-max
+    equals the oracle's on every evaluated slot."""
+    import bench
+    from inaspeechsegmenter_amd import segmenter as S
+    pcm = read_wav_int16(os.path.join(GOLDEN, 'musanmix.wav'))
+    mspec, loge, difflen = osk.media2feats((pcm / 32768.0).astype(np.float32))
+    l0 = oseg.energy_seglist(loge, 0.03)
+    l1, raw = oseg.dnn_segment('smn', lambda b: ocnn.forward(seg.vad.layers, b), mspec, l0, difflen, return_raw=True)
+    seg.segment_signal(pcm)                                                   # leaves musanmix's features resident
+    idx = np.concatenate([np.arange(a, b) for lab, a, b in l0 if lab == 'energy'])
+    p, fin = seg.ctx.cnn_probs(0, S._window_rows(len(loge))[idx])
+    hist = np.bincount(p.argmax(1), minlength=3) / len(p)
+    assert hist.min() > 0.10, hist
+    srt = np.sort(raw, axis=1)
+    decided = (srt[:, -1] - srt[:, -2]) > 1e-3                                # (a near-tie may go either way within 1e-4)
+    assert np.array_equal(p.argmax(1)[decided], raw.argmax(1)[decided]) and decided.mean() > 0.99
+    assert np.abs(p - raw).max() < 1e-4
+    pcm = bench.synth_recording(0, 200 * 16000, 'cpu').numpy()
+    res = seg.segment_signal(pcm)
+    assert res == _oracle_segmentation(seg, pcm)
+    dur = {}
+    for lab, a, b in res:
+        dur[lab] = dur.get(lab, 0.0) + b - a
+    vad_total = sum(v for k, v in dur.items() if k != 'noEnergy')
+    assert min(dur['music'], dur['noise'], dur['male'] + dur['female']) / vad_total >= 0.15, dur
+    assert min(dur['male'], dur['female']) / (dur['male'] + dur['female']) >= 0.15, dur
+    assert bench.cnn_driven_boundaries(res) >= 3
+
+
 def test_synthetic_signals_identical_to_oracle_pipeline(seg):
     for seed, n in ((1, 160000), (2, 48000), (3, 400 + 160 * 67 + 5)):
         pcm = synth_pcm(seed, n)
@@ -79,6 +120,18 @@ def test_sm_engine_and_no_gender():
     assert set(l for l, _, _ in res) <= {'noEnergy', 'speech', 'music'}
 
 
+def test_sm_engine_reference_golden(seg):
+    """media/musanmix-sm-gender.csv: same label sequence, every boundary within 0.2 s (its CNN-driven boundary at 32.48 s --
+    `male` | `music` inside one energy segment -- is where the Viterbi path of the fitted stand-in switches), and the GPU
+    result equals the oracle pipeline exactly."""
+    s2 = Segmenter(vad_engine='sm', detect_gender=True, ffmpeg=None, models='synthetic')
+    res = s2(os.path.join(GOLDEN, 'musanmix.wav'))
+    gold = _csv_rows(os.path.join(GOLDEN, 'musanmix-sm-gender.csv'))
+    assert [r[0] for r in res] == [g[0] for g in gold]
+    assert max(max(abs(a - c), abs(b - d)) for (_, a, b), (_, c, d) in zip(res, gold)) <= 0.2
+    assert res == _oracle_segmentation(s2, read_wav_int16(os.path.join(GOLDEN, 'musanmix.wav')), 'sm')
+
+
 def test_batch_process_contract(seg, tmp_path):
     src = os.path.join(GOLDEN, 'musanmix.wav')
     lout = [str(tmp_path / 'a' / '1.csv'), str(tmp_path / '2.csv'), str(tmp_path / '3.csv'), str(tmp_path / '4.TextGrid')]
@@ -94,6 +147,32 @@ def test_batch_process_contract(seg, tmp_path):
     assert nb == 1 and open(lout[3]).read().startswith('File type = "ooTextFile"')
     with pytest.raises(NotImplementedError):
         seg.batch_process([src], [lout[0]], output_format='json')
+
+
+def test_pipeline_workers_follow_the_segmenters_settings(tmp_path):
+    """The extra device contexts of the multi-file pipeline take over the arithmetic mode and workspace cap of seg.ctx, at
+    creation and again on every call (they are cached): f32 batch_process with two workers == per-file f32 calls."""
+    from inaspeechsegmenter_amd import _native
+    s2 = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models='synthetic')
+    lin = []
+    for i in range(4):
+        _wav(tmp_path / f'p{i}.wav', synth_pcm(40 + i, 16000 * 20 + 7 * i))
+        lin.append(str(tmp_path / f'p{i}.wav'))
+    for prec, wsl in ((_native.PREC_F32, 1 << 30), (_native.PREC_BF16X3, 2 << 30)):
+        s2.ctx.set_precision(prec)
+        s2.ctx.set_workspace_limit(wsl)
+        lout = [str(tmp_path / f'o{prec}_{i}.csv') for i in range(4)]
+        t, nb, avg, lmsg = s2.batch_process(lin, lout, batch_files=1, workers=2)
+        assert nb == 4
+        ws = s2.__dict__['_pipeline_workers']
+        assert len(ws) == 2 and all(w.ctx.precision == prec and w.ctx.workspace_limit == wsl for w in ws)
+        for src, dst in zip(lin, lout):
+            ref = str(tmp_path / 'ref.csv')
+            seg2csv(s2(src), ref)
+            assert filecmp.cmp(dst, ref, shallow=False)
+        secs = [float(m[2].split()[1]) for m in lmsg]
+        assert all(0.0 < v < t for v in secs) and sum(secs) < 2.5 * t          # per-file figures, not time since batch start
+    s2.close()
 
 
 def test_constructor_contract():

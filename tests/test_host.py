@@ -462,8 +462,8 @@ def test_super_batch_pipeline_equals_per_file_calls_with_fake_device(tmp_path):
 
     got = {}
 
-    def on_result(i, src, lseg, err):
-        assert i not in got and src == paths[i]
+    def on_result(i, src, lseg, err, secs=0.0):
+        assert i not in got and src == paths[i] and secs >= 0.0
         got[i] = (lseg, err)
 
     with warnings.catch_warnings():
@@ -552,6 +552,61 @@ def test_pipeline_device_failure_propagates(tmp_path):
         with pytest.raises(_native.NativeError, match='simulated'):
             seg.batch_process([src], [str(tmp_path / 'o.csv')], workers=1)
     assert not os.path.exists(tmp_path / 'o.csv')
+
+
+def test_pipeline_failure_drains_every_stage(tmp_path):
+    """With more super-batches queued than the bounded batch queue holds, a failing device worker must keep draining it:
+    process_files raises instead of hanging with the packer blocked on `put` (one worker, and two workers failing both),
+    and an exception raised by on_result (unwritable output) propagates the same way."""
+    import threading
+    from inaspeechsegmenter_amd import pipeline
+
+    class Broken(_FakeDevice):
+        def cnn_probs(self, net_id, win_rows):
+            raise _native.NativeError('iss_cnn_probs: device lost (simulated)')
+
+    def make(dev):
+        seg = object.__new__(S.Segmenter)
+        seg.energy_ratio, seg.detect_gender, seg.ctx, seg.ffmpeg = 0.03, True, dev, None
+        seg.vad, seg.gender = object.__new__(S.SpeechMusicNoise), object.__new__(S.Gender)
+        seg.vad.ctx = seg.gender.ctx = dev
+        seg.vad.compiled = seg.gender.compiled = None
+        return seg
+
+    src = os.path.join(GOLDEN, 'musanmix.wav')
+    out = {}
+
+    def run(seg, cb, workers):
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                pipeline.process_files(seg, [src] * 9, cb, batch_files=1, workers=workers, decode_threads=2)
+            out['exc'] = None
+        except BaseException as e:                                  # noqa: B902
+            out['exc'] = e
+
+    for workers in (1, 2):
+        seg = make(Broken({}, {0: 21, 1: 24}))
+        if workers == 2:                                            # a second fake context instead of a real device one
+            seg.__dict__['_pipeline_workers'] = [pipeline._Worker(seg, seg.ctx), pipeline._Worker(seg, seg.ctx)]
+        th = threading.Thread(target=run, args=(seg, lambda *a: None, workers), daemon=True)
+        th.start()
+        th.join(60)
+        assert not th.is_alive(), f'process_files hangs after a device failure ({workers} worker(s))'
+        assert isinstance(out['exc'], _native.NativeError)
+
+    def predict3(x):
+        return np.tile(np.array([[.8, .1, .1]], np.float32), (len(x), 1))
+
+    def predict2(x):
+        return np.tile(np.array([[.3, .7]], np.float32), (len(x), 1))
+
+    def cb(i, src, lseg, err, secs=0.0):
+        raise OSError('disk full (simulated)')
+    th = threading.Thread(target=run, args=(make(_FakeDevice({0: predict3, 1: predict2}, {0: 21, 1: 24})), cb, 1), daemon=True)
+    th.start()
+    th.join(120)
+    assert not th.is_alive() and isinstance(out['exc'], OSError)
 
 
 def test_oracle_is_only_used_as_the_checker():

@@ -112,6 +112,8 @@ def test_merge_gathered_overflow_path():
     parts = np.stack([rows[0][:4], rows[1][:4]])     # capacity 4 < 5, 9: truncated first pass
     out = sh._merge_gathered(parts, np.array([5, 9]), 4, regather)
     assert np.array_equal(out, np.concatenate(rows))
+    with pytest.raises(sh.RankFailure, match=r'\[1\]'):
+        sh._merge_gathered(parts, np.array([5, -1]), 4, regather)
 
 
 @pytest.mark.gpu
@@ -127,6 +129,10 @@ def test_rccl_allgather_single_rank():
     assert np.array_equal(comm.allgather(np.zeros((0, 4), np.int32), 4), np.zeros((0, 4), np.int32))
     assert comm.max_over_ranks(3.25) == 3.25
     comm.barrier()
+    info = comm.info()                                            # what RCCL itself says about the communicator
+    assert info['world'] == 1 and info['rank'] == 0 and info['version'] > 0 and 'rccl' in info['lib'].lower()
+    with pytest.raises(sh.RankFailure):                           # a rank that reports failure: nobody keeps a table
+        comm.allgather(None, 8)
     ctx.comm_destroy()
     ctx.close()
 

@@ -1,0 +1,101 @@
+"""CPU: the calibrated stand-in networks DECIDE (tests/golden/make_standin_heads.py).
+
+The reference's goldens pin labels its CNNs decide (run_test.py:90-127); the real weights are un-vendored.  The seeded
+stand-ins with a random head answer one class on > 99.8 % of all slots, which reduces every label-identity test to the
+energy detector.  With the fitted last layer, run through the ORACLE pipeline, they reproduce the reference's golden CSVs
+on media/musanmix.wav and follow the ground truth of the synthetic generator -- so that the GPU-vs-oracle label tests
+(tests/test_gpu_segmenter.py) and bench.py's parity_check compare CNN-driven boundaries."""
+import os
+
+import numpy as np
+import pytest
+
+import bench
+from inaspeechsegmenter_amd import keras_model as KM
+from oracle import sidekit as osk, segment as oseg, keras_cnn as ocnn
+from conftest import GOLDEN, read_wav_int16
+
+FS = 16000
+
+
+def _rows(name):
+    rows = [l.rstrip('\n').split('\t') for l in open(os.path.join(GOLDEN, name))][1:]
+    return [(r[0], float(r[1]), float(r[2])) for r in rows]
+
+
+def _oracle(pcm, vad, nets):
+    mspec, loge, difflen = osk.media2feats((pcm / 32768.0).astype(np.float32))
+    l0 = oseg.energy_seglist(loge, 0.03)
+    l1, rv = oseg.dnn_segment(vad, lambda b: ocnn.forward(nets[vad], b), mspec, l0, difflen, return_raw=True)
+    l2, rg = oseg.dnn_segment('gender', lambda b: ocnn.forward(nets['gender'], b), mspec, l1, difflen, return_raw=True)
+    return l0, l1, l2, rv, rg
+
+
+@pytest.fixture(scope='module')
+def nets():
+    return {'smn': KM.synthetic_ina_like(21, 3, seed=1)[0], 'sm': KM.synthetic_ina_like(21, 2, seed=1)[0],
+            'gender': KM.synthetic_ina_like(24, 2, seed=2)[0]}
+
+
+def test_fixture_is_what_segmenter_synthetic_uses(nets):
+    for key, (nmel, ncls, seed) in {'smn': (21, 3, 1), 'sm': (21, 2, 1), 'gender': (24, 2, 2)}.items():
+        W, b = KM.standin_head(nmel, ncls, seed)
+        assert W.shape == (128, ncls) and b.shape == (ncls,) and W.dtype == np.float32
+        assert np.array_equal(nets[key][-1]['W'], W) and nets[key][-1]['activation'] == 'softmax'
+        rnd = KM.synthetic_ina_like(nmel, ncls, seed=seed, head=None)[0]
+        assert all(np.array_equal(a['W'], c['W']) for a, c in zip(nets[key][:-1], rnd[:-1]) if 'W' in a)    # same trunk
+        assert not np.array_equal(rnd[-1]['W'], W)
+    assert KM.standin_head(21, 3, 5) is None                                  # other seeds keep their random head
+
+
+def test_musanmix_reference_goldens_reproduced(nets):
+    """smn + gender: the golden CSV row for row, float reprs included; sm + gender: same labels, every boundary within
+    0.2 s (its one CNN-driven boundary, 32.48 s, is where the Viterbi path of a fitted head switches)."""
+    pcm = read_wav_int16(os.path.join(GOLDEN, 'musanmix.wav'))
+    l0, l1, l2, rv, rg = _oracle(pcm, 'smn', nets)
+    got = [(lab, a * .02, b * .02) for lab, a, b in l2]
+    assert got == _rows('musanmix-smn-gender.csv')
+    hist = np.bincount(rv.argmax(1), minlength=3) / len(rv)
+    assert hist.min() > 0.10, hist                                            # speech / music / noise all decided
+    l0, l1, l2, rv, rg = _oracle(pcm, 'sm', nets)
+    got, gold = [(lab, a * .02, b * .02) for lab, a, b in l2], _rows('musanmix-sm-gender.csv')
+    assert [g[0] for g in got] == [g[0] for g in gold]
+    assert max(max(abs(a - c), abs(b - d)) for (_, a, b), (_, c, d) in zip(got, gold)) <= 0.2
+    assert bench.cnn_driven_boundaries(l2) >= 1                               # male | music inside one energy segment
+
+
+def test_generator_ground_truth_is_followed(nets):
+    """The first 200 s of bench.py's rank-0 recording: every class wins >= 15 % of the slots its network evaluates,
+    >= 3 boundaries are CNN-driven (20 in the 600 s bench.py checks), and the labels follow the generator's plan (noise / voiced f0 / chords)."""
+    n = 200 * FS
+    pcm = bench.synth_recording(0, n, 'cpu').numpy()
+    l0, l1, l2, rv, rg = _oracle(pcm, 'smn', nets)
+    hv = np.bincount(rv.argmax(1), minlength=3) / len(rv)
+    hg = np.bincount(rg.argmax(1), minlength=2) / len(rg)
+    assert hv.min() >= 0.15 and hg.min() >= 0.15, (hv, hg)
+    assert bench.cnn_driven_boundaries(l2) >= 3
+    want = {1: ('noise',), 2: ('female', 'male'), 3: ('music',)}
+    agree = total = 0
+    lab_at = np.empty(l2[-1][2], dtype=object)
+    for lab, a, b in l2:
+        lab_at[a:b] = lab
+    for kind, pos, cnt, f0, chord, trem in bench.synth_plan(0, n):
+        if kind == 0:
+            continue
+        a, b = pos // 320 + 40, (pos + cnt) // 320 - 40                       # 0.8 s of guard at both ends
+        if b <= a:
+            continue
+        exp = want[kind] if kind != 2 else (('female',) if f0 == 200.0 else ('male',))
+        agree += int(np.isin(lab_at[a:b], exp).sum())
+        total += b - a
+    assert agree / total > 0.9, agree / total
+
+
+def test_random_head_is_degenerate():
+    """Why the calibration exists: with its seeded random head the same trunk answers ONE class almost everywhere."""
+    n = 40 * FS
+    pcm = bench.synth_recording(0, n, 'cpu').numpy()
+    rnd = {'smn': KM.synthetic_ina_like(21, 3, seed=1, head=None)[0], 'gender': KM.synthetic_ina_like(24, 2, seed=2, head=None)[0]}
+    l0, l1, l2, rv, rg = _oracle(pcm, 'smn', rnd)
+    assert (np.bincount(rv.argmax(1), minlength=3) / len(rv)).max() > 0.95
+    assert bench.cnn_driven_boundaries(l2) == 0
