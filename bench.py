@@ -126,7 +126,7 @@ def gemm_kernel_table(ctxs, peak_tf):
 
 
 # ------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(seg, pcm_host, target_s=15.0):
+def cpu_baseline(seg, pcm_host, target_s=40.0):
     """The oracle (numpy restatement of the reference feature path + torch-CPU Keras-semantics
     forward + the reference-order Viterbi) on a bounded sample of the same recording.  Also returns what the parity check
     needs: the oracle's segments and raw network outputs on that sample."""

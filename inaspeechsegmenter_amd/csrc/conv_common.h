@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <functional>
+#include <type_traits>
 
 namespace issk {
 
@@ -257,6 +258,14 @@ __device__ __forceinline__ void epilogue_tr(const P& p, const floatx16& acc0, co
             if (p.ps) {
                 const float4 s4 = *reinterpret_cast<const float4*>(p.ps + c), t4 = *reinterpret_cast<const float4*>(p.pt + c);
                 v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
+            }
+            if constexpr (std::is_same<P, ConvArgs>::value) {        // ISS_DBG experiments on the store tail (0 in production)
+                if (p.dbg & 1) {                                     // nontemporal stores
+                    __builtin_nontemporal_store(v.x, orow + c); __builtin_nontemporal_store(v.y, orow + c + 1);
+                    __builtin_nontemporal_store(v.z, orow + c + 2); __builtin_nontemporal_store(v.w, orow + c + 3);
+                    continue;
+                }
+                if ((p.dbg & 2) && g != 0) continue;                 // a quarter of the stores (wrong results: timing only)
             }
             *reinterpret_cast<float4*>(orow + c) = v;
         }

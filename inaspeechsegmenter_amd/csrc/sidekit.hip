@@ -76,19 +76,37 @@ __global__ __launch_bounds__(256) void sidekit_kernel(const SampleT* __restrict_
     float* spec = s_spec[wv];
     const int frames_per_pass = gridDim.x * 4;
     const int npass = (T + frames_per_pass - 1) / frames_per_pass;
+    // twiddles of this lane's butterflies in the span-64 and span-16 stages: constant across frames, kept in registers
+    const Tw3 tw1 = bfly_twiddles(lane & 15, 4, s_w256), tw2 = bfly_twiddles(lane & 3, 16, s_w256);
+
+    // the samples of the NEXT frame of this wave are fetched while the current one is transformed: the 7 loads of a frame
+    // (64 x 2 bytes each) would otherwise expose one HBM round trip per frame in front of ~3 k cycles of arithmetic
+    float xs[7];
+    auto fetch = [&](int tt) {
+        const int64_t s0 = (int64_t)(tt < T ? tt : T - 1) * 160;     // (a frame that does not exist re-reads the last one)
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int i = lane + 64 * r;
+            xs[r] = sample_at(sig, s0 + (i < 400 ? i : 399));
+        }
+    };
+    fetch(blockIdx.x * 4 + wv);
 
     for (int pass = 0; pass < npass; ++pass) {
         const int t = pass * frames_per_pass + blockIdx.x * 4 + wv;
         const bool live = t < T;
 
-        // ---- 1. load + per-frame pre-emphasis (sidekit_mfcc.py:275) -------------------------
+        // ---- 1. per-frame pre-emphasis (sidekit_mfcc.py:275) on the prefetched samples; next frame's loads issued
+        float xc[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) xc[r] = xs[r];
+        if (pass + 1 < npass) fetch(t + frames_per_pass);
         if (live) {
-            const int64_t s0 = (int64_t)t * 160;
             float carry = 0.f;
 #pragma unroll
             for (int r = 0; r < 7; ++r) {
                 const int i = lane + 64 * r;
-                float x = (i < 400) ? sample_at(sig, s0 + i) : 0.f;
+                float x = (i < 400) ? xc[r] : 0.f;
                 float prev = __shfl_up(x, 1);
                 if (lane == 0) prev = (r == 0) ? x : carry;
                 carry = __shfl(x, 63);
@@ -135,11 +153,11 @@ __global__ __launch_bounds__(256) void sidekit_kernel(const SampleT* __restrict_
             fft256_stage0(z, lane, a, s_w256);
         }
         wave_sync();
-        if (live) bfly4(z, (lane >> 4) * 64, 16, lane & 15, 4, s_w256);
+        if (live) bfly4<true>(z, (lane >> 4) * 64, 16, lane & 15, tw1);
         wave_sync();
-        if (live) bfly4(z, (lane >> 2) * 16, 4, lane & 3, 16, s_w256);
+        if (live) bfly4<true>(z, (lane >> 2) * 16, 4, lane & 3, tw2);
         wave_sync();
-        if (live) bfly4(z, lane * 4, 1, 0, 0, s_w256);
+        if (live) bfly4<false>(z, lane * 4, 1, 0, tw2);
         wave_sync();
 
         // ---- 4. real-input untangle + power (sidekit_mfcc.py:232-233) -------------------------

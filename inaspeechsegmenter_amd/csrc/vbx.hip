@@ -65,14 +65,27 @@ __global__ __launch_bounds__(256) void vbx_fbank_kernel(const SampleT* __restric
     double* spec = s_spec[wv];
     const int frames_per_pass = gridDim.x * 4;
     const int npass = (T + frames_per_pass - 1) / frames_per_pass;
+    const Tw3 tw1 = bfly_twiddles(lane & 15, 4, s_w256), tw2 = bfly_twiddles(lane & 3, 16, s_w256);   // see sidekit.hip
+    // next frame's samples (+ dither) are fetched while the current frame is transformed (see sidekit.hip)
+    double xs[7];
+    auto fetch = [&](int tt) {
+        const int64_t s0 = (int64_t)(tt < T ? tt : T - 1) * 160;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int i = lane + 64 * r;
+            xs[r] = seg_at(sig, u, n, s0 + (i < 400 ? i : 399));
+        }
+    };
+    fetch(blockIdx.x * 4 + wv);
 
     for (int pass = 0; pass < npass; ++pass) {
         const int t = pass * frames_per_pass + blockIdx.x * 4 + wv;
         const bool live = t < T;
         if (live) {
-            const int64_t s0 = (int64_t)t * 160;
-            for (int i = lane; i < 400; i += 64) x[i] = seg_at(sig, u, n, s0 + i);
+#pragma unroll
+            for (int r = 0; r < 7; ++r) { const int i = lane + 64 * r; if (i < 400) x[i] = xs[r]; }
         }
+        if (pass + 1 < npass) fetch(t + frames_per_pass);
         wave_sync();
         // frame mean, numpy pairwise order (features_vbx.py:100-101)
         double mean = 0.0;
@@ -109,11 +122,11 @@ __global__ __launch_bounds__(256) void vbx_fbank_kernel(const SampleT* __restric
             fft256_stage0(z, lane, a, s_w256);
         }
         wave_sync();
-        if (live) bfly4(z, (lane >> 4) * 64, 16, lane & 15, 4, s_w256);
+        if (live) bfly4<true>(z, (lane >> 4) * 64, 16, lane & 15, tw1);
         wave_sync();
-        if (live) bfly4(z, (lane >> 2) * 16, 4, lane & 3, 16, s_w256);
+        if (live) bfly4<true>(z, (lane >> 2) * 16, 4, lane & 3, tw2);
         wave_sync();
-        if (live) bfly4(z, lane * 4, 1, 0, 0, s_w256);
+        if (live) bfly4<false>(z, lane * 4, 1, 0, tw2);
         wave_sync();
         if (live) {
 #pragma unroll

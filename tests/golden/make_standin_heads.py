@@ -48,8 +48,10 @@ def slot_patches(mspec, nmel):
     return p.reshape(len(p), 68, nmel, 1), fin
 
 
-def fit_head(F, y, C, wt=None, ridge=1e-2, margin=8.0):
-    """Weighted ridge least squares onto logit targets +margin/2 (true class) / -margin/2, float64 normal equations."""
+def fit_head(F, y, C, wt=None, ridge=0.15, margin=8.0):
+    """Weighted ridge least squares onto logit targets +margin/2 (true class) / -margin/2, float64 normal equations.
+    ridge 0.15 is the strongest that still reproduces the goldens: |W| rms 0.27 (a seeded random head has 0.12), sum |w f| per
+    logit ~ 25: with weaker regularisation the head cancels 10:1 and amplifies the float32-level differences of its inputs."""
     X = np.concatenate((F, np.ones((len(F), 1))), axis=1).astype(np.float64)
     wt = np.ones(len(F)) if wt is None else np.asarray(wt, np.float64)
     T = np.full((len(F), C), -margin / 2)
