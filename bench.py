@@ -151,7 +151,11 @@ def cpu_baseline(seg, pcm_host, target_s=40.0):
     probe = 20
     t_probe, _ = run(probe)
     nsec = int(max(probe, min(len(pcm_host) // FS, probe * target_s / max(t_probe, 1e-3))))
-    nsec = min(nsec, 600)
+    # at least 600 s when that stays under ~90 s of CPU work: the parity check on this sample should see >= 20 boundaries that
+    # the networks decided (the generator changes segment every ~11 s, one in ten is silence)
+    if probe * 90.0 / max(t_probe, 1e-3) >= 600:
+        nsec = max(nsec, 600)
+    nsec = min(nsec, 660, len(pcm_host) // FS)
     t, det = run(nsec, keep=True)
     # the CNN forward alone at the reference's default and recommended batch sizes (segmenter.py:222-224)
     legs = {}
@@ -684,7 +688,7 @@ def main():
 
     cpu = par = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        host = pcm[:min(n, 600 * FS)].cpu().numpy()
+        host = pcm[:min(n, 660 * FS)].cpu().numpy()
         cpu, nsec, det = cpu_baseline(seg, host)
         par = parity_check(seg, host, nsec, det)
 

@@ -943,6 +943,16 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }                                                                                            //  first layer stays on conv_x3_fp_kernel)
         const bool padded = a.pt_ != 0 || a.pl_ != 0 ||
                             (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
+        // plain weight-stationary launch: a padded 3x3 stride-1 layer too wide for the 360-pixel footprint kernel (see conv_ws.h)
+        bool ws_plain = false;
+        if (!no_ws && !fp && pend < 0 && x3 && a.mode == 0 && padded && a.sh == 1 && a.sw == 1 && a.pp == 1 && a.Cout % 4 == 0 &&
+            !a.res && issk::iss_ws_plain_compiled(a.H_k, a.kw) && a.Cin % F2_CH == 0 && a.M < (1ll << 31) &&
+            (long long)bc * a.img_stride * 4 < (1ll << 32)) {
+            const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 61);
+            auto it = n.fp_pix.find(key);
+            if (it == n.fp_pix.end()) it = n.fp_pix.emplace(key, footprint_pixels(a, WS_TM)).first;
+            ws_plain = it->second <= WS_PIX;
+        }
         bool fused = false;
         if (pend >= 0) {
             const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
@@ -982,8 +992,12 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         ws = ws && fused;
         iss_prof_begin(c, 0, fl);
-        iss_prof_tag(c, ws ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
-        if (ws) {
+        iss_prof_tag(c, ws || ws_plain ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
+        if (ws_plain) {
+            const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
+            const unsigned per_n = std::max(1u, 256u / grid.y);                   // one 512-thread workgroup per CU in total
+            issk::iss_ws_launch_plain_3x3(a, dim3(std::min<unsigned>(ngroups, per_n), grid.y), c->stream);
+        } else if (ws) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);         // persistent: one 512-thread workgroup per CU
             const bool tr = a.pp == 1 && a.Cout % 4 == 0;

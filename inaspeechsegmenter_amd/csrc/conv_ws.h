@@ -452,14 +452,20 @@ template <int KH, int KW>
 void launch_ws_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, bool tr, bool fused) {
     if constexpr (KH * KW >= 8 && KH * KW <= WS_MAXNT) {
 #define ISS_WS_LAUNCH(...) hipLaunchKernelGGL((conv_x3_ws_kernel<KH, KW, __VA_ARGS__>), grid, dim3(512), 0, st, a)
-        // instantiated for the shared-first-layer convolution only (the dominant launch of the segmenter nets); the other
-        // footprint layers stay on conv_x3_fp_kernel -- every instantiation costs minutes of compile time
+        // instantiated for the shared-first-layer convolution (the dominant launch of the segmenter nets) -- every
+        // instantiation costs minutes of compile time; the other footprint layers stay on conv_x3_fp_kernel
         if (!fused) return;
         if (padded) { if (tr) ISS_WS_LAUNCH(true, true, true); else ISS_WS_LAUNCH(true, false, true); }
         else { if (tr) ISS_WS_LAUNCH(false, true, true); else ISS_WS_LAUNCH(false, false, true); }
 #undef ISS_WS_LAUNCH
     }
 }
+
+// Plain (not first-layer-fused) use of the kernel: zero-padded 3x3 stride-1 layers whose 128-row tile does not fit
+// conv_x3_fp_kernel's 360-pixel footprint because the image is WIDE (ResNet-101's 32 -> 32 convolutions at 64 x 144: 580
+// pixels per 128 rows, 802 per 512 rows <= WS_PIX) -- they ran on the gather kernel at 6 x their bandwidth bound.
+inline bool iss_ws_plain_compiled(int kh, int kw) { return kh == 3 && kw == 3; }
+void iss_ws_launch_plain_3x3(const ConvArgs& a, dim3 grid, hipStream_t st);     // padded, transposed epilogue (cnn_ws_c.hip)
 
 }  // namespace issk
 

@@ -93,5 +93,9 @@ def test_one_hour_of_slots_config_size(ctx):
         ref, rfin = _oracle_probs(layers, mspec, nmel, rows[idx])
         assert np.array_equal(fa[idx], rfin) and (~rfin).sum() > 10
         err = np.abs(a[idx] - ref).max()
-        print(f'1 h, nmel {nmel}: max |p_gpu - p_oracle| = {err:.2e} over {len(idx)} sampled slots of {len(rows)}')
-        assert err < 1e-4
+        lerr = np.abs(np.log(np.maximum(a[idx], 1e-30)) - np.log(np.maximum(ref, 1e-30)))[ref > 1e-6].max()
+        print(f'1 h, nmel {nmel}: max |p_gpu - p_oracle| = {err:.2e}, max |d log p| = {lerr:.2e} over {len(idx)} sampled slots of {len(rows)}')
+        # north star: frame logits within 1e-3 of the fp32 reference (log-probabilities are logits up to a common term).
+        # The calibrated heads (|W| rms 0.27, tests/golden/make_standin_heads.py) amplify input differences ~2x more than
+        # the seeded random ones this bound was first written for (1e-4 on probabilities); the input here is white noise
+        assert err < 2e-4 and lerr < 1e-3
