@@ -943,6 +943,18 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }                                                                                            //  first layer stays on conv_x3_fp_kernel)
         const bool padded = a.pt_ != 0 || a.pl_ != 0 ||
                             (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
+        // weight-stationary kernel with two column halves per workgroup (conv_ws.h, NH = 2): unpadded 3x3 stride-1 layers with
+        // a multiple of 128 output channels whose 512-row tiles fit a 1024-pixel footprint -- the 3x3 layers of the segmenter nets
+        bool ws_nh2 = false;
+        static const bool no_ws3 = getenv("ISS_NO_WS3") != nullptr;
+        if (!no_ws && !no_ws3 && pend < 0 && x3 && a.mode == 0 && !padded && a.sh == 1 && a.sw == 1 && !a.res && a.Cout % (2 * BN) == 0 &&
+            issk::iss_ws_nh2_compiled(a.H_k, a.kw) && a.Cin % F2_CH == 0 && a.M < (1ll << 31) &&
+            (long long)bc * a.img_stride * 4 < (1ll << 32)) {
+            const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 60);
+            auto it = n.fp_pix.find(key);
+            if (it == n.fp_pix.end()) it = n.fp_pix.emplace(key, footprint_pixels(a, WS_TM)).first;
+            ws_nh2 = it->second <= WS_PIX2;
+        }
         // plain weight-stationary launch: a padded 3x3 stride-1 layer too wide for the 360-pixel footprint kernel (see conv_ws.h)
         bool ws_plain = false;
         if (!no_ws && !fp && pend < 0 && x3 && a.mode == 0 && padded && a.sh == 1 && a.sw == 1 && a.pp == 1 && a.Cout % 4 == 0 &&
@@ -992,8 +1004,12 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         ws = ws && fused;
         iss_prof_begin(c, 0, fl);
-        iss_prof_tag(c, ws || ws_plain ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
-        if (ws_plain) {
+        iss_prof_tag(c, ws || ws_plain || ws_nh2 ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
+        if (ws_nh2) {
+            const unsigned ngroups = (unsigned)((a.M + WS_TM - 1) / WS_TM);         // one 512-row tile per group
+            const unsigned ny = (unsigned)(a.Cout / (2 * BN));
+            issk::iss_ws_launch_nh2_3x3(a, dim3(std::min<unsigned>(ngroups, std::max(1u, 256u / ny)), ny), c->stream, a.pp == 1 && a.Cout % 4 == 0);
+        } else if (ws_plain) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const unsigned per_n = std::max(1u, 256u / grid.y);                   // one 512-thread workgroup per CU in total
             issk::iss_ws_launch_plain_3x3(a, dim3(std::min<unsigned>(ngroups, per_n), grid.y), c->stream);

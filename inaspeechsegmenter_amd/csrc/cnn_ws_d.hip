@@ -1,0 +1,9 @@
+// Instantiation unit of conv_x3_ws_kernel (conv_ws.h): the two-column-half (NH = 2) variant for unpadded 3x3 layers.
+#include "conv_ws.h"
+
+namespace issk {
+void iss_ws_launch_nh2_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool tr) {
+    if (tr) hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, false, true, false, 2>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, false, false, false, 2>), grid, dim3(512), 0, st, a);
+}
+}  // namespace issk

@@ -61,33 +61,45 @@ struct EpiArgs {
 
 
 constexpr int WS_TM = 512;                         // GEMM rows per tile: 8 waves x 64 (two 32-row blocks per wave)
-constexpr int WS_G = 2;                            // tiles per group
-constexpr int WS_PIX = 896;                        // footprint capacity in pixels (host-validated per launch)
-constexpr int WS_ZERO = WS_PIX * F2_ROW;           // byte offset of the all-zero pixel behind a footprint
-constexpr int WS_BUF = (WS_PIX + 1) * F2_ROW;      // bytes of the footprint buffer (71 760)
-constexpr int WS_NFV = WS_PIX / 128;               // 128-pixel slices per footprint (7): 512 threads x 4 channels each
+constexpr int WS_G = 2;                            // tiles per group (NH = 1)
+constexpr int WS_PIX = 896;                        // footprint capacity in pixels, NH = 1 (host-validated per launch)
+constexpr int WS_PIX2 = 1024;                      // footprint capacity, NH = 2 (9-tap layers: 18 x 4 KB of weights beside it)
 constexpr int WS_MAXNT = 16;                       // taps: NT x 4 KB of weights + the footprint must fit 160 KB of LDS
-constexpr int ws_lds_bytes(int nt) { return WS_BUF + nt * F2_BST; }
+constexpr int ws_pix(int nh) { return nh == 2 ? WS_PIX2 : WS_PIX; }
+constexpr int ws_lds_bytes(int nt, int nh) { return (ws_pix(nh) + 1) * F2_ROW + nt * nh * F2_BST; }
 
-template <int KH, int KW, bool PADDED, bool TR, bool FUSED>
+// NH = 2 (layers with >= 128 output channels, not first-layer-fused): the workgroup computes TWO 64-column halves of ONE
+// 512-row tile per group instead of one half of two tiles -- the same eight accumulators, indexed (half, row block, column
+// block) instead of (tile, row block, column block).  A block then runs NT x 2 'virtual steps' (tap, half) on one footprint
+// with 2 NT resident weight tiles: the footprint is fetched / converted / written once per 128 output channels, the A
+// fragments of a tap are read once for both halves (6 instead of 8 ds_read_b128 per 12 MFMAs), and a block is twice as long
+// against the same serial block boundary.  This is what moved the 3x3 layers of the segmenter nets (64 -> 128, 128 -> 128)
+// off conv_x3_fp_kernel (8 KB weight ring, a barrier per 12 MFMAs, 12 reads per 12 MFMAs: 42 / 55 % matrix-pipe occupancy).
+template <int KH, int KW, bool PADDED, bool TR, bool FUSED, int NH = 1>
 __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     constexpr int NT = KH * KW;
-    static_assert(NT >= 8 && NT <= WS_MAXNT, "");
-    // [NT weight tiles][footprint 0][footprint 1]: the weights first, so that (lane base + tap * 4096 + plane / half offset)
-    // fits the 16-bit immediate offset of ds_read (<= 64 512) and every tap shares ONE address register
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[ws_lds_bytes(NT)];
+    constexpr int NV = NT * NH;                      // virtual steps per block = resident 4 KB weight tiles
+    constexpr int G = NH == 2 ? 1 : WS_G;            // tiles per group
+    constexpr int PIX = ws_pix(NH);
+    constexpr int WS_ZERO = PIX * F2_ROW;            // byte offset of the all-zero pixel behind the footprint
+    constexpr int WS_NFV = PIX / 128;                // 128-pixel slices per footprint: 512 threads x 4 channels each
+    static_assert(NT >= 8 && NT <= WS_MAXNT && (NH == 1 || (NH == 2 && !FUSED)), "");
+    static_assert(ws_lds_bytes(NT, NH) <= 160 * 1024, "");
+    // [NV weight tiles][footprint]: the weights first, so that (lane base + step * 4096 + plane / half offset) stays an
+    // immediate offset of ds_read for the first 16 tiles and the steps share ONE address register
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[ws_lds_bytes(NT, NH)];
     const unsigned sB_base = (unsigned)(size_t)smem;
-    const unsigned sF_base = sB_base + NT * F2_BST;
+    const unsigned sF_base = sB_base + NV * F2_BST;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
-    const int n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * BN * NH;
     const int li = lane & 31, lh = lane >> 5;
     const int M = (int)p.M;
     int totpix;                                      // samples * H * W
     { const int spp = p.Hq * p.Wq * p.pp; totpix = (int)(p.img_stride / p.Cin) * (M / spp); }
     const int ntiles = (M + WS_TM - 1) / WS_TM;
-    const int ngroups = (ntiles + WS_G - 1) / WS_G;
+    const int ngroups = (ntiles + G - 1) / G;
     int grp = (int)blockIdx.x;
     if (grp >= ngroups) return;
 
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
         map_row32(ga, m < M ? m : m0, b, oy, ox);
         const int iy0 = oy * ga.sh - ga.pt_, ix0 = ox * ga.sw - ga.pl_;
         const int lp = (b * ga.H + iy0) * ga.W + ix0 - u.p_lo;
-        const int hi = WS_PIX - 1 - ((KH - 1) * ga.W + (KW - 1));    // keeps every tap of a row >= M inside the buffer
+        const int hi = PIX - 1 - ((KH - 1) * ga.W + (KW - 1));       // keeps every tap of a row >= M inside the buffer
         lanepix = (int)sF_base + (lp < 0 ? 0 : (lp > hi ? hi : lp)) * F2_ROW + lh * 16;      // LDS byte address of the lane's first tap
         vmask = 0xffffffffu;
         if (PADDED) {
@@ -164,21 +176,25 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     // piece i: tap i >> 2, plane (i >> 1) & 1 (hi / lo), half i & 1 (rows 0-31 / 32-63).  Lane l of a piece writes 16-byte
     // slot 64 half + l and fetches the (row n, k half h) that belongs there: n = 32 half + (l >> 1),
     // h = (l & 1) ^ ((n >> 3) & 1)  (conflict-free B reads, see above).  Rows >= Cout read row 0 (never stored).
-    unsigned boff[2];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int n = 32 * half + (lane >> 1), h = (lane & 1) ^ ((n >> 3) & 1);
-        boff[half] = 2u * ((unsigned)(n0 + n < p.Cout ? n0 + n : 0) * (unsigned)p.Kpad + (unsigned)(h * 8));      // bytes
+    // NH = 2: weight tile v = tap * 2 + column half ch; the rows of column half ch start at n0 + 64 ch.  Piece i = wv + 8 k
+    // has (half, plane, ch) = (wv & 1, (wv >> 1) & 1, (wv >> 2) & 1) for EVERY k: a wave always moves the same kind of piece,
+    // only the tap changes, so one source offset per lane serves all of its pieces.
+    const int w_half = wv & 1, w_plane = (wv >> 1) & 1, w_ch = NH == 2 ? (wv >> 2) & 1 : 0;
+    unsigned boff_w;
+    {
+        const int n = 32 * w_half + (lane >> 1), h = (lane & 1) ^ ((n >> 3) & 1);
+        const int row = n0 + 64 * w_ch + n;
+        boff_w = 2u * ((unsigned)(row < p.Cout ? row : 0) * (unsigned)p.Kpad + (unsigned)(h * 8));      // bytes
     }
     auto load_weights = [&](int c0) {
 #pragma unroll
-        for (int k = 0; k < (4 * NT + 7) / 8; ++k) {
+        for (int k = 0; k < (4 * NV + 7) / 8; ++k) {
             const int i = wv + 8 * k;                // uniform
-            if (i < 4 * NT) {
-                const int tap = i >> 2, plane = (i >> 1) & 1, half = i & 1;
-                const uint16_t* src = (plane ? p.wl : p.wh) + (tap * p.Cin + c0);
-                glds16(src, half ? boff[1] : boff[0],
-                       (unsigned)__builtin_amdgcn_readfirstlane((int)(sB_base + tap * F2_BST + plane * 2048 + half * 1024)));
+            if (i < 4 * NV) {
+                const int v = i >> 2;                // weight tile: tap v / NH (column half v % NH == w_ch)
+                const uint16_t* src = (w_plane ? p.wl : p.wh) + ((v / NH) * p.Cin + c0);
+                glds16(src, boff_w,
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)(sB_base + v * F2_BST + w_plane * 2048 + w_half * 1024)));
             }
         }
     };
@@ -256,13 +272,22 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     const unsigned fwrite = sF_base + (unsigned)(prow * F2_ROW + cg * 8);
     auto write_footprint = [&]() {
         unsigned b = fwrite;
-        asm volatile("" : "+v"(b));                  // opaque base: one address register, the slices are immediates (< 64 KB)
-        const LdsW8 pb = (LdsW8)(b);
-        static_assert((WS_NFV - 1) * 128 * F2_ROW + 32 < 65536, "");
+        asm volatile("" : "+v"(b));                  // opaque base: one address register, the slices are immediates (< 64 KB;
+        const LdsW8 pb = (LdsW8)(b);                 // a second register from slice 6 on: the 8-slice footprint of NH = 2)
+        constexpr int QB = 6;
+        static_assert((QB - 1) * 128 * F2_ROW + 32 < 65536 && (WS_NFV - 1 - QB) * 128 * F2_ROW + 32 < 65536, "");
+        unsigned b2 = fwrite + (unsigned)(QB * 128 * F2_ROW);
+        asm volatile("" : "+v"(b2));
+        const LdsW8 pb2 = (LdsW8)(b2);
 #pragma unroll
         for (int q = 0; q < WS_NFV; ++q) {
-            pb[q * (128 * F2_ROW / 8)] = cvh[q];
-            pb[q * (128 * F2_ROW / 8) + 4] = cvl[q];
+            if (q < QB) {
+                pb[q * (128 * F2_ROW / 8)] = cvh[q];
+                pb[q * (128 * F2_ROW / 8) + 4] = cvl[q];
+            } else {
+                pb2[(q - QB) * (128 * F2_ROW / 8)] = cvh[q];
+                pb2[(q - QB) * (128 * F2_ROW / 8) + 4] = cvl[q];
+            }
         }
     };
 
@@ -314,27 +339,27 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc000[i] = 0.f; acc001[i] = 0.f; acc010[i] = 0.f; acc011[i] = 0.f; acc100[i] = 0.f; acc101[i] = 0.f; acc110[i] = 0.f; acc111[i] = 0.f; }
 
-    // conversion schedule inside a block of NT steps: loads at step 0, constants at step CS - 1, slice q at step CS + q * CSTRIDE
-    constexpr int CS = NT >= 12 ? 7 : 2;
-    constexpr int CSTRIDE = (NT - CS) / WS_NFV >= 1 ? (NT - CS) / WS_NFV : 1;
-    static_assert(CS + (WS_NFV - 1) * CSTRIDE <= NT - 1, "");
+    // conversion schedule inside a block of NV steps: loads at step 0, constants at step CS - 1, slice q at step CS + q * CSTRIDE
+    constexpr int CS = NV >= 12 ? 7 : 2;
+    constexpr int CSTRIDE = (NV - CS) / WS_NFV >= 1 ? (NV - CS) / WS_NFV : 1;
+    static_assert(CS + (WS_NFV - 1) * CSTRIDE <= NV - 1, "");
 
     // ---- prologue: zero pixels; geometry of the first group; its first footprint converted serially
     if (tid < F2_ROW / 4) *(LdsW4)(sF_base + (unsigned)(WS_ZERO + tid * 4)) = 0u;
-    TGeo ug[WS_G + 2];                               // the group's tiles + the next group's first two tiles
-    int lanepix[WS_G][2];
-    unsigned vmask[WS_G][2];
+    TGeo ug[G + 2];                                  // the group's tiles + the next group's first two tiles
+    int lanepix[G][2];
+    unsigned vmask[G][2];
     auto group_geometry = [&](int g0) {
         const GeoArgs ga = geo_args();
 #pragma unroll
-        for (int t = 0; t < WS_G; ++t) {
-            ug[t] = geo_uniform(ga, g0 * WS_G + t);
+        for (int t = 0; t < G; ++t) {
+            ug[t] = geo_uniform(ga, g0 * G + t);
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) geo_lane(ga, g0 * WS_G + t, rb, ug[t], lanepix[t][rb], vmask[t][rb]);
+            for (int rb = 0; rb < 2; ++rb) geo_lane(ga, g0 * G + t, rb, ug[t], lanepix[t][rb], vmask[t][rb]);
         }
     };
     group_geometry(grp);
-    ug[WS_G] = ug[0]; ug[WS_G + 1] = ug[1];
+    ug[G] = ug[0]; ug[G + 1] = ug[G == 1 ? 0 : 1];
     if (FUSED) { wx = settle(windows_of(ug[0].wb)); wpend = windows_of(ug[1].wb); }
     fetch_block(ug[0], 0);
     conv_consts();
@@ -347,32 +372,37 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     // ISS_DBG bit 2 (experiment): static priority for the second-dispatched half of the workgroup (waves 4..7 share their
     // SIMDs with waves 0..3 and lose the issue arbitration by age: MI355X_MICROARCH.md, "two waves per SIMD", item 4)
     if ((p.dbg & 4) && wv >= 4) __builtin_amdgcn_s_setprio(1);
+    bool first_chunk = true;
     for (; grp < ngroups; grp += gstep) {
         const bool last_group = grp + gstep >= ngroups;
         for (int ch = 0; ch < nchunk; ++ch) {
             const int c0 = ch * F2_CH;
             const bool last_chunk = ch + 1 == nchunk;
-            // ---- weights of this chunk.  Every wave has passed the barrier that ends the previous block, so nobody reads
-            // the old ones any more; the geometry of the next group's first tiles is computed while the DMAs are in flight.
-            load_weights(c0);
+            // ---- weights of this chunk: their LDS-DMAs were issued at the boundary that ended the previous chunk's last
+            // block (behind its first barrier, in flight while the footprint is written); only the very first chunk of the
+            // workgroup loads them here.  The geometry of the next group's first tiles is computed here.
+            const bool fc = first_chunk;
+            if (fc) { load_weights(c0); first_chunk = false; }
             if (last_chunk) {
                 if (!last_group) {
                     const GeoArgs ga = geo_args();
-                    ug[WS_G] = geo_uniform(ga, (grp + gstep) * WS_G);
-                    ug[WS_G + 1] = geo_uniform(ga, (grp + gstep) * WS_G + 1);
-                } else { ug[WS_G] = ug[0]; ug[WS_G + 1] = ug[1]; }     // nothing follows: re-build this group's first footprint (never read)
+                    ug[G] = geo_uniform(ga, (grp + gstep) * G);
+                    ug[G + 1] = geo_uniform(ga, (grp + gstep) * G + 1);
+                } else { ug[G] = ug[0]; ug[G + 1] = ug[G == 1 ? 0 : 1]; }   // nothing follows: re-build this group's first footprint (never read)
             }
-            wait_vmcnt<0>();
-            __syncthreads();
-            // one block = one tile x one chunk: t and the accumulators are compile-time constants after inlining
-            auto run_block = [&](const int t, floatx16& c00, floatx16& c01, floatx16& c10, floatx16& c11) __attribute__((always_inline)) {
+            if (fc) { wait_vmcnt<0>(); __syncthreads(); }
+            // one block = one tile x one chunk: t and the accumulators are compile-time constants after inlining.
+            // (c..): accumulators of column half 0 (NH = 1: of the tile), (d..): of column half 1 (NH = 2 only)
+            auto run_block = [&](const int t, floatx16& c00, floatx16& c01, floatx16& c10, floatx16& c11,
+                                 floatx16& d00, floatx16& d01, floatx16& d10, floatx16& d11) __attribute__((always_inline)) {
                 // the footprint this block builds (for the block after it) and the one after that (whose windows it loads)
-                const TGeo un = t + 1 < WS_G ? ug[t + 1] : (last_chunk ? ug[WS_G] : ug[0]);
-                const TGeo un2 = t + 2 < WS_G ? ug[t + 2] : (last_chunk ? ug[t + 2] : ug[t + 2 - WS_G]);
-                const int nc0 = t + 1 < WS_G ? c0 : (last_chunk ? 0 : c0 + F2_CH);
-                // Per step: 12 MFMAs on two row blocks x two column blocks, in three groups ordered a.l * b.h, a.h * b.h,
-                // a.h * b.l, and 8 fragment reads: the A fragments of step v + 1 (double-buffered) behind the first group, its
-                // hi weights behind the second (the hi registers are free by then), its lo weights behind the third.  The order
+                const TGeo un = t + 1 < G ? ug[t + 1] : (last_chunk ? ug[G] : ug[0]);
+                const TGeo un2 = t + 2 < G ? ug[t + 2] : (last_chunk ? ug[t + 2] : ug[t + 2 - G]);
+                const int nc0 = t + 1 < G ? c0 : (last_chunk ? 0 : c0 + F2_CH);
+                // Per virtual step (tap, column half): 12 MFMAs on two row blocks x two column blocks, in three groups ordered
+                // a.l * b.h, a.h * b.h, a.h * b.l.  Fragment reads: the A fragments of the next TAP (double-buffered) behind the
+                // first group of the tap's last half, the next step's hi weights behind the second group (the hi registers are
+                // free by then), its lo weights behind the third: 8 (NH = 1) / 6 (NH = 2) ds_read_b128 per 12 MFMAs.  The order
                 // is PINNED (sched_barrier): left alone, hipcc sinks every ds_read to just in front of its MFMA.
                 AFr a[2][2];
                 BH bh, bl;
@@ -382,14 +412,17 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                 read_bh(bh, 0);
                 read_bl(bl, 0);
 #pragma unroll
-                for (int v = 0; v < NT; ++v) {
+                for (int v = 0; v < NV; ++v) {
+                    const int tap = v / NH, half = v % NH;
+                    const AFr& a0 = a[tap & 1][0];
+                    const AFr& a1 = a[tap & 1][1];
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma2(a[v & 1][0].l, bh, c00, c01);
-                    mfma2(a[v & 1][1].l, bh, c10, c11);
+                    if (half == 0) { mfma2(a0.l, bh, c00, c01); mfma2(a1.l, bh, c10, c11); }
+                    else { mfma2(a0.l, bh, d00, d01); mfma2(a1.l, bh, d10, d11); }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (v + 1 < NT) {
+                    if (half == NH - 1 && tap + 1 < NT) {
 #pragma unroll
-                        for (int rb = 0; rb < 2; ++rb) { cur[rb] = next_tap(cur[rb], v); read_a(a[(v + 1) & 1][rb], cur[rb], vmask[t][rb], v + 1); }
+                        for (int rb = 0; rb < 2; ++rb) { cur[rb] = next_tap(cur[rb], tap); read_a(a[(tap + 1) & 1][rb], cur[rb], vmask[t][rb], tap + 1); }
                     }
                     if (v == 0) {
                         if (FUSED) { wx = settle(wpend); wpend = windows_of(un2.wb); }
@@ -397,26 +430,31 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                     }
                     if (v == CS - 1) conv_consts();
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma2(a[v & 1][0].h, bh, c00, c01);
-                    mfma2(a[v & 1][1].h, bh, c10, c11);
+                    if (half == 0) { mfma2(a0.h, bh, c00, c01); mfma2(a1.h, bh, c10, c11); }
+                    else { mfma2(a0.h, bh, d00, d01); mfma2(a1.h, bh, d10, d11); }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (v + 1 < NT) read_bh(bh, v + 1);
+                    if (v + 1 < NV) read_bh(bh, v + 1);
 #pragma unroll
                     for (int q = 0; q < WS_NFV; ++q)
                         if (v == CS + q * CSTRIDE) convert_slice(q);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma2(a[v & 1][0].h, bl, c00, c01);
-                    mfma2(a[v & 1][1].h, bl, c10, c11);
+                    if (half == 0) { mfma2(a0.h, bl, c00, c01); mfma2(a1.h, bl, c10, c11); }
+                    else { mfma2(a0.h, bl, d00, d01); mfma2(a1.h, bl, d10, d11); }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (v + 1 < NT) read_bl(bl, v + 1);
+                    if (v + 1 < NV) read_bl(bl, v + 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();                     // every wave has read its last fragments of this footprint
+                __syncthreads();                     // every wave has read its last fragments of this footprint (and of the weights)
+                if (t + 1 == G) load_weights(nc0);   // the next chunk's weights fly while the footprint is written
                 write_footprint();
+                if (t + 1 == G) wait_vmcnt<0>();
                 __syncthreads();
             };
-            run_block(0, acc000, acc001, acc010, acc011);
-            run_block(1, acc100, acc101, acc110, acc111);
+            if (NH == 2) run_block(0, acc000, acc001, acc010, acc011, acc100, acc101, acc110, acc111);
+            else {
+                run_block(0, acc000, acc001, acc010, acc011, acc000, acc001, acc010, acc011);
+                run_block(1, acc100, acc101, acc110, acc111, acc100, acc101, acc110, acc111);
+            }
         }
         // ---- group complete: epilogue parameters through the kernel-argument pointer
         {
@@ -425,14 +463,16 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
             EpiArgs e;
             e.bias = q->bias; e.ps = q->ps; e.pt = q->pt; e.res = q->res; e.out = q->out;
             e.M = q->M; e.Cout = q->Cout; e.act = q->act; e.pp = q->pp; e.poolkind = q->poolkind;
+            // t: NH = 1: tile of the group; NH = 2: column half of the group's one tile
             auto finish = [&](const int t, const int rb, floatx16& c0acc, floatx16& c1acc) __attribute__((always_inline)) {
-                const int tile = grp * WS_G + t;
+                const int tile = NH == 2 ? grp : grp * G + t;
+                const int nc = NH == 2 ? n0 + BN * t : n0;
                 const long long row0 = (long long)tile * WS_TM + (wv * 2 + rb) * 32;
                 if (tile < ntiles) {
-                    if (TR) epilogue_tr(e, c0acc, c1acc, row0 + li, n0, lh);
+                    if (TR) epilogue_tr(e, c0acc, c1acc, row0 + li, nc, lh);
                     else {
-                        epilogue_tile(e, c0acc, row0, n0 + li, lh);
-                        epilogue_tile(e, c1acc, row0, n0 + 32 + li, lh);
+                        epilogue_tile(e, c0acc, row0, nc + li, lh);
+                        epilogue_tile(e, c1acc, row0, nc + 32 + li, lh);
                     }
                 }
 #pragma unroll
@@ -443,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
         }
         if (!last_group) {
             group_geometry(grp + gstep);
-            // (ug[WS_G], ug[WS_G + 1] are rewritten at the next group's last chunk)
+            // (ug[G], ug[G + 1] are rewritten at the next group's last chunk)
         }
     }
 }
@@ -466,6 +506,9 @@ void launch_ws_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, 
 // pixels per 128 rows, 802 per 512 rows <= WS_PIX) -- they ran on the gather kernel at 6 x their bandwidth bound.
 inline bool iss_ws_plain_compiled(int kh, int kw) { return kh == 3 && kw == 3; }
 void iss_ws_launch_plain_3x3(const ConvArgs& a, dim3 grid, hipStream_t st);     // padded, transposed epilogue (cnn_ws_c.hip)
+// NH = 2 (see the kernel): unpadded 3x3 layers with a multiple of 128 output channels (cnn_ws_d.hip); tr: transposed epilogue
+inline bool iss_ws_nh2_compiled(int kh, int kw) { return kh == 3 && kw == 3; }
+void iss_ws_launch_nh2_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool tr);
 
 }  // namespace issk
 
