@@ -216,6 +216,19 @@ __device__ __forceinline__ void epilogue_tile(const P& p, const floatx16& acc, l
     else epilogue_pp<2>(p, acc, mrow0, n, lh);
 }
 
+// The one combination the segmenter nets' pooled layers use -- relu, non-overlapping max pool over 2 or 4 outputs, no
+// post-activation affine, no residual -- as its own entry: epilogue_tile, inlined once per accumulator, carries all 24
+// combinations (the weight-stationary kernel's object code was 2.3 MB, seven times its size with this entry alone, and the
+// step 3.3 % slower: instruction-cache footprint of code a launch never executes).  Host: epi_is_pool_relu().
+template <class P>
+__device__ __forceinline__ void epilogue_pool_relu(const P& p, const floatx16& acc, long long mrow0, int n, int lh) {
+    if (p.pp == 4) epilogue_impl<1, 4, false, false>(p, acc, mrow0, n, lh);
+    else epilogue_impl<1, 2, false, false>(p, acc, mrow0, n, lh);
+}
+inline bool epi_is_pool_relu(const ConvArgs& a) {
+    return a.act == 1 && (a.pp == 2 || a.pp == 4) && a.poolkind == 0 && !a.ps && !a.res;
+}
+
 // Epilogue of TRANSPOSED accumulators (the MFMAs were issued as W-fragment x A-fragment, i.e. C^T): lane = GEMM row
 // (pixel) m, register group g of tile t = output channels n0 + 32 t + 8 g + 4 lh + {0..3}.  Every access is a float4:
 // bias / scale / shift, the residual, and the store (8 x 16 B per lane and tile pair instead of 32 x 4 B).  Needs

@@ -75,7 +75,8 @@ constexpr int ws_lds_bytes(int nt, int nh) { return (ws_pix(nh) + 1) * F2_ROW + 
 // fragments of a tap are read once for both halves (6 instead of 8 ds_read_b128 per 12 MFMAs), and a block is twice as long
 // against the same serial block boundary.  This is what moved the 3x3 layers of the segmenter nets (64 -> 128, 128 -> 128)
 // off conv_x3_fp_kernel (8 KB weight ring, a barrier per 12 MFMAs, 12 reads per 12 MFMAs: 42 / 55 % matrix-pipe occupancy).
-template <int KH, int KW, bool PADDED, bool TR, bool FUSED, int NH = 1>
+// EPI = 1: the pooled relu epilogue only (epilogue_pool_relu; host-checked), EPI = 0: the generic one.
+template <int KH, int KW, bool PADDED, bool TR, bool FUSED, int NH = 1, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     constexpr int NT = KH * KW;
     constexpr int NV = NT * NH;                      // virtual steps per block = resident 4 KB weight tiles
@@ -186,11 +187,12 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
         const int row = n0 + 64 * w_ch + n;
         boff_w = 2u * ((unsigned)(row < p.Cout ? row : 0) * (unsigned)p.Kpad + (unsigned)(h * 8));      // bytes
     }
-    auto load_weights = [&](int c0) {
+    // tiles [v_lo, v_hi) of chunk c0
+    auto load_weights = [&](int c0, int v_lo, int v_hi) {
 #pragma unroll
         for (int k = 0; k < (4 * NV + 7) / 8; ++k) {
             const int i = wv + 8 * k;                // uniform
-            if (i < 4 * NV) {
+            if (i < 4 * NV && (i >> 2) >= v_lo && (i >> 2) < v_hi) {
                 const int v = i >> 2;                // weight tile: tap v / NH (column half v % NH == w_ch)
                 const uint16_t* src = (w_plane ? p.wl : p.wh) + ((v / NH) * p.Cin + c0);
                 glds16(src, boff_w,
@@ -340,9 +342,15 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     for (int i = 0; i < 16; ++i) { acc000[i] = 0.f; acc001[i] = 0.f; acc010[i] = 0.f; acc011[i] = 0.f; acc100[i] = 0.f; acc101[i] = 0.f; acc110[i] = 0.f; acc111[i] = 0.f; }
 
     // conversion schedule inside a block of NV steps: loads at step 0, constants at step CS - 1, slice q at step CS + q * CSTRIDE
-    constexpr int CS = NV >= 12 ? 7 : 2;
+    constexpr int CS = NV >= 16 ? 7 : (NV >= 12 ? 5 : 2);
     constexpr int CSTRIDE = (NV - CS) / WS_NFV >= 1 ? (NV - CS) / WS_NFV : 1;
     static_assert(CS + (WS_NFV - 1) * CSTRIDE <= NV - 1, "");
+    // Early weight refresh: the weight tiles of steps < VB are dead once EVERY wave has reached step VB, and the last
+    // conversion slice (whose compiler-placed vmcnt wait would otherwise also wait for the DMAs) is behind us: one extra
+    // barrier there, and the next chunk's tiles [0, VB) are in flight for the rest of the block instead of being waited for
+    // at the boundary.  Only when that buys at least two steps.
+    constexpr int VB = CS + (WS_NFV - 1) * CSTRIDE + 1;
+    constexpr bool EARLY_W = VB + 2 <= NV;
 
     // ---- prologue: zero pixels; geometry of the first group; its first footprint converted serially
     if (tid < F2_ROW / 4) *(LdsW4)(sF_base + (unsigned)(WS_ZERO + tid * 4)) = 0u;
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
             // block (behind its first barrier, in flight while the footprint is written); only the very first chunk of the
             // workgroup loads them here.  The geometry of the next group's first tiles is computed here.
             const bool fc = first_chunk;
-            if (fc) { load_weights(c0); first_chunk = false; }
+            if (fc) { load_weights(c0, 0, NV); first_chunk = false; }
             if (last_chunk) {
                 if (!last_group) {
                     const GeoArgs ga = geo_args();
@@ -416,6 +424,11 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                     const int tap = v / NH, half = v % NH;
                     const AFr& a0 = a[tap & 1][0];
                     const AFr& a1 = a[tap & 1][1];
+                    if (EARLY_W && v == VB && t + 1 == G) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                        load_weights(nc0, 0, VB);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (half == 0) { mfma2(a0.l, bh, c00, c01); mfma2(a1.l, bh, c10, c11); }
                     else { mfma2(a0.l, bh, d00, d01); mfma2(a1.l, bh, d10, d11); }
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                     // every wave has read its last fragments of this footprint (and of the weights)
-                if (t + 1 == G) load_weights(nc0);   // the next chunk's weights fly while the footprint is written
+                if (t + 1 == G) load_weights(nc0, EARLY_W ? VB : 0, NV);   // the (rest of the) next chunk's weights fly while the footprint is written
                 write_footprint();
                 if (t + 1 == G) wait_vmcnt<0>();
                 __syncthreads();
@@ -470,7 +483,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                 const long long row0 = (long long)tile * WS_TM + (wv * 2 + rb) * 32;
                 if (tile < ntiles) {
                     if (TR) epilogue_tr(e, c0acc, c1acc, row0 + li, nc, lh);
-                    else {
+                    else if (EPI == 1) {
+                        epilogue_pool_relu(e, c0acc, row0, nc + li, lh);
+                        epilogue_pool_relu(e, c1acc, row0, nc + 32 + li, lh);
+                    } else {
                         epilogue_tile(e, c0acc, row0, nc + li, lh);
                         epilogue_tile(e, c1acc, row0, nc + 32 + li, lh);
                     }
@@ -495,8 +511,9 @@ void launch_ws_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, 
         // instantiated for the shared-first-layer convolution (the dominant launch of the segmenter nets) -- every
         // instantiation costs minutes of compile time; the other footprint layers stay on conv_x3_fp_kernel
         if (!fused) return;
-        if (padded) { if (tr) ISS_WS_LAUNCH(true, true, true); else ISS_WS_LAUNCH(true, false, true); }
-        else { if (tr) ISS_WS_LAUNCH(false, true, true); else ISS_WS_LAUNCH(false, false, true); }
+        const bool fast = !tr && epi_is_pool_relu(a);            // (the transposed epilogue is compact as it is)
+        if (padded) { if (tr) ISS_WS_LAUNCH(true, true, true); else if (fast) ISS_WS_LAUNCH(true, false, true, 1, 1); else ISS_WS_LAUNCH(true, false, true); }
+        else { if (tr) ISS_WS_LAUNCH(false, true, true); else if (fast) ISS_WS_LAUNCH(false, false, true, 1, 1); else ISS_WS_LAUNCH(false, false, true); }
 #undef ISS_WS_LAUNCH
     }
 }
