@@ -3,6 +3,7 @@
 
 namespace issk {
 void iss_ws_launch_plain_3x3(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, true, true, false>), grid, dim3(512), 0, st, a);
+    if (epi_is_simple_tr(a)) hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, true, true, false, 1, 1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, true, true, false>), grid, dim3(512), 0, st, a);
 }
 }  // namespace issk

@@ -3,7 +3,8 @@
 
 namespace issk {
 void iss_ws_launch_nh2_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool tr) {
-    if (tr) hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, false, true, false, 2>), grid, dim3(512), 0, st, a);
+    if (tr && epi_is_simple_tr(a)) hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, false, true, false, 2, 1>), grid, dim3(512), 0, st, a);
+    else if (tr) hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, false, true, false, 2>), grid, dim3(512), 0, st, a);
     else if (epi_is_pool_relu(a)) hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, false, false, false, 2, 1>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, false, false, false, 2>), grid, dim3(512), 0, st, a);
 }

@@ -228,17 +228,21 @@ __device__ __forceinline__ void epilogue_pool_relu(const P& p, const floatx16& a
 inline bool epi_is_pool_relu(const ConvArgs& a) {
     return a.act == 1 && (a.pp == 2 || a.pp == 4) && a.poolkind == 0 && !a.ps && !a.res;
 }
+inline bool epi_is_simple_tr(const ConvArgs& a) { return a.act <= 1 && !a.ps && !a.res; }
 
 // Epilogue of TRANSPOSED accumulators (the MFMAs were issued as W-fragment x A-fragment, i.e. C^T): lane = GEMM row
 // (pixel) m, register group g of tile t = output channels n0 + 32 t + 8 g + 4 lh + {0..3}.  Every access is a float4:
 // bias / scale / shift, the residual, and the store (8 x 16 B per lane and tile pair instead of 32 x 4 B).  Needs
 // pp == 1 and Cout % 4 == 0 (parameter offsets in the blob are multiples of 8 floats).
-template <bool PRELOAD_RES = false, class P = ConvArgs>
+// SIMPLE (host-checked, epi_is_simple_tr): no residual, no sigmoid / tanh, no post-activation affine -- bias and an optional
+// relu only.  The generic form inlines expf / tanhf four times per register group; eight calls per kernel made the
+// transposed weight-stationary kernels 78-92 KB, more than the 64 KB instruction cache two CUs share.
+template <bool PRELOAD_RES = false, class P = ConvArgs, bool SIMPLE = false>
 __device__ __forceinline__ void epilogue_tr(const P& p, const floatx16& acc0, const floatx16& acc1, long long m,
                                             int n0, int lh) {
     if (m >= p.M) return;
     float* orow = p.out + (size_t)m * p.Cout;
-    const float* rrow = p.res ? p.res + (size_t)m * p.Cout : nullptr;
+    const float* rrow = (!SIMPLE && p.res) ? p.res + (size_t)m * p.Cout : nullptr;
     // PRELOAD_RES: all eight residual loads first, back to back: inside the per-group code below each one is waited for
     // on the spot (8 serial round trips to L2 / HBM per tile -- most of the pointwise ResNet layers' time).  Costs 32
     // VGPRs, which the footprint kernels do not have to spare (their residual-free or 3x3 layers gain nothing from it).
@@ -267,8 +271,8 @@ __device__ __forceinline__ void epilogue_tr(const P& p, const floatx16& acc0, co
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
             if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            else if (p.act > 1) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
-            if (p.ps) {
+            else if (!SIMPLE && p.act > 1) { v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act); }
+            if (!SIMPLE && p.ps) {
                 const float4 s4 = *reinterpret_cast<const float4*>(p.ps + c), t4 = *reinterpret_cast<const float4*>(p.pt + c);
                 v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
             }

@@ -75,7 +75,8 @@ constexpr int ws_lds_bytes(int nt, int nh) { return (ws_pix(nh) + 1) * F2_ROW + 
 // fragments of a tap are read once for both halves (6 instead of 8 ds_read_b128 per 12 MFMAs), and a block is twice as long
 // against the same serial block boundary.  This is what moved the 3x3 layers of the segmenter nets (64 -> 128, 128 -> 128)
 // off conv_x3_fp_kernel (8 KB weight ring, a barrier per 12 MFMAs, 12 reads per 12 MFMAs: 42 / 55 % matrix-pipe occupancy).
-// EPI = 1: the pooled relu epilogue only (epilogue_pool_relu; host-checked), EPI = 0: the generic one.
+// EPI = 1: the pooled relu epilogue only (epilogue_pool_relu; TR: bias + optional relu only, epilogue_tr<.., SIMPLE>); host-checked.
+// EPI = 0: the generic ones.
 template <int KH, int KW, bool PADDED, bool TR, bool FUSED, int NH = 1, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     constexpr int NT = KH * KW;
@@ -482,7 +483,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                 const int nc = NH == 2 ? n0 + BN * t : n0;
                 const long long row0 = (long long)tile * WS_TM + (wv * 2 + rb) * 32;
                 if (tile < ntiles) {
-                    if (TR) epilogue_tr(e, c0acc, c1acc, row0 + li, nc, lh);
+                    if (TR && EPI == 1) epilogue_tr<false, EpiArgs, true>(e, c0acc, c1acc, row0 + li, nc, lh);
+                    else if (TR) epilogue_tr(e, c0acc, c1acc, row0 + li, nc, lh);
                     else if (EPI == 1) {
                         epilogue_pool_relu(e, c0acc, row0, nc + li, lh);
                         epilogue_pool_relu(e, c1acc, row0, nc + 32 + li, lh);
@@ -511,9 +513,14 @@ void launch_ws_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, 
         // instantiated for the shared-first-layer convolution (the dominant launch of the segmenter nets) -- every
         // instantiation costs minutes of compile time; the other footprint layers stay on conv_x3_fp_kernel
         if (!fused) return;
-        const bool fast = !tr && epi_is_pool_relu(a);            // (the transposed epilogue is compact as it is)
-        if (padded) { if (tr) ISS_WS_LAUNCH(true, true, true); else if (fast) ISS_WS_LAUNCH(true, false, true, 1, 1); else ISS_WS_LAUNCH(true, false, true); }
-        else { if (tr) ISS_WS_LAUNCH(false, true, true); else if (fast) ISS_WS_LAUNCH(false, false, true, 1, 1); else ISS_WS_LAUNCH(false, false, true); }
+        const bool fast = tr ? epi_is_simple_tr(a) : epi_is_pool_relu(a);
+        if (padded) {
+            if (tr) { if (fast) ISS_WS_LAUNCH(true, true, true, 1, 1); else ISS_WS_LAUNCH(true, true, true); }
+            else { if (fast) ISS_WS_LAUNCH(true, false, true, 1, 1); else ISS_WS_LAUNCH(true, false, true); }
+        } else {
+            if (tr) { if (fast) ISS_WS_LAUNCH(false, true, true, 1, 1); else ISS_WS_LAUNCH(false, true, true); }
+            else { if (fast) ISS_WS_LAUNCH(false, false, true, 1, 1); else ISS_WS_LAUNCH(false, false, true); }
+        }
 #undef ISS_WS_LAUNCH
     }
 }
