@@ -343,7 +343,16 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     for (int i = 0; i < 16; ++i) { acc000[i] = 0.f; acc001[i] = 0.f; acc010[i] = 0.f; acc011[i] = 0.f; acc100[i] = 0.f; acc101[i] = 0.f; acc110[i] = 0.f; acc111[i] = 0.f; }
 
     // conversion schedule inside a block of NV steps: loads at step 0, constants at step CS - 1, slice q at step CS + q * CSTRIDE
-    constexpr int CS = NV >= 16 ? 7 : (NV >= 12 ? 5 : 2);
+#ifndef ISS_CS15
+#define ISS_CS15 7
+#endif
+#ifndef ISS_CS18
+#define ISS_CS18 7
+#endif
+#ifndef ISS_EARLY
+#define ISS_EARLY 1
+#endif
+    constexpr int CS = NV >= 16 ? ISS_CS18 : (NV >= 12 ? ISS_CS15 : 2);
     constexpr int CSTRIDE = (NV - CS) / WS_NFV >= 1 ? (NV - CS) / WS_NFV : 1;
     static_assert(CS + (WS_NFV - 1) * CSTRIDE <= NV - 1, "");
     // Early weight refresh: the weight tiles of steps < VB are dead once EVERY wave has reached step VB, and the last
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     // barrier there, and the next chunk's tiles [0, VB) are in flight for the rest of the block instead of being waited for
     // at the boundary.  Only when that buys at least two steps.
     constexpr int VB = CS + (WS_NFV - 1) * CSTRIDE + 1;
-    constexpr bool EARLY_W = VB + 2 <= NV;
+    constexpr bool EARLY_W = ISS_EARLY && VB + 2 <= NV;
 
     // ---- prologue: zero pixels; geometry of the first group; its first footprint converted serially
     if (tid < F2_ROW / 4) *(LdsW4)(sF_base + (unsigned)(WS_ZERO + tid * 4)) = 0u;
