@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): the measurement set committed under profiles/ at the end of a round.
 #   gpurun --timeout 1500 -- 'bash tools/final_profiles.sh r01'
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/final
 mkdir -p $OUT
@@ -21,8 +21,13 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_
 python $ROOT/tools/pmc_summary.py $(find /tmp/p_q1 -name '*.db' | head -1) > $OUT/pmc_q1.json
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_VALU_MFMA_COEXEC_CYCLES SQ_IFETCH SQ_LDS_CMD_FIFO_FULL --kernel-trace -d /tmp/p_q2 -o r -- $B > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py $(find /tmp/p_q2 -name '*.db' | head -1) > $OUT/pmc_q2.json
+rocprofv3 --kernel-trace --stats -d /tmp/p_vbx -o r -- python $ROOT/bench.py --workload vbx --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python $ROOT/tools/rocprof_summary.py $(find /tmp/p_vbx -name '*.db' | head -1) $OUT/${R}_vbx_kernel_stats.md "bench.py --workload vbx --steps 2 --warmup 1" > /dev/null
+rocprofv3 --kernel-trace -d /tmp/p_vbxl -o r -- python $ROOT/bench.py --workload vbx --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+python $ROOT/tools/layer_times.py $(find /tmp/p_vbxl -name '*.db' | head -1) > $OUT/${R}_vbx_layer_times.md 2>&1
 cd $ROOT
 python bench.py --workload vbx > $OUT/${R}_vbx_1h.json 2> $OUT/vbx.err
+python bench.py --workload archive --files-per-gpu 1250 --steps 2 --warmup 1 > $OUT/${R}_bench_archive_1250.json 2> $OUT/archive1250.err
 python bench.py --workload batch > $OUT/${R}_bench_batch.json 2> $OUT/batch.err
 python bench.py --workload archive > $OUT/${R}_bench_archive_1gpu.json 2> $OUT/archive.err
 python tests/topology_sweep.py --out $OUT/${R}_topology_sweep.json > $OUT/sweep.log 2>&1
