@@ -947,7 +947,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         // a multiple of 128 output channels whose 512-row tiles fit a 1024-pixel footprint -- the 3x3 layers of the segmenter nets
         bool ws_nh2 = false;
         static const bool no_ws3 = getenv("ISS_NO_WS3") != nullptr;
-        if (!no_ws && !no_ws3 && pend < 0 && x3 && a.mode == 0 && !padded && a.sh == 1 && a.sw == 1 && !a.res && a.Cout % (2 * BN) == 0 &&
+        const bool nh2_pad_ok = a.pp == 1 && a.Cout % 4 == 0 && issk::epi_is_simple_tr(a);       // the padded form is compiled transposed + simple only
+        if (!no_ws && !no_ws3 && pend < 0 && x3 && a.mode == 0 && (!padded || nh2_pad_ok) && a.sh == 1 && a.sw == 1 && !a.res && a.Cout % (2 * BN) == 0 &&
             issk::iss_ws_nh2_compiled(a.H_k, a.kw) && a.Cin % F2_CH == 0 && a.M < (1ll << 31) &&
             (long long)bc * a.img_stride * 4 < (1ll << 32)) {
             const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 60);
@@ -1008,7 +1009,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         if (ws_nh2) {
             const unsigned ngroups = (unsigned)((a.M + WS_TM - 1) / WS_TM);         // one 512-row tile per group
             const unsigned ny = (unsigned)(a.Cout / (2 * BN));
-            issk::iss_ws_launch_nh2_3x3(a, dim3(std::min<unsigned>(ngroups, std::max(1u, 256u / ny)), ny), c->stream, a.pp == 1 && a.Cout % 4 == 0);
+            const dim3 g2(std::min<unsigned>(ngroups, std::max(1u, 256u / ny)), ny);
+            if (padded) issk::iss_ws_launch_nh2_3x3_padded(a, g2, c->stream);
+            else issk::iss_ws_launch_nh2_3x3(a, g2, c->stream, a.pp == 1 && a.Cout % 4 == 0);
         } else if (ws_plain) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const unsigned per_n = std::max(1u, 256u / grid.y);                   // one 512-thread workgroup per CU in total

@@ -2,6 +2,10 @@
 #include "conv_ws.h"
 
 namespace issk {
+// zero-padded form (ResNet-101's 128 -> 128 / 256 -> 256 convolutions): transposed, simple epilogue only (host-checked)
+void iss_ws_launch_nh2_3x3_padded(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, true, true, false, 2, 1>), grid, dim3(512), 0, st, a);
+}
 void iss_ws_launch_nh2_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool tr) {
     if (tr && epi_is_simple_tr(a)) hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, false, true, false, 2, 1>), grid, dim3(512), 0, st, a);
     else if (tr) hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, false, true, false, 2>), grid, dim3(512), 0, st, a);

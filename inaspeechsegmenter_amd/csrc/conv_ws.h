@@ -542,6 +542,7 @@ void iss_ws_launch_plain_3x3(const ConvArgs& a, dim3 grid, hipStream_t st);     
 // NH = 2 (see the kernel): unpadded 3x3 layers with a multiple of 128 output channels (cnn_ws_d.hip); tr: transposed epilogue
 inline bool iss_ws_nh2_compiled(int kh, int kw) { return kh == 3 && kw == 3; }
 void iss_ws_launch_nh2_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool tr);
+void iss_ws_launch_nh2_3x3_padded(const ConvArgs& a, dim3 grid, hipStream_t st);    // transposed + simple epilogue (epi_is_simple_tr)
 
 }  // namespace issk
 
