@@ -319,10 +319,12 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
 
     def step():
         if kind == 'batch':
-            t, nb, avg, lmsg = seg.batch_process(lin, lout, batch_files=args.batch_files, workers=args.workers)
+            t, nb, avg, lmsg = seg.batch_process(lin, lout, batch_files=args.batch_files or None, workers=args.workers or None,
+                                                 batch_seconds=args.batch_seconds or None)
             assert nb == nfiles, [m for m in lmsg if m[1] != 0][:3]
             return nb
-        table, lmsg = segment_archive(seg, lin, lout, sizes=sizes, comm=comm)
+        table, lmsg = segment_archive(seg, lin, lout, sizes=sizes, comm=comm, batch_files=args.batch_files or None,
+                                      workers=args.workers or None, batch_seconds=args.batch_seconds or None)
         assert len(table) == nfiles and all(m[1] == 0 for m in lmsg), (len(table), [m for m in lmsg if m[1] != 0][:3])
         return sum(len(v) for v in table.values())
 
@@ -343,6 +345,8 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
     barrier()
     torch.cuda.synchronize()
     mem_trace = [host_mem()]
+    for w in seg.__dict__.get('_pipeline_workers', []):
+        w.stats = {k: 0.0 for k in w.stats}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nseg = step()
@@ -352,6 +356,8 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
     barrier()
     dt = time.perf_counter() - t0
     dt_local = dt
+    pipe = [{k: (round(v * 1e3 / args.steps, 1) if k not in ('batches', 'files') else v / args.steps) for k, v in w.stats.items()}
+            for w in seg.__dict__.get('_pipeline_workers', [])]
     if comm:
         dt = comm.max_over_ranks(dt)
     # roofline of the conv/dense GEMM launches, live: HIP events on the library's streams around every launch of ONE extra
@@ -416,6 +422,10 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
                        "parallelism": (f"file-parallel x{world}: files dealt by size (LPT), no data-path collective, ONE ncclAllGather of int32 segment "
                                        "tables per step through the C-ABI (iss_allgather_segments)") if world > 1 else "single GPU"},
             "roofline": roofline,
+            "pipeline_workers_ms_per_step": {"workers": pipe,
+                                             "what": "wall ms per step each device worker thread spent packing PCM into its page-locked buffer, in "
+                                                     "H2D + sidekit + log-energy read-back, in the host energy detector, blocked in iss_cnn_probs, "
+                                                     "and in Viterbi smoothing / bookkeeping (Python threads: the host phases share the GIL)"},
             "host_memory": {"rss_mb_after_warmup_then_each_step": [m[0] for m in mem_trace],
                             "files_mount_used_mb": [m[1] for m in mem_trace],
                             "what": "rank 0's resident set and the space in use under the WAV / CSV directory, sampled after the "
@@ -538,8 +548,9 @@ def main():
     ap.add_argument('--file-minutes', type=float, default=0.0, help='batch / archive: minutes per file (default 5 / 3)')
     ap.add_argument('--dir', default='/dev/shm/iss_bench', help='batch / archive: where the synthetic WAV files live')
     ap.add_argument('--no-f32-companion', action='store_true', help='skip the exact-f32 (ISS_PREC_F32) companion step')
-    ap.add_argument('--batch-files', type=int, default=32, help='batch / archive: files per device pass (super-batch)')
-    ap.add_argument('--workers', type=int, default=2, help='batch / archive: device contexts alternating super-batches')
+    ap.add_argument('--batch-files', type=int, default=0, help='batch / archive: files per device pass at most (0 = library default, 32)')
+    ap.add_argument('--batch-seconds', type=float, default=0, help='batch / archive: audio per device pass at most (0 = library default, 2400 s)')
+    ap.add_argument('--workers', type=int, default=0, help='batch / archive: device contexts taking super-batches in turn (0 = library default, 4)')
     ap.add_argument('--workspace-mb', type=int, default=0, help='activation workspace cap (0 = library default)')
     ap.add_argument('--precision', choices=['bf16x3', 'f32'], default='bf16x3',
                     help='conv/dense GEMM arithmetic: split-bf16 MFMA (default) or exact-f32 MFMA')

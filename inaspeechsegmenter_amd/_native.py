@@ -90,6 +90,8 @@ def lib():
         'iss_prof_reset': (C.c_int, [vp]),
         'iss_viterbi_f64': (C.c_int, [pd, i64, i32, pd, pi32]),
         'iss_viterbi_f32': (C.c_int, [pf, i64, i32, pd, pi32]),
+        'iss_energy_viterbi': (C.c_int, [pf, i64, C.c_double, C.c_double, C.c_double, pd, pi32]),
+        'iss_viterbi_segments_f32': (C.c_int, [pf, pi64, i64, i32, pd, pi32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here == header/library mismatch
@@ -120,6 +122,38 @@ def viterbi(emission, transition):
         rc = L.iss_viterbi_f64(_ptr(em, C.c_double), T, K, _ptr(tr, C.c_double), _ptr(out, C.c_int32))
     if rc != 0:
         raise NativeError(f"iss_viterbi failed ({rc}): T={T} K={K}")
+    return out
+
+
+def viterbi_segments(emission, seg_len, transition):
+    """iss_viterbi_segments_f32: emission (n,K) float32 log-scores of consecutive segments of lengths seg_len, each smoothed on
+    its own.  Returns int32 state ids (n,)."""
+    L = lib()
+    em = np.ascontiguousarray(emission, dtype=np.float32)
+    sl = np.ascontiguousarray(seg_len, dtype=np.int64)
+    tr = np.ascontiguousarray(transition, dtype=np.float64)
+    n, K = em.shape
+    assert int(sl.sum()) == n
+    out = np.empty(n, dtype=np.int32)
+    rc = L.iss_viterbi_segments_f32(_ptr(em, C.c_float), _ptr(sl, C.c_int64), sl.size, K, _ptr(tr, C.c_double), _ptr(out, C.c_int32))
+    if rc != 0:
+        raise NativeError(f"iss_viterbi_segments_f32 failed ({rc}): n={n} K={K} segments={sl.size}")
+    return out
+
+
+_LOG_EPS = np.log(np.full(1, 1e-10))[0], np.log(np.full(1, 1 - 1e-10))[0]     # as pred2logemission's np.log(ret) yields them
+
+
+def energy_viterbi(loge, threshold, transition):
+    """iss_energy_viterbi: smoothed activity (T,) int32 of `loge > threshold` (see include/iss.h)."""
+    L = lib()
+    x = np.ascontiguousarray(loge, dtype=np.float32)
+    tr = np.ascontiguousarray(transition, dtype=np.float64)
+    out = np.empty(x.size, dtype=np.int32)
+    rc = L.iss_energy_viterbi(_ptr(x, C.c_float), x.size, float(threshold), float(_LOG_EPS[0]), float(_LOG_EPS[1]),
+                              _ptr(tr, C.c_double), _ptr(out, C.c_int32))
+    if rc != 0:
+        raise NativeError(f"iss_energy_viterbi failed ({rc}): T={x.size}")
     return out
 
 

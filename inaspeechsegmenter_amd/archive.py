@@ -29,7 +29,7 @@ def _default_comm(device):
 
 
 def segment_archive(segment_file, linput, loutput=None, output_format='csv', sizes=None, skipifexist=False,
-                    capacity=None, device=None, comm=None):
+                    capacity=None, device=None, comm=None, batch_files=None, workers=None, batch_seconds=None):
     """segment_file: a `Segmenter` (its share of the files runs through pipeline.process_files), or any callable
     path -> [(label, start_sec, stop_sec)] with times on the 20 ms grid (what Segmenter.__call__ returns).  linput / loutput: all files, identical on every rank.
     Returns (table, lmsg): table = {file_index: [(label, start_sec, stop_sec)]} for ALL files (gathered),
@@ -53,7 +53,8 @@ def segment_archive(segment_file, linput, loutput=None, output_format='csv', siz
     # communicator's timeout: ISS_COMM_TIMEOUT_S on RCCL, the process group's timeout on torch.distributed.)
     cap = capacity or max(1024, 64 * (len(linput) // world + 1))      # the same on every rank, failing or not
     try:
-        local, lmsg = _segment_share(segment_file, linput, loutput, fexport, mine, skipifexist)
+        local, lmsg = _segment_share(segment_file, linput, loutput, fexport, mine, skipifexist,
+                                     dict(batch_files=batch_files, workers=workers, batch_seconds=batch_seconds))
     except BaseException:
         if comm:
             try:
@@ -68,7 +69,7 @@ def segment_archive(segment_file, linput, loutput=None, output_format='csv', siz
     return sharding.unpack_segments(allrows), lmsg
 
 
-def _segment_share(segment_file, linput, loutput, fexport, mine, skipifexist):
+def _segment_share(segment_file, linput, loutput, fexport, mine, skipifexist, pipe_kw):
     """This rank's files -> ((k,4) int32 segment rows, lmsg)."""
     rows, lmsg = [], []
     if hasattr(segment_file, 'batch_process') and hasattr(segment_file, 'ctx'):
@@ -99,7 +100,7 @@ def _segment_share(segment_file, linput, loutput, fexport, mine, skipifexist):
             got[k] = sharding.pack_segments(mine[k], [(lab, int(round(s / .02)), int(round(e / .02))) for lab, s, e in lseg])
             msgs[k] = (dst, 0, 'ok ' + str(secs + time.time() - b))      # per-file time, segmenter.py:322-327
 
-        pipeline.process_files(seg, [linput[i] for i in mine], on_result, skip=skip)
+        pipeline.process_files(seg, [linput[i] for i in mine], on_result, skip=skip, **pipe_kw)
         rows = [got[k] for k in sorted(got)]
         lmsg = [msgs[k] for k in range(len(mine))]
         mine = []

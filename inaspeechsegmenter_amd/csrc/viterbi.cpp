@@ -22,18 +22,18 @@ inline bool beats(double cand, double best) {      // numpy argmax ordering: NaN
     return cand > best || std::isnan(cand);
 }
 
-template <typename E>
-int viterbi_impl(const E* em, int64_t T, int32_t K, const double* tr, int32_t* out) {
-    if (!em || !tr || !out || T < 0 || K < 1 || K > 16) return ISS_EINVAL;
+// em(t, k): emission score of state k at step t, already promoted to float64
+template <class EmFn>
+int viterbi_core(EmFn em, int64_t T, int32_t K, const double* tr, int32_t* out) {
+    if (!tr || !out || T < 0 || K < 1 || K > 16) return ISS_EINVAL;
     if (T == 0) return ISS_OK;
     std::vector<uint8_t> P((size_t)T * K);
     double va[16], vb[16];
     double* prev = va;
     double* cur = vb;
     const double init = std::log(1.0 / (double)K);
-    for (int k = 0; k < K; ++k) { prev[k] = (double)em[k] + init; P[k] = (uint8_t)k; }
+    for (int k = 0; k < K; ++k) { prev[k] = em(0, k) + init; P[k] = (uint8_t)k; }
     for (int64_t t = 1; t < T; ++t) {
-        const E* e = em + t * K;
         uint8_t* p = &P[(size_t)t * K];
         for (int j = 0; j < K; ++j) {
             int best = 0;
@@ -43,7 +43,7 @@ int viterbi_impl(const E* em, int64_t T, int32_t K, const double* tr, int32_t* o
                 if (beats(v, bv)) { bv = v; best = k; }
             }
             p[j] = (uint8_t)best;
-            cur[j] = (double)e[j] + bv;
+            cur[j] = em(t, j) + bv;
         }
         double* tmp = prev; prev = cur; cur = tmp;
     }
@@ -57,6 +57,12 @@ int viterbi_impl(const E* em, int64_t T, int32_t K, const double* tr, int32_t* o
     return ISS_OK;
 }
 
+template <typename E>
+int viterbi_impl(const E* em, int64_t T, int32_t K, const double* tr, int32_t* out) {
+    if (!em) return ISS_EINVAL;
+    return viterbi_core([em, K](int64_t t, int k) { return (double)em[t * K + k]; }, T, K, tr, out);
+}
+
 }  // namespace
 
 extern "C" int iss_viterbi_f64(const double* em, int64_t T, int32_t K, const double* tr, int32_t* out) {
@@ -64,4 +70,32 @@ extern "C" int iss_viterbi_f64(const double* em, int64_t T, int32_t K, const dou
 }
 extern "C" int iss_viterbi_f32(const float* em, int64_t T, int32_t K, const double* tr, int32_t* out) {
     return viterbi_impl<float>(em, T, K, tr, out);
+}
+// The energy detector in one call (segmenter.py:69-73 behind the threshold): raw activity `loge > threshold` compared in
+// float64 like numpy compares a float32 array with a float64 scalar (a NaN threshold -- all-silent input -- is never
+// exceeded), two-state emissions pred2logemission (viterbi_utils.py:29-34) whose two values the caller passes as numpy
+// computed them (log(1e-10), log(1 - 1e-10)), smoothed by the same recursion as iss_viterbi_f64.  Saves the (T,2) float64
+// emission array, its fancy-indexed fill and its np.log per file.
+extern "C" int iss_energy_viterbi(const float* loge, int64_t T, double threshold, double log_eps, double log_1m_eps,
+                                  const double* tr, int32_t* out) {
+    if (!loge && T > 0) return ISS_EINVAL;
+    return viterbi_core([=](int64_t t, int k) {
+        const int active = (double)loge[t] > threshold ? 1 : 0;
+        return k == active ? log_1m_eps : log_eps;
+    }, T, 2, tr, out);
+}
+// Viterbi over nseg consecutive segments of one (sum(seg_len), K) float32 emission array, each smoothed on its own exactly
+// like iss_viterbi_f32 (segmenter.py:168-178 runs the smoothing per `inlabel` segment): one call per network and device pass
+// instead of one per segment.
+extern "C" int iss_viterbi_segments_f32(const float* em, const int64_t* seg_len, int64_t nseg, int32_t K, const double* tr,
+                                        int32_t* out) {
+    if (nseg < 0 || (nseg > 0 && (!em || !seg_len))) return ISS_EINVAL;
+    int64_t pos = 0;
+    for (int64_t s = 0; s < nseg; ++s) {
+        if (seg_len[s] < 0) return ISS_EINVAL;
+        const int rc = viterbi_impl<float>(em + pos * K, seg_len[s], K, tr, out + pos);
+        if (rc != ISS_OK) return rc;
+        pos += seg_len[s];
+    }
+    return ISS_OK;
 }

@@ -6,7 +6,7 @@ main thread runs the two Keras `predict` calls, the Viterbi smoothing and the ex
 launches, copies and Python bookkeeping become the limit.  Here files are processed in SUPER-BATCHES:
 
   decode threads   N files  ->  int16 PCM (RIFF parse, or the ffmpeg pipe)
-  packer           the PCM of a super-batch (default 32 files / <= 3 h of audio) is laid end to end in ONE page-locked
+  packer           the PCM of a super-batch (default <= 32 files / ~40 min of audio) is laid end to end in ONE page-locked
                    buffer, every file starting on a multiple of 160 samples: frame t of file f is then frame
                    off_f / 160 + t of the concatenation, and the frames that straddle two files are simply never used
   device worker    ONE H2D copy, ONE sidekit launch, one log-energy read-back; per-file energy Viterbi (compiled);
@@ -14,8 +14,8 @@ launches, copies and Python bookkeeping become the limit.  Here files are proces
                    gender windows, Viterbi; hand the segment lists to the exporter
   exporter         CSV / TextGrid writers
 
-Two device workers with a context each (own stream, own workspace) alternate super-batches, so while one is in its host
-phases (Viterbi, bookkeeping) the other's kernels run.  Results are identical to per-file processing: every frame and
+Four device workers with a context each (own stream, own workspace) take super-batches in turn, so while some are in their
+host phases (packing, Viterbi, bookkeeping) the others' kernels run.  Results are identical to per-file processing: every frame and
 every 20 ms slot is computed from the same samples by the same kernels (tests/test_gpu_segmenter.py).
 """
 import queue
@@ -117,6 +117,8 @@ class _Worker:
             self.owned = False
         self.ctx = ctx
         self.pin = None
+        # wall seconds this worker spent per phase since the last reset (bench.py reports them: where a step's host time goes)
+        self.stats = {k: 0.0 for k in ('pack', 'features', 'energy_host', 'cnn_device', 'smooth_host', 'batches', 'files')}
 
     def close(self):
         if self.owned:
@@ -139,6 +141,8 @@ class _Worker:
         """-> [ [(label, start_slot, stop_slot)] per file of the batch ]"""
         from . import segmenter as S
         seg, ctx = self.seg, self.ctx
+        st = self.stats
+        t_ = time.perf_counter()
         offs, pos = [], 0
         for s in batch.sigs:
             offs.append(pos)
@@ -150,9 +154,11 @@ class _Worker:
             else:                                    # float sources: what libsndfile's float32 read holds, re-quantised is NOT exact
                 raise TypeError('float media take the single-file path')
             buf[o + s.size:o + -(-s.size // FRAME_HOP) * FRAME_HOP] = 0
+        st['pack'] += time.perf_counter() - t_; t_ = time.perf_counter()
         ctx.set_signal(buf[:pos])
         ctx.sidekit()
         loge = ctx.get_loge()
+        st['features'] += time.perf_counter() - t_; t_ = time.perf_counter()
         g0 = [o // FRAME_HOP for o in offs]
         nfr = [(s.size - 400) // FRAME_HOP + 1 for s in batch.sigs]
         # energy segmentation per file (segmenter.py:261-267)
@@ -163,37 +169,70 @@ class _Worker:
             for lab, start, stop in S._binidx2seglist(S._energy_activity(le, seg.energy_ratio)[::2]):
                 lseg.append(('noEnergy' if lab == 0 else 'energy', start, stop))
             lsegs.append(lseg)
+        st['energy_host'] += time.perf_counter() - t_
+        wrs = [S._window_rows(nfr[f]) + np.int32(g0[f]) for f in range(len(lsegs))]
         for net in ([seg.vad, seg.gender] if seg.detect_gender else [seg.vad]):
-            rows, spans = [], []
+            t_ = time.perf_counter()
+            # slots of every `inlabel` segment of every file, in order (segmenter.py:156-159), in ONE device call; the
+            # per-segment smoothing (:168-178) in ONE host call on np.log of the whole probability array (elementwise: the
+            # same values as per-segment np.log calls); run-length encoding vectorised over the pass
+            rows, seglen = [], []
             for f, lseg in enumerate(lsegs):
-                wr = S._window_rows(nfr[f]) + np.int32(g0[f])
+                wr = wrs[f]
                 for lab, start, stop in lseg:
                     if lab == net.inlabel:
                         rows.append(wr[start:stop])
-                        spans.append(stop - start)
-            if rows:
-                probs, _fin = ctx.cnn_probs(net.net_id, np.concatenate(rows))
-            trans = S.diag_trans_exp(net.viterbi_arg, len(net.outlabels))
-            pos, out = 0, []
+                        seglen.append(stop - start)
+            if not rows:
+                st['smooth_host'] += time.perf_counter() - t_
+                continue
+            allrows = np.concatenate(rows)
+            st['smooth_host'] += time.perf_counter() - t_; t_ = time.perf_counter()
+            probs, _fin = ctx.cnn_probs(net.net_id, allrows)
+            st['cnn_device'] += time.perf_counter() - t_; t_ = time.perf_counter()
+            with np.errstate(divide='ignore'):
+                logp = np.log(probs)
+            states = _native.viterbi_segments(logp, seglen, S.diag_trans_exp(net.viterbi_arg, len(net.outlabels)))
+            seg_off = np.concatenate(([0], np.cumsum(seglen)))
+            change = np.empty(len(states), dtype=bool)
+            change[0] = True
+            np.not_equal(states[1:], states[:-1], out=change[1:])
+            change[seg_off[:-1]] = True
+            run_start = np.flatnonzero(change)
+            run_stop = np.concatenate((run_start[1:], [len(states)]))
+            run_seg = np.searchsorted(seg_off, run_start, side='right') - 1
+            run_lab = states[run_start].tolist()
+            rs = (run_start - seg_off[run_seg]).tolist()
+            re_ = (run_stop - seg_off[run_seg]).tolist()
+            run_seg = run_seg.tolist()
+            out, k, sidx = [], 0, 0
             for lseg in lsegs:
                 ret = []
                 for lab, start, stop in lseg:
                     if lab != net.inlabel:
                         ret.append((lab, start, stop))
                         continue
-                    n = stop - start
-                    with np.errstate(divide='ignore'):
-                        pred = S.viterbi_decoding(np.log(probs[pos:pos + n]), trans)
-                    pos += n
-                    for lab2, start2, stop2 in S._binidx2seglist(pred):
-                        ret.append((net.outlabels[int(lab2)], start2 + start, stop2 + start))
+                    while k < len(run_seg) and run_seg[k] == sidx:
+                        ret.append((net.outlabels[run_lab[k]], start + rs[k], start + re_[k]))
+                        k += 1
+                    sidx += 1
                 out.append(ret)
             lsegs = out
+            st['smooth_host'] += time.perf_counter() - t_
+        st['batches'] += 1
+        st['files'] += len(batch.sigs)
         return lsegs
 
 
-def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch_files=32, batch_seconds=3 * 3600,
-                  workers=2, decode_threads=4):
+DEFAULT_BATCH_FILES = 32          # files per device pass at most ...
+DEFAULT_BATCH_SECONDS = 40 * 60   # ... and ~40 minutes of audio (120 k slots: four full-size passes of each network).  Smaller
+RAMP_SECONDS = 300                # first pass of a call; doubles per pass up to batch_seconds
+DEFAULT_WORKERS = 4               # passes with more contexts in flight overlap the host phases better than 32-file passes on
+                                  # two contexts did (same box, 128 x 5 min files: 7.2 -> 8.2 audio-hours/s)
+
+
+def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch_files=None, batch_seconds=None,
+                  workers=None, decode_threads=4):
     """Segment `linput` with the networks of `seg`; on_result(index, src, lseg | None, errtext | None, secs) is called from
     the worker threads (serialised by a lock) as results become available, lseg = [(label, start_sec, stop_sec)], secs =
     this file's share of the processing time of its device pass (the pass's wall time / its files: what the reference's
@@ -201,6 +240,9 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
     skip: set of indices not to process.  Device failures (NativeError) and exceptions raised by on_result (unwritable
     outputs) propagate to the caller: the first one is re-raised here once every stage has drained."""
     from . import segmenter as S
+    batch_files = batch_files or DEFAULT_BATCH_FILES
+    batch_seconds = batch_seconds or DEFAULT_BATCH_SECONDS
+    workers = workers or DEFAULT_WORKERS
     items = [(i, src) for i, src in enumerate(linput) if not (skip and i in skip)]
     dec_q = queue.Queue(maxsize=4 * batch_files)
     budget = _AudioBudget(2 * batch_seconds * 16000)        # decoded audio waiting for the packer: <= 2 super-batches
@@ -211,6 +253,7 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
 
     def packer():
         cur = _Batch()
+        nbatch = 0
         try:
             while True:
                 it = dec_q.get()
@@ -232,9 +275,13 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
                     batch_q.put(('single', i, src, sig))
                     continue
                 cur.idx.append(i); cur.sigs.append(sig); cur.names.append(src)
-                if len(cur.idx) >= batch_files or cur.samples() >= batch_seconds * 16000:
+                # the first passes of a call are short (5, 10, 20 ... minutes of audio) so that the device starts as soon as
+                # a few files are decoded instead of after a whole 40-minute pass per worker
+                lim_s = min(batch_seconds, RAMP_SECONDS * (1 << min(nbatch, 20)))
+                if len(cur.idx) >= batch_files or cur.samples() >= lim_s * 16000:
                     batch_q.put(('batch', cur))
                     cur = _Batch()
+                    nbatch += 1
             if cur.idx:
                 batch_q.put(('batch', cur))
         finally:

@@ -54,6 +54,9 @@ def diag_trans_exp(exp, dim):
     return ret
 
 
+_ENERGY_TRANS = log_trans_exp(150, cost0=-5)
+
+
 def viterbi_decoding(emission, transition):
     """pyannote_viterbi.py:118-224 (unconstrained path) via the compiled host routine."""
     return _native.viterbi(emission, transition)
@@ -64,6 +67,10 @@ def _energy_activity(loge, ratio):
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')                 # all-silent input: mean of an empty slice
         threshold = np.mean(loge[np.isfinite(loge)]) + np.log(ratio)
+    if isinstance(loge, np.ndarray) and loge.dtype == np.float32 and isinstance(threshold, np.floating):
+        # the comparison (float64, like numpy compares a float32 array with a float64 scalar), pred2logemission and the
+        # two-state Viterbi in one compiled call: same arithmetic, no (T,2) float64 emission array per file
+        return _native.energy_viterbi(loge, np.float64(threshold), _ENERGY_TRANS)
     raw_activity = (loge > threshold)
     return viterbi_decoding(pred2logemission(raw_activity), log_trans_exp(150, cost0=-5))
 
@@ -357,11 +364,11 @@ class Segmenter:
         return self.segment_feats(mspec, loge, difflen, start_sec)
 
     def batch_process(self, linput, loutput, verbose=False, skipifexist=False, nbtry=1, trydelay=2., output_format='csv',
-                      batch_files=32, workers=2):
+                      batch_files=None, workers=None, batch_seconds=None):
         """segmenter.py:297-335: same arguments, same (t_batch_dur, nb_processed, avg, lmsg) with
         lmsg entries (dst, code, text), code 0 ok / 1 already exists / 2 error, in input order.
-        The files run through pipeline.process_files: decode threads, super-batches of `batch_files` files per device
-        pass, `workers` device contexts alternating (the reference overlaps the feature extraction of file i+1 with the
+        The files run through pipeline.process_files: decode threads, super-batches of at most `batch_files` files /
+        `batch_seconds` of audio per device pass (defaults 32 / 40 min), `workers` (default 4) device contexts in turn (the reference overlaps the feature extraction of file i+1 with the
         networks of file i, :377-387).  Undecodable or too-short media are per-file errors (code 2) as in the
         reference; device failures and unwritable outputs raise."""
         from . import pipeline
@@ -401,7 +408,7 @@ class Segmenter:
                 print('%d/%d' % (done[0] + len(skip), len(linput)), [msgs[i]])
 
         pipeline.process_files(self, linput, on_result, skip=skip, nbtry=nbtry, trydelay=trydelay,
-                               batch_files=batch_files, workers=workers)
+                               batch_files=batch_files, workers=workers, batch_seconds=batch_seconds)
         lmsg = [msgs[i] for i in range(len(linput))]
         t_batch_dur = time.time() - t_batch_start
         nb_processed = len([e for e in lmsg if e[1] == 0])

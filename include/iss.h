@@ -247,6 +247,15 @@ int iss_viterbi_f64(const double* emission, int64_t T, int32_t K, const double* 
                     int32_t* states_out);
 int iss_viterbi_f32(const float* emission, int64_t T, int32_t K, const double* transition,
                     int32_t* states_out);
+/* nseg consecutive segments of one (sum(seg_len), K) emission array, each smoothed on its own like iss_viterbi_f32
+ * (the per-segment loop of segmenter.py:168-178 in one call).                                                          */
+int iss_viterbi_segments_f32(const float* emission, const int64_t* seg_len, int64_t nseg, int32_t K,
+                             const double* transition, int32_t* states_out);
+/* `_energy_activity` behind its threshold (segmenter.py:69-73): raw activity loge[t] > threshold (float64 compare),
+ * pred2logemission (viterbi_utils.py:29-34; the caller passes numpy's log(eps) and log(1 - eps)), two-state Viterbi with the
+ * (2,2) transition matrix of log_trans_exp (viterbi_utils.py:36-42).  states_out[t] in {0, 1}.                         */
+int iss_energy_viterbi(const float* loge, int64_t T, double threshold, double log_eps, double log_1m_eps,
+                       const double* transition, int32_t* states_out);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,7 @@
 the C ABI, against the committed reference outputs (media/test.h5, reference get_features) and
 the oracle.  Tolerances: features 2e-5 abs (float64 pipeline, float32 result: FFT rounding differs
 from pocketfft at 1e-16, a few results land on the other side of a float32 rounding boundary);
-embeddings 1e-3 of the embedding scale (101 layers of float32 accumulation in a different order)."""
+embeddings 1e-4 of the embedding scale (measured 1e-5; the reference holds its ONNX x-vector to 4 decimals, run_test.py:189-195)."""
 import os
 
 import numpy as np
@@ -58,7 +58,7 @@ def test_resnet101_matches_reference_topology_golden(extractor):
     fea = [xi.T for xi in x]                                          # (144, 64) each, as VBxExtractor sees them
     emb = np.stack([extractor.get_embedding(f) for f in fea])
     scale = np.abs(g['emb']).max()
-    assert np.abs(emb - g['emb']).max() <= 1e-3 * scale, (np.abs(emb - g['emb']).max(), scale)
+    assert np.abs(emb - g['emb']).max() <= 1e-4 * scale, (np.abs(emb - g['emb']).max(), scale)
 
 
 def test_window_loop_and_tail_window(extractor):
@@ -71,7 +71,7 @@ def test_window_loop_and_tail_window(extractor):
     assert got[0][1] == (0.0, 1.44) and got[-1][1] == (round(wins[-1][0] / 100.0, 3), round(T / 100.0, 3))
     for (key, seg, x), (a, b) in zip(got, wins):
         ref = ovbx.resnet101_forward(extractor.params, fea[a:b].T[None])[0] * 10
-        assert np.abs(x - ref).max() <= 1e-3 * np.abs(ref).max(), key
+        assert np.abs(x - ref).max() <= 1e-4 * np.abs(ref).max(), key
 
 
 def test_batched_equals_single(extractor):

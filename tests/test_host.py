@@ -609,6 +609,32 @@ def test_pipeline_failure_drains_every_stage(tmp_path):
     assert not th.is_alive() and isinstance(out['exc'], OSError)
 
 
+def test_fused_energy_detector_equals_generic_path():
+    """iss_energy_viterbi (comparison + pred2logemission + two-state Viterbi in one compiled call) == the generic
+    `viterbi_decoding(pred2logemission(loge > threshold), log_trans_exp(150, cost0=-5))` of segmenter.py:69-73 -- random
+    log-energies, -inf frames, all-silent input (NaN threshold), thresholds that equal samples."""
+    rng = np.random.default_rng(0)
+    for trial in range(120):
+        T = int(rng.integers(1, 3000))
+        loge = rng.normal(-5, 3, T).astype(np.float32)
+        if trial % 5 == 0:
+            loge[rng.integers(0, T, T // 3)] = -np.inf
+        if trial % 17 == 0:
+            loge[:] = -np.inf
+        if trial % 7 == 0:
+            loge = np.round(loge)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            thr = np.mean(loge[np.isfinite(loge)]) + np.log(0.03)
+        assert isinstance(thr, np.float64)                      # float32 mean + float64 log: what the fast path keys on
+        want = S.viterbi_decoding(S.pred2logemission(loge > thr), S.log_trans_exp(150, cost0=-5))
+        got = S._energy_activity(loge, 0.03)
+        assert got.dtype == want.dtype and np.array_equal(got, want), trial
+        thr2 = np.float64(loge[0]) if np.isfinite(loge[0]) else thr
+        assert np.array_equal(_native.energy_viterbi(loge, thr2, S._ENERGY_TRANS),
+                              S.viterbi_decoding(S.pred2logemission(loge > thr2), S.log_trans_exp(150, cost0=-5))), trial
+
+
 def test_oracle_is_only_used_as_the_checker():
     """oracle/ is test infrastructure: nothing in the product package, the scripts or the tools may import it; bench.py only
     inside its cpu_baseline / parity legs and __graft_entry__ only inside smoke()."""
