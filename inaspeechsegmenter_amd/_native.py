@@ -88,6 +88,7 @@ def lib():
         'iss_prof_enable': (C.c_int, [vp, C.c_int]),
         'iss_prof_get': (C.c_int, [vp, C.c_int, pd, pi64, pd]),
         'iss_prof_reset': (C.c_int, [vp]),
+        'iss_prof_get_row': (C.c_int, [vp, C.c_int, pd, pi64]),
         'iss_viterbi_f64': (C.c_int, [pd, i64, i32, pd, pi32]),
         'iss_viterbi_f32': (C.c_int, [pf, i64, i32, pd, pi32]),
         'iss_energy_viterbi': (C.c_int, [pf, i64, C.c_double, C.c_double, C.c_double, pd, pi32]),
@@ -431,3 +432,9 @@ class Context:
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         self._ck(self._L.iss_prof_get(self._h, kind, C.byref(ms), C.byref(n), C.byref(fl)), 'iss_prof_get')
         return ms.value, n.value, fl.value
+
+    def prof_get_row(self, row):
+        """(ms, launches) of op-program row `row` since the last prof_reset (per-layer view of the same event brackets)."""
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self._L.iss_prof_get_row(self._h, int(row), C.byref(ms), C.byref(n)), 'iss_prof_get_row')
+        return ms.value, n.value

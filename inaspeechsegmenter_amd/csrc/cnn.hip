@@ -23,6 +23,7 @@
 //   statpool_kernel      mean || std over time                           (resnet.py:123-127)
 #include "conv_common.h"
 #include "conv_ws.h"
+#include "conv_pw.h"
 
 using namespace issk;
 
@@ -1006,6 +1007,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         ws = ws && fused;
         iss_prof_begin(c, 0, fl);
         iss_prof_tag(c, ws || ws_plain || ws_nh2 ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
+        iss_prof_row(c, r);
         if (ws_nh2) {
             const unsigned ngroups = (unsigned)((a.M + WS_TM - 1) / WS_TM);         // one 512-row tile per group
             const unsigned ny = (unsigned)(a.Cout / (2 * BN));
@@ -1051,6 +1053,12 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const bool pointwise = !no_pw && a.mode == 0 && tr && a.H_k == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt_ == 0 &&
                                    a.pl_ == 0 && R[ISS_C_HO] == a.H && R[ISS_C_WO] == a.W && a.Kpad == a.Cin;
             if (pointwise) iss_prof_tag(c, ISS_PROF_PW);
+            static const bool no_pws = getenv("ISS_NO_PWS") != nullptr;          // diagnostic: the round-2 pointwise kernel
+            // deep-K layers (the segmenter nets' dense head, K = 4992 / 8320: three column tiles sweep 2.5 MB of A side by side
+            // and live on their L2 hits) measured 8 % slower on the deeper ring: they keep the two-set kernel
+            if (pointwise && !no_pws && issk::pws_supported(a) && a.Kpad <= 2048)
+                issk::iss_pws_launch(a, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), c->stream);
+            else
             if (pointwise) hipLaunchKernelGGL(conv_x3_pw_kernel, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), dim3(256), 0, c->stream, a);
             else
             if (ntn == 4) hipLaunchKernelGGL((conv_x3_kernel<0, true, 4>), gridw, dim3(256), 0, c->stream, a);

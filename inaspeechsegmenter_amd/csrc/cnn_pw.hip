@@ -1,0 +1,12 @@
+// Instantiation unit of conv_x3_pws_kernel (conv_pw.h): streaming pointwise GEMM, four epilogue forms.
+#include "conv_pw.h"
+
+namespace issk {
+void iss_pws_launch(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    const bool simple = a.act <= 1 && !a.ps;
+    if (a.res && simple) hipLaunchKernelGGL((conv_x3_pws_kernel<true, true>), grid, dim3(256), 0, st, a);
+    else if (simple) hipLaunchKernelGGL((conv_x3_pws_kernel<false, true>), grid, dim3(256), 0, st, a);
+    else if (a.res) hipLaunchKernelGGL((conv_x3_pws_kernel<true, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_x3_pws_kernel<false, false>), grid, dim3(256), 0, st, a);
+}
+}  // namespace issk

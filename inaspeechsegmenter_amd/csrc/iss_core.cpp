@@ -302,13 +302,17 @@ static hipEvent_t get_event(iss_ctx* c) {
 }
 void iss_prof_begin(iss_ctx* c, int kind, double flops) {
     if (!c->prof) return;
-    iss_ctx::Pending p; p.a = get_event(c); p.b = get_event(c); p.kind = kind; p.sub = -1; p.flops = flops;
+    iss_ctx::Pending p; p.a = get_event(c); p.b = get_event(c); p.kind = kind; p.sub = -1; p.row = -1; p.flops = flops;
     (void)hipEventRecord(p.a, c->stream);
     c->pending.push_back(p);
 }
 void iss_prof_tag(iss_ctx* c, int sub) {
     if (!c->prof || c->pending.empty() || sub < 0 || sub >= ISS_PROF_KINDS) return;
     c->pending.back().sub = sub;
+}
+void iss_prof_row(iss_ctx* c, int row) {
+    if (!c->prof || c->pending.empty() || row < 0 || row >= ISS_PROF_ROWS) return;
+    c->pending.back().row = row;
 }
 void iss_prof_end(iss_ctx* c) {
     if (!c->prof || c->pending.empty()) return;
@@ -320,6 +324,7 @@ void iss_prof_collect(iss_ctx* c) {      // stream must be idle
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             c->prof_ms[p.kind] += ms; c->prof_launch[p.kind] += 1; c->prof_flops[p.kind] += p.flops;
             if (p.sub >= 0) { c->prof_ms[p.sub] += ms; c->prof_launch[p.sub] += 1; c->prof_flops[p.sub] += p.flops; }
+            if (p.row >= 0) { c->prof_row_ms[p.row] += ms; c->prof_row_launch[p.row] += 1; }
         }
         c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b);
     }
@@ -331,6 +336,15 @@ extern "C" int iss_prof_reset(iss_ctx* c) {
     ISS_HIP(c, hipStreamSynchronize(c->stream));
     iss_prof_collect(c);
     for (int i = 0; i < ISS_PROF_KINDS; ++i) { c->prof_ms[i] = 0; c->prof_launch[i] = 0; c->prof_flops[i] = 0; }
+    for (int i = 0; i < ISS_PROF_ROWS; ++i) { c->prof_row_ms[i] = 0; c->prof_row_launch[i] = 0; }
+    return ISS_OK;
+}
+extern "C" int iss_prof_get_row(iss_ctx* c, int row, double* ms, int64_t* launches) {
+    if (!c || row < 0 || row >= ISS_PROF_ROWS) return ISS_EINVAL;
+    ISS_HIP(c, hipStreamSynchronize(c->stream));
+    iss_prof_collect(c);
+    if (ms) *ms = c->prof_row_ms[row];
+    if (launches) *launches = c->prof_row_launch[row];
     return ISS_OK;
 }
 extern "C" int iss_prof_get(iss_ctx* c, int kind, double* ms, int64_t* launches, double* flops) {

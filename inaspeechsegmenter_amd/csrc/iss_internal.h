@@ -95,7 +95,9 @@ struct iss_ctx {
     double prof_ms[ISS_PROF_KINDS] = {};
     int64_t prof_launch[ISS_PROF_KINDS] = {};
     double prof_flops[ISS_PROF_KINDS] = {};
-    struct Pending { hipEvent_t a, b; int kind; int sub; double flops; };
+    double prof_row_ms[ISS_PROF_ROWS] = {};
+    int64_t prof_row_launch[ISS_PROF_ROWS] = {};
+    struct Pending { hipEvent_t a, b; int kind; int sub; int row; double flops; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_pool;
 };
@@ -116,6 +118,7 @@ void iss_stage_mark(iss_ctx* c, int slot);                                      
 // profiling brackets: record events around a kernel class when enabled
 void iss_prof_begin(iss_ctx* c, int kind, double flops);
 void iss_prof_tag(iss_ctx* c, int sub);      // kernel class (ISS_PROF_* >= 3) of the launch bracketed last: counted there too
+void iss_prof_row(iss_ctx* c, int row);      // op-program row of the launch bracketed last
 void iss_prof_end(iss_ctx* c);
 void iss_prof_collect(iss_ctx* c);
 

@@ -235,6 +235,10 @@ int iss_comm_info(iss_ctx* ctx, int32_t* world, int32_t* rank, int32_t* version,
 int iss_prof_enable(iss_ctx* ctx, int on);
 int iss_prof_get(iss_ctx* ctx, int kind, double* ms, int64_t* launches, double* flops);
 int iss_prof_reset(iss_ctx* ctx);
+/* Per-layer view of the same HIP-event brackets: time and launch count of op-program row `row` (the conv / dense row of
+ * the loaded network that a launch executed; rows of different networks share the index space) since the last reset. */
+#define ISS_PROF_ROWS      512
+int iss_prof_get_row(iss_ctx* ctx, int row, double* ms, int64_t* launches);
 
 /* ------------------------------------------------------------------ host only
  * Viterbi smoothing, replaces pyannote_viterbi.py:118-224 `viterbi_decoding` on the
