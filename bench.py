@@ -103,7 +103,7 @@ def synth_recording(file_index, n_samples, device):
 
 
 # ------------------------------------------------------------------------------ per-kernel roofline
-GEMM_CLASSES = ((3, 'conv_x3_ws_kernel'), (4, 'conv_x3_fp_kernel'), (5, 'conv_x3_pw_kernel'), (6, 'conv_x3_kernel'),
+GEMM_CLASSES = ((3, 'conv_x3_ws_kernel'), (4, 'conv_x3_fp_kernel'), (5, 'conv_x3_pws_kernel / conv_x3_pws2_kernel / conv_x3_pw_kernel'), (6, 'conv_x3_kernel'),
                 (7, 'conv1_patch_x3_kernel'), (8, 'conv_igemm_kernel'))     # include/iss.h ISS_PROF_*
 
 
@@ -481,6 +481,7 @@ def bench_vbx(args, torch, dev, local_rank, rank, world):
     step()
     conv_ms, conv_launches, conv_flops = ctx.prof_get(0)
     fb_ms, _, _ = ctx.prof_get(1)                    # vbx_fbank_kernel alone (HIP events on the library's stream)
+    ktab, kdom = gemm_kernel_table([ctx], MFMA_BF16_PEAK_TF if args.precision == 'bf16x3' else MFMA_F32_PEAK_TF)
     ctx.prof_enable(False)
     # feature stage: algorithmic bytes = PCM16 in + the cached dither stream (f64) + (T, 64) f32 out
     T = n // 160
@@ -521,6 +522,7 @@ def bench_vbx(args, torch, dev, local_rank, rank, world):
             "roofline": {"bound": "mfma", "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0, "peak": MFMA_BF16_PEAK_TF,
                          "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF) if conv_ms else 0.0,
                          "unit": "TFLOP/s", "kernel_ms_per_step": conv_ms, "launches_per_step": conv_launches, "flops_per_step": conv_flops,
+                         "dominant": kdom, "kernels": ktab,
                          "secondary": {"kernel": "vbx_fbank_kernel + vbx_cumsum_kernel + vbx_cmn_kernel (PCM16 + dither -> 64-band fbank, CMN)",
                                        "bound": "hbm", "algorithmic_bytes": fea_bytes, "stage_ms_per_step": tf / args.steps * 1e3,
                                        "fbank_kernel_ms": fb_ms,

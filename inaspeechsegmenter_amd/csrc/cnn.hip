@@ -1056,6 +1056,14 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             static const bool no_pws = getenv("ISS_NO_PWS") != nullptr;          // diagnostic: the round-2 pointwise kernel
             // deep-K layers (the segmenter nets' dense head, K = 4992 / 8320: three column tiles sweep 2.5 MB of A side by side
             // and live on their L2 hits) measured 8 % slower on the deeper ring: they keep the two-set kernel
+            static const bool no_pws2 = getenv("ISS_NO_PWS2") != nullptr;        // diagnostic: 64-column tiles everywhere
+            // strided 1x1 (shortcut projections): the streaming kernel on a strided pixel list
+            const bool pw_strided = !no_pws && !no_pws2 && a.mode == 0 && tr && a.H_k == 1 && a.kw == 1 && (a.sh > 1 || a.sw > 1) && a.pt_ == 0 &&
+                                    a.pl_ == 0 && a.Kpad == a.Cin && a.Kpad <= 2048 && issk::pws2_strided_supported(a, R[ISS_C_HO], R[ISS_C_WO]);
+            if (pw_strided) { iss_prof_tag(c, ISS_PROF_PW); issk::iss_pws2_launch(a, c->stream, true); }
+            else
+            if (pointwise && !no_pws && !no_pws2 && issk::pws2_supported(a) && a.Kpad <= 2048) issk::iss_pws2_launch(a, c->stream);
+            else
             if (pointwise && !no_pws && issk::pws_supported(a) && a.Kpad <= 2048)
                 issk::iss_pws_launch(a, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), c->stream);
             else

@@ -101,6 +101,24 @@ __device__ __forceinline__ void map_row(const ConvArgs& p, long long m, int& b, 
     ox = qx * p.pw + dx;
 }
 
+// 32-bit replica of map_row (the launch guarantees M < 2^31) on host-precomputed reciprocals (ConvArgs::dv_*):
+// it runs three times per tile, and run-time integer division is ~28 (32-bit) / ~100 (64-bit) instructions on gfx950.
+template <class P>
+__device__ __forceinline__ void map_row32(const P& p, int m, int& b, int& oy, int& ox) {
+    int q = m, dy = 0, dx = 0;
+    if (p.pp > 1) {
+        q = fast_div(p, 0, m);                       // m / pp
+        const int j = m - q * p.pp;
+        dy = fast_div(p, 1, j); dx = j - dy * p.pw;  // j / pw
+    }
+    const int hw = p.Hq * p.Wq;
+    b = fast_div(p, 2, q);                           // q / (Hq * Wq)
+    const int rem = q - b * hw;
+    const int qy = fast_div(p, 3, rem), qx = rem - qy * p.Wq;    // rem / Wq
+    oy = qy * p.ph + dy;
+    ox = qx * p.pw + dx;
+}
+
 // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed); give every XCD one contiguous
 // range of M tiles so that neighbouring tiles (which share im2col halos) hit the same L2.
 __device__ __forceinline__ unsigned tile_of_block(unsigned bid, unsigned nblk) {

@@ -25,24 +25,6 @@ struct Frags { bf16x8 ah, al, b0h, b0l, b1h, b1l; };
 // B-stage parity and the footprint-slice schedule become constants.  (With a run-time tap loop the
 // scalar bookkeeping alone was ~80 SALU instructions + a dozen taken branches per 12 MFMAs, more
 // than the five issue slots a wave has between two back-to-back MFMAs.)
-// 32-bit replica of map_row (the launch guarantees M < 2^31) on host-precomputed reciprocals (ConvArgs::dv_*):
-// it runs three times per tile, and run-time integer division is ~28 (32-bit) / ~100 (64-bit) instructions on gfx950.
-template <class P>
-__device__ __forceinline__ void map_row32(const P& p, int m, int& b, int& oy, int& ox) {
-    int q = m, dy = 0, dx = 0;
-    if (p.pp > 1) {
-        q = fast_div(p, 0, m);                       // m / pp
-        const int j = m - q * p.pp;
-        dy = fast_div(p, 1, j); dx = j - dy * p.pw;  // j / pw
-    }
-    const int hw = p.Hq * p.Wq;
-    b = fast_div(p, 2, q);                           // q / (Hq * Wq)
-    const int rem = q - b * hw;
-    const int qy = fast_div(p, 3, rem), qx = rem - qy * p.Wq;    // rem / Wq
-    oy = qy * p.ph + dy;
-    ox = qx * p.pw + dx;
-}
-
 // Persistent workgroups: a 128-row tile is only 7-14 k cycles of MFMA work, while filling the
 // pipeline (footprint + weight loads from HBM/L2, geometry) and draining it (32 stores per lane)
 // cost several thousand cycles -- one-tile-per-workgroup launches measured 33 % matrix-pipe

@@ -288,11 +288,247 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pws_kernel(const ConvArgs p) {
 #undef ISS_PWS_GATHER
 }
 
+// ------------------------------------------------------------------------------------------
+// conv_x3_pws2_kernel: the residual-free layers with a multiple of 128 output channels (ResNet-101's 512 -> 128 /
+// 1024 -> 256 reductions, the transition layers) on 128 x 128 tiles.  With 64-column tiles the two (or four) column tiles
+// of a row tile run on neighbouring workgroups of one XCD and are meant to share the A rows through its L2; measured
+// (rocprofv3 --pmc FETCH_SIZE per layer, tools/pmc_by_order.py): 512 -> 128 fetches 1.67 x, 512 -> 256 2.10 x, 1024 -> 256
+// 1.72 x its algorithmic bytes -- the second column tile misses -- and these layers ran at 3.6 TB/s where the one-column-tile
+// layers (256 -> 64, 128 -> 32) reach 5.4.  Here one workgroup computes all 128 columns of its rows: A is read, split and
+// staged once per 128 columns.  Same asm loads / counted waits as above with a two-set ring (depth made no difference on
+// these read-dominated layers); 24 MFMAs per k-step and wave (four 32 x 32 accumulators).  LDS: 40 KB A + 40 KB W = 80 KB
+// exactly (two workgroups per CU), so the epilogue's transpose staging ALIASES the A buffer the last k-step has just
+// consumed, with one more barrier per tile before the next k-step's conversion may overwrite it.
+// STRIDED: a 1x1 convolution with stride > 1 (the ResNet shortcut projections, resnet.py:60-64) -- the same GEMM on a
+// strided pixel list: only the per-tile row addresses change (map_row32 once per tile), the k loop does not.
+template <bool SIMPLE, bool STRIDED = false>
+__global__ __launch_bounds__(256, 2) void conv_x3_pws2_kernel(const ConvArgs p) {
+    constexpr int BN2 = 128;
+    constexpr int ABUF = 2 * BM * XLD * 2;           // bytes of one A buffer: hi | lo
+    constexpr int WBUF = 2 * BN2 * XLD * 2;          // bytes of one W buffer: hi | lo
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ABUF + 2 * WBUF];
+    static_assert(2 * ABUF + 2 * WBUF == 81920 && ABUF >= 4 * 32 * PWS_ELD * 4, "LDS budget");
+    auto sAh = [&](int b) { return reinterpret_cast<uint16_t*>(smem + b * ABUF); };
+    auto sAl = [&](int b) { return reinterpret_cast<uint16_t*>(smem + b * ABUF + ABUF / 2); };
+    auto sBh = [&](int b) { return reinterpret_cast<uint16_t*>(smem + 2 * ABUF + b * WBUF); };
+    auto sBl = [&](int b) { return reinterpret_cast<uint16_t*>(smem + 2 * ABUF + b * WBUF + WBUF / 2); };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned ntiles = p.nblk * p.nblk_n;       // nblk_n = Cout / 128 here
+    unsigned t = blockIdx.x;
+    if (t >= ntiles) return;
+    const int k8 = tid & 7, lr = tid >> 3;
+    const int br = tid >> 2, bseg = tid & 3;         // W staging: 8 bf16 of weight rows br and br + 64, hi and lo
+    const int li = lane & 31, lh = lane >> 5;
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+
+    struct Tile { long long m0; int n0; bool full; const float* abase; unsigned ao[4]; unsigned wo[2]; };
+    auto coords = [&](unsigned tt) {
+        Tile T;
+        unsigned mt, nt;
+        gemm_tile_of_block(tt, p.nblk, p.nblk_n, mt, nt);
+        T.m0 = (long long)mt * BM;
+        T.n0 = (int)nt * BN2;
+        const int left = (int)(p.M - T.m0 < BM ? p.M - T.m0 : BM);
+        T.full = left == BM;                         // Cout % 128 == 0: no column edge
+        if (STRIDED) {                               // GEMM row m = output pixel (b, oy, ox) -> input pixel (b, oy * sh, ox * sw)
+            auto pix = [&](int m) {
+                int b, oy, ox;
+                map_row32(p, m, b, oy, ox);
+                return ((long long)b * p.H + oy * p.sh) * p.W + ox * p.sw;
+            };
+            const long long p0 = pix((int)T.m0);
+            T.abase = p.in + p0 * p.Cin;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                T.ao[j] = (unsigned)((pix((int)T.m0 + (lr + 32 * j < left ? lr + 32 * j : left - 1)) - p0) * p.Cin + k8 * 4) * 4u;
+        } else {
+            T.abase = p.in + T.m0 * p.Cin;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) T.ao[j] = (unsigned)((lr + 32 * j < left ? lr + 32 * j : left - 1) * p.Cin + k8 * 4) * 4u;
+        }
+        T.wo[0] = (unsigned)((T.n0 + br) * p.Kpad + bseg * 8) * 2u;
+        T.wo[1] = (unsigned)((T.n0 + br + 64) * p.Kpad + bseg * 8) * 2u;
+        return T;
+    };
+
+    f32x4 ra[2][4];
+    u32x4 rh[2][2], rl[2][2];
+    f32x4 b4[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rh[i][0] = rh[i][1] = rl[i][0] = rl[i][1] = u32x4{0, 0, 0, 0};
+    }
+    b4[0] = b4[1] = b4[2] = b4[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned issued = 0, mark[2], mark_epi = 0;
+
+    const int nk = p.Kpad / XBK;
+    unsigned tl = t;
+    Tile TL = coords(t);
+    int ktl = 0;
+    Tile TC = TL;
+    int ktc = 0;
+
+#define ISS_PWS2_GATHER(I)                                                                                           \
+    {                                                                                                                \
+        const float* sa_ = TL.abase + ktl * XBK;                                                                     \
+        const uint16_t* sh_ = p.wh + ktl * XBK;                                                                      \
+        const uint16_t* sl_ = p.wl + ktl * XBK;                                                                      \
+        ISS_PWS_LD(ra[I][0], TL.ao[0], sa_); ISS_PWS_LD(ra[I][1], TL.ao[1], sa_);                                    \
+        ISS_PWS_LD(ra[I][2], TL.ao[2], sa_); ISS_PWS_LD(ra[I][3], TL.ao[3], sa_);                                    \
+        ISS_PWS_LD(rh[I][0], TL.wo[0], sh_); ISS_PWS_LD(rl[I][0], TL.wo[0], sl_);                                    \
+        ISS_PWS_LD(rh[I][1], TL.wo[1], sh_); ISS_PWS_LD(rl[I][1], TL.wo[1], sl_);                                    \
+        issued += 8; mark[I] = issued;                                                                               \
+        if (++ktl == nk) {                                                                                           \
+            ktl = 0;                                                                                                 \
+            tl = tl + gridDim.x < ntiles ? tl + gridDim.x : tl;                                                      \
+            TL = coords(tl);                                                                                         \
+        }                                                                                                            \
+    }
+#define ISS_PWS2_STAGE(I, BUF)                                                                                       \
+    {                                                                                                                \
+        pws_wait_outstanding(issued - mark[I]);                                                                      \
+        asm volatile("" : "+v"(ra[I][0]), "+v"(ra[I][1]), "+v"(ra[I][2]), "+v"(ra[I][3]), "+v"(rh[I][0]), "+v"(rl[I][0]),   \
+                          "+v"(rh[I][1]), "+v"(rl[I][1]));                                                           \
+        uint16_t* ah_ = sAh(BUF); uint16_t* al_ = sAl(BUF); uint16_t* bh_ = sBh(BUF); uint16_t* bl_ = sBl(BUF);      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+            bf16x4 h, l;                                                                                             \
+            pws_split4(ra[I][j], h, l);                                                                              \
+            *reinterpret_cast<bf16x4*>(&ah_[(lr + 32 * j) * XLD + k8 * 4]) = h;                                      \
+            *reinterpret_cast<bf16x4*>(&al_[(lr + 32 * j) * XLD + k8 * 4]) = l;                                      \
+        }                                                                                                            \
+        *reinterpret_cast<u32x4*>(&bh_[br * XLD + bseg * 8]) = rh[I][0];                                             \
+        *reinterpret_cast<u32x4*>(&bl_[br * XLD + bseg * 8]) = rl[I][0];                                             \
+        *reinterpret_cast<u32x4*>(&bh_[(br + 64) * XLD + bseg * 8]) = rh[I][1];                                      \
+        *reinterpret_cast<u32x4*>(&bl_[(br + 64) * XLD + bseg * 8]) = rl[I][1];                                      \
+    }
+
+    auto preload_epi = [&](const Tile& T) {          // bias of the tile's 128 channels, in the store layout
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) ISS_PWS_LD(b4[t2], (unsigned)(T.n0 + 32 * t2 + ec) * 4u, p.bias);
+        issued += 4;
+        mark_epi = issued;
+    };
+
+    floatx16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+    const int aoff = (wv * 32 + li) * XLD + lh * 8;
+    const int boff_s = li * XLD + lh * 8;
+
+    auto epilogue = [&](const Tile& T, int ebuf) {   // ebuf: the A buffer the tile's last k-step has consumed
+        float* const E = reinterpret_cast<float*>(smem + ebuf * ABUF) + wv * 32 * PWS_ELD;
+        pws_wait_outstanding(issued - mark_epi);
+        asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+                v[0] = acc[t2][4 * g + 0]; v[1] = acc[t2][4 * g + 1]; v[2] = acc[t2][4 * g + 2]; v[3] = acc[t2][4 * g + 3];
+                *reinterpret_cast<f32x4*>(&E[li * PWS_ELD + 8 * g + 4 * lh]) = v;
+            }
+            const int c = T.n0 + 32 * t2 + ec;
+            f32x4 s4 = f32x4{1.f, 1.f, 1.f, 1.f}, t4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!SIMPLE && p.ps) { s4 = *reinterpret_cast<const f32x4*>(p.ps + c); t4 = *reinterpret_cast<const f32x4*>(p.pt + c); }
+            const long long mrow = T.m0 + wv * 32 + er;
+            float* orow = p.out + (size_t)mrow * p.Cout + c;
+            f32x4 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(&E[(8 * j + er) * PWS_ELD + ec]);
+                v += b4[t2];
+                if (p.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                else if (!SIMPLE && p.act > 1) { v[0] = apply_act(v[0], p.act); v[1] = apply_act(v[1], p.act); v[2] = apply_act(v[2], p.act); v[3] = apply_act(v[3], p.act); }
+                if (!SIMPLE && p.ps) v = v * s4 + t4;
+                o[j] = v;
+            }
+            if (T.full) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(orow + (size_t)(8 * j) * p.Cout) = o[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (mrow + 8 * j < p.M) *reinterpret_cast<f32x4*>(orow + (size_t)(8 * j) * p.Cout) = o[j];
+            }
+        }
+        if (T.full) issued += 16;
+    };
+
+    int cur = 0;
+    bool done = false;
+#define ISS_PWS2_STEP(LD, ST)                                                                                        \
+    {                                                                                                                \
+        ISS_PWS2_GATHER(LD)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_setprio(2);                                                                               \
+        {                                                                                                            \
+            const uint16_t* ah_ = sAh(cur); const uint16_t* al_ = sAl(cur);                                          \
+            const uint16_t* bh_ = sBh(cur); const uint16_t* bl_ = sBl(cur);                                          \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                       \
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&ah_[aoff + ks * 16]);                            \
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&al_[aoff + ks * 16]);                            \
+                bf16x8 bh[4], bl[4];                                                                                 \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                      \
+                    bh[c] = *reinterpret_cast<const bf16x8*>(&bh_[boff_s + c * 32 * XLD + ks * 16]);                 \
+                    bl[c] = *reinterpret_cast<const bf16x8*>(&bl_[boff_s + c * 32 * XLD + ks * 16]);                 \
+                }                                                                                                    \
+                /* C^T: rows = channels, columns = pixels; the four accumulators take turns */                       \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[c], al, acc[c], 0, 0, 0); \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[c], ah, acc[c], 0, 0, 0); \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[c], ah, acc[c], 0, 0, 0); \
+            }                                                                                                        \
+        }                                                                                                            \
+        __builtin_amdgcn_s_setprio(0);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        ISS_PWS2_STAGE(ST, cur ^ 1)                                                                                  \
+        __syncthreads();                                                                                             \
+        cur ^= 1;                                                                                                    \
+        if (++ktc == nk) {                           /* tile complete */                                            \
+            epilogue(TC, cur ^ 1);                                                                                   \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                            \
+                _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;                                      \
+            ktc = 0;                                                                                                 \
+            t += gridDim.x;                                                                                          \
+            if (t >= ntiles) done = true;                                                                            \
+            else { TC = coords(t); preload_epi(TC); }                                                                \
+            __syncthreads();                         /* the staging aliased an operand buffer */                    \
+        }                                                                                                            \
+    }
+
+    preload_epi(TC);
+    ISS_PWS2_GATHER(0) ISS_PWS2_GATHER(1)
+    ISS_PWS2_STAGE(0, 0)
+    __syncthreads();
+    for (;;) {
+        ISS_PWS2_STEP(0, 1)
+        if (done) break;
+        ISS_PWS2_STEP(1, 0)
+        if (done) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef ISS_PWS2_STEP
+#undef ISS_PWS2_STAGE
+#undef ISS_PWS2_GATHER
+}
+
 // host: can this launch run on conv_x3_pws_kernel?
 inline bool pws_supported(const ConvArgs& a) {
     return a.bias != nullptr && a.Cout % 4 == 0 && a.pp == 1 && a.Kpad == a.Cin && a.Kpad % XBK == 0 &&
            (long long)BM * a.Cin * 4 < (1ll << 31) && (long long)a.Cout * a.Kpad * 2 < (1ll << 31) && (long long)BM * a.Cout * 4 < (1ll << 31);
 }
+inline bool pws2_supported(const ConvArgs& a) { return pws_supported(a) && !a.res && a.Cout % 128 == 0; }
+// strided 1x1: rows of one tile may span several samples; their byte offsets from the tile's first pixel stay below 2^31
+inline bool pws2_strided_supported(const ConvArgs& a, int Ho, int Wo) {
+    return pws2_supported(a) && a.M < (1ll << 31) && a.act <= 1 && !a.ps &&
+           ((long long)(BM / ((long long)Ho * Wo) + 2) * a.img_stride * 4 < (1ll << 31));
+}
 void iss_pws_launch(const ConvArgs& a, dim3 grid, hipStream_t st);               // cnn_pw.hip
+void iss_pws2_launch(const ConvArgs& a, hipStream_t st, bool strided = false);   // 128 x 128 tiles: sets its own column tiling and grid
 
 }  // namespace issk
