@@ -235,3 +235,62 @@ def test_shared_first_layer_needs_overlap(ctx):
     finally:
         del os.environ['ISS_NO_FUSE']
     assert n_a == n_b and np.array_equal(a, b)
+
+
+def _pw_program(rng, n, h, w, cin, specs):
+    """A chain of 1x1 convolutions lowered by hand (no channel padding): specs = [(cout, act, residual?, stride, affine?)].
+    A residual layer adds the activation two layers back IN PLACE (the ResNet bottleneck pattern, resnet.py:66-75).
+    -> (CompiledNet, x, float64 reference of the flattened output)."""
+    B = KM._Builder()
+    x = rng.normal(0, 1, (n, h, w, cin)).astype(np.float32)
+    acts = {0: lambda v: v, 1: lambda v: np.maximum(v, 0), 2: lambda v: 1 / (1 + np.exp(-v)), 3: np.tanh}
+    shape, src = (h, w, cin), _native.BUF_INPUT
+    vals = {src: x.astype(np.float64)}
+    bufs = [0, 1, 2]
+    hist = []
+    for cout, act, res, stride, affine in specs:
+        hh, ww, c = shape
+        Wm = rng.normal(0, np.sqrt(1.0 / c), (cout, c)).astype(np.float32)
+        b = rng.normal(0, 0.2, cout).astype(np.float32)
+        ps = rng.uniform(0.5, 1.5, cout).astype(np.float32) if affine else None
+        pt = rng.normal(0, 0.2, cout).astype(np.float32) if affine else None
+        dst = hist[-2] if res else next(bb for bb in bufs if bb != src and (len(hist) < 1 or bb != hist[-1]))
+        ho, wo = (hh - 1) // stride + 1, (ww - 1) // stride + 1
+        xin = vals[src][:, ::stride, ::stride, :]
+        y = xin @ Wm.astype(np.float64).T + b
+        if res:
+            y = y + vals[dst]
+        y = acts[act](y)
+        if affine:
+            y = y * ps + pt
+        shape = B.conv(src, dst, shape, Wm, 1, 1, stride, stride, 0, 0, ho, wo, bias=b, act=act, ps=ps, pt_=pt,
+                       res=dst if res else -1)
+        vals[dst] = y
+        hist.append(dst)
+        src = dst
+    return B.finish((h, w, cin), int(np.prod(shape)), False), x, vals[src].reshape(n, -1)
+
+
+@pytest.mark.parametrize('case', ['bottleneck_odd_channels', 'strided_projection', 'post_affine_and_sigmoid', 'k1024_n256'])
+def test_pointwise_streaming_kernels(ctx, prec, case):
+    """conv_x3_pws_kernel / conv_x3_pws2_kernel (conv_pw.h): partial row tiles (M % 128 != 0), partial column tiles
+    (Cout % 64 != 0), in-place residuals, the generic epilogue (sigmoid / tanh / post-activation affine), strided
+    1x1 projections and deep K, against a float64 reference of the same GEMM chain."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    if case == 'bottleneck_odd_channels':       # M = 5 * 7 * 11 = 385: three full row tiles + one of a single row
+        comp, x, ref = _pw_program(rng, 5, 7, 11, 64, [(96, 1, False, 1, False), (32, 1, False, 1, False),
+                                                        (96, 1, True, 1, False), (100, 3, False, 1, False)])
+    elif case == 'strided_projection':          # (8, 10) -> (4, 5): M = 9 * 20 = 180 rows spanning several samples per tile
+        comp, x, ref = _pw_program(rng, 9, 8, 10, 64, [(128, 0, False, 2, False), (256, 1, False, 1, False),
+                                                       (128, 1, False, 1, False), (256, 1, True, 1, False)])
+    elif case == 'post_affine_and_sigmoid':
+        comp, x, ref = _pw_program(rng, 3, 9, 15, 32, [(64, 1, False, 1, True), (128, 2, False, 1, True),
+                                                       (64, 1, True, 1, True), (36, 0, False, 1, False)])
+    else:                                       # 8 x 18 maps of ResNet-101's last stage: K = 1024 (32 k-steps), 4 x 128 columns
+        comp, x, ref = _pw_program(rng, 4, 8, 18, 1024, [(256, 1, False, 1, False), (1024, 1, False, 1, False)])
+    ctx.cnn_load(5, comp)
+    out = ctx.cnn_forward(5, x)
+    scale = max(1.0, np.abs(ref).max())
+    err = np.abs(out - ref).max() / scale
+    print(f'{case} [{prec}]: max rel err {err:.2e}')
+    assert err < 1e-4, (case, err)
