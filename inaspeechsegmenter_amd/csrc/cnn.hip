@@ -539,6 +539,58 @@ __global__ __launch_bounds__(256) void first_layer_raw_kernel(const float* __res
     }
 }
 
+// The same R for a compile-time filter shape, one thread per (log-mel row t, 4 channels): the thread keeps the 24 values
+// of each of its KH input rows in registers and produces ALL Wout positions of the row from them -- 6 float4
+// loads per input row instead of KH * KW scalar loads per OUTPUT (first_layer_raw_kernel issues 20 loads per 16 bytes
+// stored and ran at 1.8 TB/s of stores, bound by the load-issue rate of the texture path, not by HBM).  Every output is
+// the same fmaf chain in (ky, kx) order: bit-identical results.  A store instruction covers 4 rows x 256 contiguous bytes.
+template <int KH_, int KW_, int WOUT>
+__global__ __launch_bounds__(256) void first_layer_rows_kernel(const float* __restrict__ mspec, int row0, int nrows, int Cout,
+                                                               const float* __restrict__ w, int Kpad, float* __restrict__ R) {
+    static_assert(WOUT + KW_ - 1 <= 24, "the log-mel rows are 24 wide");
+    extern __shared__ __attribute__((aligned(16))) float sW[];     // [K][Cout]
+    constexpr int K = KH_ * KW_;
+    for (int e = threadIdx.x; e < K * Cout; e += 256) {
+        const int co = e / K, k = e - co * K;
+        sW[k * Cout + co] = w[(size_t)co * Kpad + k];
+    }
+    __syncthreads();
+    const unsigned cg = (unsigned)Cout >> 2, total = (unsigned)nrows * cg;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned t = idx / cg;
+        const int c4 = (int)(idx - t * cg) * 4;
+        float4 acc[WOUT];
+#pragma unroll
+        for (int x = 0; x < WOUT; ++x) acc[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < KH_; ++ky) {
+            float v[24];
+            const float4* src = reinterpret_cast<const float4*>(mspec + (size_t)(row0 + (int)t + ky) * 24);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { const float4 f = src[q]; v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w; }
+#pragma unroll
+            for (int kx = 0; kx < KW_; ++kx) {
+                const float4 wk = *reinterpret_cast<const float4*>(&sW[(ky * KW_ + kx) * Cout + c4]);
+#pragma unroll
+                for (int x = 0; x < WOUT; ++x) {
+                    acc[x].x = fmaf(v[x + kx], wk.x, acc[x].x);
+                    acc[x].y = fmaf(v[x + kx], wk.y, acc[x].y);
+                    acc[x].z = fmaf(v[x + kx], wk.z, acc[x].z);
+                    acc[x].w = fmaf(v[x + kx], wk.w, acc[x].w);
+                }
+            }
+        }
+        float* dst = R + ((size_t)t * WOUT) * Cout + c4;
+#pragma unroll
+        for (int x = 0; x < WOUT; ++x) {
+            float4 o;
+            o.x = isfinite(acc[x].x) ? acc[x].x : 0.f; o.y = isfinite(acc[x].y) ? acc[x].y : 0.f;
+            o.z = isfinite(acc[x].z) ? acc[x].z : 0.f; o.w = isfinite(acc[x].w) ? acc[x].w : 0.f;
+            *reinterpret_cast<float4*>(dst + (size_t)x * Cout) = o;
+        }
+    }
+}
+
 // One wavefront per slot.  segmenter.py:82 (np.mean / np.std over the flattened window) and
 // :86 (finite = all(isfinite(normalised))).
 __global__ __launch_bounds__(256) void patch_stats_kernel(const float* __restrict__ mspec,
@@ -987,7 +1039,18 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 iss_prof_begin(c, 2, 0);
                 const dim3 rgrid((unsigned)std::min<long long>((rtot + 255) / 256, 4096));
                 const size_t rlds = (size_t)R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4;
-                if (R1[ISS_C_KH] == 4 && R1[ISS_C_KW] == 5)
+                static const bool no_rows = getenv("ISS_NO_FLROWS") != nullptr;       // diagnostic: the per-output kernel
+                // compiled for the two input widths of the reference's nets: 21 bands (smn / sm) -> 17 positions, 24 (gender) -> 20
+                const bool rows_ok = !no_rows && R1[ISS_C_KH] == 4 && R1[ISS_C_KW] == 5 && (R1[ISS_C_WO] == 17 || R1[ISS_C_WO] == 20) &&
+                                     rrows * (R1[ISS_C_COUT] / 4) < (1ll << 31);
+                const dim3 rowgrid((unsigned)std::min<long long>((rrows * (R1[ISS_C_COUT] / 4) + 255) / 256, 4096));
+                if (rows_ok && R1[ISS_C_WO] == 17)
+                    hipLaunchKernelGGL((first_layer_rows_kernel<4, 5, 17>), rowgrid, dim3(256), rlds, c->stream, (const float*)c->mspec.p, rmin, (int)rrows,
+                                       R1[ISS_C_COUT], (const float*)(n.d_blob + R1[ISS_C_WOFF]), n.kpad[pend], Rraw);
+                else if (rows_ok)
+                    hipLaunchKernelGGL((first_layer_rows_kernel<4, 5, 20>), rowgrid, dim3(256), rlds, c->stream, (const float*)c->mspec.p, rmin, (int)rrows,
+                                       R1[ISS_C_COUT], (const float*)(n.d_blob + R1[ISS_C_WOFF]), n.kpad[pend], Rraw);
+                else if (R1[ISS_C_KH] == 4 && R1[ISS_C_KW] == 5)
                     hipLaunchKernelGGL((first_layer_raw_kernel<4, 5>), rgrid, dim3(256), rlds, c->stream, (const float*)c->mspec.p, rmin, rtot,
                                        R1[ISS_C_WO], R1[ISS_C_COUT], 4, 5, (const float*)(n.d_blob + R1[ISS_C_WOFF]), n.kpad[pend], Rraw);
                 else
