@@ -596,32 +596,44 @@ __global__ __launch_bounds__(256) void first_layer_rows_kernel(const float* __re
 __global__ __launch_bounds__(256) void patch_stats_kernel(const float* __restrict__ mspec,
                                                           const int32_t* __restrict__ win_row, int n, int h,
                                                           float* __restrict__ stats, uint8_t* __restrict__ finite) {
+    // A lane owns the flattened elements e = lane + 64 k of the 68 x h window (k < 23 for h <= 21, < 26 for h = 24): they are
+    // loaded ONCE into registers and the three passes (mean, squared deviations, finite test) run on the registers, in
+    // the element order and with the f64 sums of the three-pass form (bit-identical results).  (r, c) of an element
+    // advance by (64 / h, 64 % h) with a carry: the run-time division per element and pass was most of this kernel's time.
+    constexpr int NV = 26;                           // ceil(68 * 24 / 64)
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= n) return;
     const float* src = mspec + (size_t)win_row[b] * 24;
     const int cnt = 68 * h;
+    const int dr = 64 / h, dc = 64 - dr * h;
+    int r = lane / h, c = lane - r * h;
+    float v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int e = lane + 64 * k;
+        v[k] = src[e < cnt ? r * 24 + c : 0];        // unconditional load (tail lanes re-read element 0 and are masked below)
+        r += dr; c += dc;
+        if (c >= h) { c -= h; ++r; }
+    }
     double s = 0.0;
-    for (int e = lane; e < cnt; e += 64) { const int r = e / h, c = e - r * h; s += (double)src[r * 24 + c]; }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) if (lane + 64 * k < cnt) s += (double)v[k];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const double mean_d = s / cnt;
     double q = 0.0;
-    for (int e = lane; e < cnt; e += 64) {
-        const int r = e / h, c = e - r * h;
-        const double d = (double)src[r * 24 + c] - mean_d;
-        q += d * d;
-    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        if (lane + 64 * k < cnt) { const double d = (double)v[k] - mean_d; q += d * d; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float meanf = (float)mean_d;
     const float sdf = (float)sqrt(q / cnt);
     int bad = 0;
-    for (int e = lane; e < cnt; e += 64) {
-        const int r = e / h, c = e - r * h;
-        const float v = (src[r * 24 + c] - meanf) / sdf;
-        bad |= !isfinite(v);
-    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        if (lane + 64 * k < cnt) bad |= !isfinite((v[k] - meanf) / sdf);
     bad = __any(bad);
     if (lane == 0) { stats[2 * b] = meanf; stats[2 * b + 1] = sdf; finite[b] = bad ? 0 : 1; }
 }
