@@ -1128,18 +1128,19 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const bool pointwise = !no_pw && a.mode == 0 && tr && a.H_k == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt_ == 0 &&
                                    a.pl_ == 0 && R[ISS_C_HO] == a.H && R[ISS_C_WO] == a.W && a.Kpad == a.Cin;
             if (pointwise) iss_prof_tag(c, ISS_PROF_PW);
-            static const bool no_pws = getenv("ISS_NO_PWS") != nullptr;          // diagnostic: the round-2 pointwise kernel
-            // deep-K layers (the segmenter nets' dense head, K = 4992 / 8320: three column tiles sweep 2.5 MB of A side by side
-            // and live on their L2 hits) measured 8 % slower on the deeper ring: they keep the two-set kernel
+            // Streaming pointwise kernels (conv_pw.h) for K <= 2048.  The segmenter nets' first dense layer (K = 4992 / 8320,
+            // 192 columns, ~28 k rows per launch) keeps conv_x3_pw_kernel: it runs at 1.7 TB/s of activations on every tiling
+            // that was built for it (deeper ring -8 %; one workgroup per 64 rows x all 192 columns +6 %, with split-K +3..+11 %,
+            // with non-temporal activation loads +8 %: profiles/HISTORY.md, round 3)
+            static const bool no_pws = getenv("ISS_NO_PWS") != nullptr;          // diagnostic: the round-2 pointwise kernel everywhere
             static const bool no_pws2 = getenv("ISS_NO_PWS2") != nullptr;        // diagnostic: 64-column tiles everywhere
-            // strided 1x1 (shortcut projections): the streaming kernel on a strided pixel list
-            const bool pw_strided = !no_pws && !no_pws2 && a.mode == 0 && tr && a.H_k == 1 && a.kw == 1 && (a.sh > 1 || a.sw > 1) && a.pt_ == 0 &&
-                                    a.pl_ == 0 && a.Kpad == a.Cin && a.Kpad <= 2048 && issk::pws2_strided_supported(a, R[ISS_C_HO], R[ISS_C_WO]);
+            const bool pws_ok = !no_pws && a.Kpad <= 2048;
+            // strided 1x1 (the shortcut projections): the 128-column kernel on a strided pixel list
+            const bool pw_strided = pws_ok && !no_pws2 && a.mode == 0 && tr && a.H_k == 1 && a.kw == 1 && (a.sh > 1 || a.sw > 1) && a.pt_ == 0 &&
+                                    a.pl_ == 0 && a.Kpad == a.Cin && issk::pws2_strided_supported(a, R[ISS_C_HO], R[ISS_C_WO]);
             if (pw_strided) { iss_prof_tag(c, ISS_PROF_PW); issk::iss_pws2_launch(a, c->stream, true); }
-            else
-            if (pointwise && !no_pws && !no_pws2 && issk::pws2_supported(a) && a.Kpad <= 2048) issk::iss_pws2_launch(a, c->stream);
-            else
-            if (pointwise && !no_pws && issk::pws_supported(a) && a.Kpad <= 2048)
+            else if (pointwise && pws_ok && !no_pws2 && issk::pws2_supported(a)) issk::iss_pws2_launch(a, c->stream);
+            else if (pointwise && pws_ok && issk::pws_supported(a))
                 issk::iss_pws_launch(a, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), c->stream);
             else
             if (pointwise) hipLaunchKernelGGL(conv_x3_pw_kernel, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), dim3(256), 0, c->stream, a);

@@ -271,7 +271,7 @@ def _pw_program(rng, n, h, w, cin, specs):
     return B.finish((h, w, cin), int(np.prod(shape)), False), x, vals[src].reshape(n, -1)
 
 
-@pytest.mark.parametrize('case', ['bottleneck_odd_channels', 'strided_projection', 'post_affine_and_sigmoid', 'k1024_n256'])
+@pytest.mark.parametrize('case', ['bottleneck_odd_channels', 'strided_projection', 'post_affine_and_sigmoid', 'k1024_n256', 'dense_192'])
 def test_pointwise_streaming_kernels(ctx, prec, case):
     """conv_x3_pws_kernel / conv_x3_pws2_kernel (conv_pw.h): partial row tiles (M % 128 != 0), partial column tiles
     (Cout % 64 != 0), in-place residuals, the generic epilogue (sigmoid / tanh / post-activation affine), strided
@@ -286,6 +286,9 @@ def test_pointwise_streaming_kernels(ctx, prec, case):
     elif case == 'post_affine_and_sigmoid':
         comp, x, ref = _pw_program(rng, 3, 9, 15, 32, [(64, 1, False, 1, True), (128, 2, False, 1, True),
                                                        (64, 1, True, 1, True), (36, 0, False, 1, False)])
+    elif case == 'dense_192':                   # the segmenter nets' dense head: 301 rows (64-row tiles, last one of 45), K = 4992 -> 192 -> 128 -> tanh 192
+        comp, x, ref = _pw_program(rng, 301, 1, 1, 4992, [(192, 1, False, 1, False), (128, 1, False, 1, False),
+                                                          (192, 3, False, 1, True)])
     else:                                       # 8 x 18 maps of ResNet-101's last stage: K = 1024 (32 k-steps), 4 x 128 columns
         comp, x, ref = _pw_program(rng, 4, 8, 18, 1024, [(256, 1, False, 1, False), (1024, 1, False, 1, False)])
     ctx.cnn_load(5, comp)

@@ -666,3 +666,23 @@ def test_oracle_is_only_used_as_the_checker():
     assert {fn for fn, _ in oracle_imports(os.path.join(ROOT, 'bench.py'))} <= {'cpu_baseline', 'bench_vbx', 'parity_check'}
     assert {fn for fn, _ in oracle_imports(os.path.join(ROOT, '__graft_entry__.py'))} <= {'smoke'}
 
+
+
+def test_asm_load_kernels_keep_their_ring_registers(tmp_path):
+    """conv_pw.h issues its global loads from inline asm into tied register variables and waits for them with counted
+    s_waitcnt statements the compiler knows nothing about: a compiler-inserted COPY of such a register between its load
+    and the wait would read stale data.  Checked statically on the gfx950 disassembly of the unit (tools/check_ring_regs.py):
+    the load destinations are only ever read by the conversion / epilogue arithmetic and LDS stores, only written by the
+    loads and the initialisation, and nothing spills."""
+    import shutil
+    import subprocess
+    if not (os.path.exists('/opt/rocm/bin/hipcc') and shutil.which('c++filt')):
+        pytest.skip('no hipcc here')
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    r = subprocess.run(['bash', os.path.join(root, 'tools', 'kernel_meta.sh'), 'cnn_pw.hip', 'pws'], capture_output=True, text=True)
+    assert r.returncode == 0 and 'spill v0 s0' in r.stdout, r.stdout + r.stderr
+    assert all('spill v0 s0' in l for l in r.stdout.strip().splitlines()), r.stdout
+    c = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_ring_regs.py'), '/tmp/iss_meta/cnn_pw.s', 'pws'],
+                       capture_output=True, text=True)
+    assert c.returncode == 0, c.stdout
+    assert c.stdout.count("ok ") >= 7, c.stdout
