@@ -297,3 +297,32 @@ def test_pointwise_streaming_kernels(ctx, prec, case):
     err = np.abs(out - ref).max() / scale
     print(f'{case} [{prec}]: max rel err {err:.2e}')
     assert err < 1e-4, (case, err)
+
+
+@pytest.mark.parametrize('nmel,nout', [(21, 3), (24, 2)])
+def test_row_wise_first_layer_is_bit_identical(ctx, nmel, nout):
+    """first_layer_rows_kernel (one thread per log-mel row and 4 channels, the input rows in registers) computes the same
+    fmaf chains as first_layer_raw_kernel (one thread per output, ISS_NO_FLROWS=1): the probabilities must not differ in a bit."""
+    import subprocess
+    import sys
+    code = f"""
+import numpy as np, sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from inaspeechsegmenter_amd import keras_model as KM, _native
+ctx = _native.Context(0)
+rng = np.random.default_rng(31)
+layers, shp = KM.synthetic_ina_like({nmel}, {nout}, seed=4)
+ctx.cnn_load(3, KM.compile_layers(layers, shp))
+ctx.set_mspec(rng.normal(-3, 2, (900, 24)).astype(np.float32))
+rows = np.arange(0, 900 - 68 + 1, 2, dtype=np.int32)
+p, f = ctx.cnn_probs(3, rows)
+sys.stdout.buffer.write(p.tobytes())
+"""
+    outs = []
+    for env_extra in ({}, {'ISS_NO_FLROWS': '1'}):                # the switch is read once per process
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(np.frombuffer(r.stdout, dtype=np.float32))
+    assert outs[0].size == outs[1].size == 417 * nout
+    assert np.array_equal(outs[0], outs[1])
