@@ -591,6 +591,71 @@ __global__ __launch_bounds__(256) void first_layer_rows_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Direct 3x3 convolution of a ONE-channel image (stride 1, zero padding 1, bias, optional relu): ResNet-101's first layer
+// (resnet.py:96-99, on the 64 x 144 fbank window of vbx_segmenter.py:262-266).  As a GEMM it has K = 9 padded to a 32-wide
+// k-tile of scalar table-driven gathers (conv_x3_kernel<1>: 470 us per 512 windows, 4.5 x the time its 604 MB of output take to
+// write).  Here a thread owns 8 consecutive rows x 4 channels of one column: 3 x 10 inputs in registers, 288 fmaf (f32, chain
+// in (ky, kx) order), and a wave's store instruction covers 8 neighbouring columns x 128 B = 1 KB contiguous.
+// Window input (vbx features, frame-major) and NHWC input share the addressing (row_stride / pix_stride / per-sample base).
+template <bool WINDOW>
+__global__ __launch_bounds__(256) void conv1_direct3x3_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];     // [9][Cout]
+    for (int e = threadIdx.x; e < 9 * p.Cout; e += 256) {
+        const int co = e / 9, k = e - co * 9;
+        sW[k * p.Cout + co] = p.w[(size_t)co * p.Kpad + k];
+    }
+    __syncthreads();
+    const unsigned cg = (unsigned)p.Cout >> 2, hb = (unsigned)(p.H + 7) >> 3;
+    const unsigned per_img = cg * (unsigned)p.W * hb;
+    const unsigned total = per_img * (unsigned)(p.M / ((long long)p.H * p.W));       // host: < 2^32
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned b = idx / per_img;
+        unsigned r = idx - b * per_img;
+        const unsigned ob = r / (cg * (unsigned)p.W);
+        r -= ob * cg * (unsigned)p.W;
+        const int ox = (int)(r / cg), c4 = (int)(r - (unsigned)ox * cg) * 4, oy0 = (int)ob * 8;
+        const float* src = p.in + (WINDOW ? (long long)p.win_row[b] * p.pix_stride : (long long)b * p.img_stride);
+        float v[3][10];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox - 1 + dx;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int iy = oy0 - 1 + j;
+                const bool ok = (unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H;
+                const float x = src[ok ? (long long)iy * p.row_stride + (long long)ix * p.pix_stride : 0];
+                v[dx][j] = ok ? x : 0.f;
+            }
+        }
+        float4 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 wk = *reinterpret_cast<const float4*>(&sW[(ky * 3 + kx) * p.Cout + c4]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[i].x = fmaf(v[kx][i + ky], wk.x, acc[i].x);
+                    acc[i].y = fmaf(v[kx][i + ky], wk.y, acc[i].y);
+                    acc[i].z = fmaf(v[kx][i + ky], wk.z, acc[i].z);
+                    acc[i].w = fmaf(v[kx][i + ky], wk.w, acc[i].w);
+                }
+            }
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + c4);
+        float* dst = p.out + (((size_t)b * p.H + oy0) * p.W + ox) * p.Cout + c4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (oy0 + i >= p.H) break;
+            float4 o = make_float4(acc[i].x + b4.x, acc[i].y + b4.y, acc[i].z + b4.z, acc[i].w + b4.w);
+            if (p.act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            *reinterpret_cast<float4*>(dst + (size_t)i * p.W * p.Cout) = o;
+        }
+    }
+}
+
 // One wavefront per slot.  segmenter.py:82 (np.mean / np.std over the flattened window) and
 // :86 (finite = all(isfinite(normalised))).
 __global__ __launch_bounds__(256) void patch_stats_kernel(const float* __restrict__ mspec,
@@ -1083,6 +1148,20 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         iss_prof_begin(c, 0, fl);
         iss_prof_tag(c, ws || ws_plain || ws_nh2 ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
         iss_prof_row(c, r);
+        // one-channel 3x3 'same' first layer of a non-PATCH network: direct f32 kernel (either arithmetic mode)
+        static const bool no_direct = getenv("ISS_NO_DIRECT1") != nullptr;
+        const bool direct1 = !no_direct && !patch && pend < 0 && a.Cin == 1 && a.H_k == 3 && a.kw == 3 && a.sh == 1 && a.sw == 1 && a.pt_ == 1 &&
+                             a.pl_ == 1 && R[ISS_C_HO] == a.H && R[ISS_C_WO] == a.W && a.pp == 1 && !a.res && !a.ps && a.act <= 1 && a.bias &&
+                             a.Cout % 4 == 0 && a.Cout <= 256 && a.M * (long long)(a.Cout / 4) < (1ll << 34);
+        if (direct1) {
+            iss_prof_tag(c, ISS_PROF_GATHER);
+            const long long items = (long long)(a.M / ((long long)a.H * a.W)) * ((a.H + 7) / 8) * a.W * (a.Cout / 4);
+            if (items >= (1ll << 32)) return iss_fail(c, ISS_EINVAL, "internal: direct first layer over %lld work items", items);
+            const dim3 dgrid((unsigned)std::min<long long>((items + 255) / 256, 8192));
+            const size_t dlds = (size_t)9 * a.Cout * sizeof(float);
+            if (window) hipLaunchKernelGGL(conv1_direct3x3_kernel<true>, dgrid, dim3(256), dlds, c->stream, a);
+            else hipLaunchKernelGGL(conv1_direct3x3_kernel<false>, dgrid, dim3(256), dlds, c->stream, a);
+        } else
         if (ws_nh2) {
             const unsigned ngroups = (unsigned)((a.M + WS_TM - 1) / WS_TM);         // one 512-row tile per group
             const unsigned ny = (unsigned)(a.Cout / (2 * BN));
