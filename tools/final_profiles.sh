@@ -23,8 +23,9 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_
 python $ROOT/tools/pmc_summary.py $(find /tmp/p_q2 -name '*.db' | head -1) > $OUT/pmc_q2.json
 rocprofv3 --kernel-trace --stats -d /tmp/p_vbx -o r -- python $ROOT/bench.py --workload vbx --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python $ROOT/tools/rocprof_summary.py $(find /tmp/p_vbx -name '*.db' | head -1) $OUT/${R}_vbx_kernel_stats.md "bench.py --workload vbx --steps 2 --warmup 1" > /dev/null
-rocprofv3 --kernel-trace -d /tmp/p_vbxl -o r -- python $ROOT/bench.py --workload vbx --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
-python $ROOT/tools/layer_times.py $(find /tmp/p_vbxl -name '*.db' | head -1) > $OUT/${R}_vbx_layer_times.md 2>&1
+cd $ROOT
+python tools/layer_prof.py > $OUT/${R}_vbx_layer_times.md 2>&1          # per-layer HIP-event times (rocprofv3's trace slows these launches ~2x on some boxes)
+python tools/seg_layer_prof.py > $OUT/${R}_seg_layer_times.txt 2>&1
 cd $ROOT
 python bench.py --workload vbx > $OUT/${R}_vbx_1h.json 2> $OUT/vbx.err
 python bench.py --workload archive --files-per-gpu 1250 --steps 2 --warmup 1 > $OUT/${R}_bench_archive_1250.json 2> $OUT/archive1250.err
