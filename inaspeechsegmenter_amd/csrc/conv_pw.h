@@ -40,7 +40,7 @@ constexpr int PWS_ELD = 36;                          // pitch of the epilogue st
 // s_waitcnt vmcnt(n) for a run-time, wave-uniform n: the largest literal <= n (fewer outstanding = a longer wait = safe).
 #define ISS_PWS_W(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 __device__ __forceinline__ void pws_wait_outstanding(unsigned n) {
-    if (n >= 63) return;                             // the counter has 6 bits: 63 outstanding is all a wave can have
+    if (n >= 63) { ISS_PWS_W(63); return; }          // the counter has 6 bits; with <= 63 outstanding, an instruction that has 63 younger ones is done
     if (n >= 36) {
         if (n >= 54) ISS_PWS_W(54); else if (n >= 48) ISS_PWS_W(48); else if (n >= 42) ISS_PWS_W(42); else ISS_PWS_W(36);
     } else if (n >= 18) {
