@@ -1,8 +1,8 @@
 // conv_x3_pws_kernel: pointwise (1x1, stride 1, unpadded) convolutions and dense layers as a STREAMING bf16x3 GEMM on the
 // NHWC pixel list -- ResNet-101's bottleneck 1x1 layers (resnet.py:48-75; 68 % of the x-vector path's GPU time) and the
-// dense head of the segmenter networks (segmenter.py:163).  Same arithmetic, tile (128 rows x 64 channels, four waves of
-// 32 x 64), LDS operand format and XCD-aware persistent tile order as conv_x3_pw_kernel (cnn.hip), which stays as the
-// ISS_NO_PWS=1 fallback.  What is different, and why:
+// K <= 2048 dense layers of the segmenter networks (segmenter.py:163).  Same arithmetic, tile (128 rows x 64 channels, four
+// waves of 32 x 64), LDS operand format and XCD-aware persistent tile order as conv_x3_pw_kernel (cnn.hip), which keeps the
+// deep-K first dense layer and is the ISS_NO_PWS=1 fallback.  What is different, and why:
 //
 // These layers are bound by memory, not by the matrix pipe (K = 32 .. 512: 1 .. 16 k-steps of ~0.2 us per tile, against
 // 2 - 4 us of loaded memory latency; the old kernel reached 4.4 TB/s on reads, 2.7 TB/s on writes, 22 % MFMA busy):
