@@ -6,13 +6,17 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
 RCCL).  Rank 0 prints ONE JSON line.
 
 Workloads
-  segmenter (default for --gpus 1)   the configuration the metric is quoted on, below
+  segmenter (default at EVERY --gpus N)  the configuration the metric is quoted on, below: one recording per rank (weak scaling,
+                                     "replicas" of configs[1]'s input: a single file is never split over GPUs), one all-gather
+                                     of the segment tables per step at N > 1 -- the same code path at N = 1 and N = 8
   batch                              BASELINE.json configs[2]: 128 x 5 min WAV files in /dev/shm through
                                      Segmenter.batch_process -- decode, H2D, device, Viterbi and CSV export inside the timed region
-  archive   (default for --gpus > 1) BASELINE.json configs[3] shape: 3-minute WAV files, file-parallel over the ranks through
+  archive                            BASELINE.json configs[3] shape: 3-minute WAV files, file-parallel over the ranks through
                                      archive.segment_archive, ONE RCCL all-gather of the segment tables per step (C-ABI
                                      iss_allgather_segments); --files-per-gpu of them per rank (weak scaling)
   vbx                                BASELINE.json configs[4]
+The default line carries the other single-GPU configurations as driver-timed `companions`: `archive` at every N (so that the
+file-based configs[3] path has a 1 -> N curve of its own), `batch` and `vbx` at N = 1 (--no-companions skips them).
 
 segmenter workload (BASELINE.json configs[1] input, with the metric's smn + gender nets): every rank holds
 ONE 1 h synthetic 16 kHz mono PCM16 recording, already resident in HBM when the timed region
@@ -103,67 +107,183 @@ def synth_recording(file_index, n_samples, device):
 
 
 # ------------------------------------------------------------------------------ per-kernel roofline
-GEMM_CLASSES = ((3, 'conv_x3_ws_kernel'), (4, 'conv_x3_fp_kernel'), (5, 'conv_x3_pws_kernel / conv_x3_pws2_kernel / conv_x3_pw_kernel'), (6, 'conv_x3_kernel'),
-                (7, 'conv1_patch_x3_kernel'), (8, 'conv_igemm_kernel'))     # include/iss.h ISS_PROF_*
+def _pmc_static():
+    """profiles/pmc_latest.json (tools/pmc_report.py): per-kernel FETCH_SIZE / WRITE_SIZE of the latest committed rocprofv3
+    --pmc passes.  PMC counters need rocprofv3 passes of their own, so HBM traffic cannot be measured inside a bench run:
+    every figure taken from here is labelled with the run it came from."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))
+    except Exception:                                       # noqa: BLE001
+        return {}
 
 
-def gemm_kernel_table(ctxs, peak_tf):
-    """HIP-event time, launches and algorithmic flops of every GEMM kernel class (iss_prof_get kinds 3..8) summed over the
-    given contexts -> ([{kernel, ms_per_step, launches, flops, achieved, frac}], the entry with the most time)."""
+def _pmc_kernel(pj, inst_name):
+    """per_kernel entry of pmc_latest.json for an instantiation name as the library spells it (no blanks, no namespace)"""
+    want = inst_name.replace(' ', '')
+    for k, v in (pj.get('per_kernel') or {}).items():
+        if k.replace(' ', '').replace('issk::', '') == want:
+            return v
+    return None
+
+
+def gemm_kernel_table(ctxs, peak_tf, pj=None):
+    """HIP-event time, launches and algorithmic flops of every GEMM kernel INSTANTIATION (iss_prof_get_instance: template
+    arguments spelled out) summed over the given contexts -> ([{kernel, ms_per_step, launches, flops, avg_launch_ms,
+    flops_per_launch, achieved, frac, traffic...}] sorted by time, the entry with the most time)."""
+    acc = {}
+    for c in ctxs:
+        for e in c.prof_instances():
+            a = acc.setdefault(e['kernel'], [0.0, 0, 0.0])
+            a[0] += e['ms']; a[1] += e['launches']; a[2] += e['flops']
     rows = []
-    for kind, name in GEMM_CLASSES:
-        ms = fl = 0.0
-        nl = 0
-        for c in ctxs:
-            a, b, d = c.prof_get(kind)
-            ms += a; nl += b; fl += d
-        if nl:
-            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            rows.append({"kernel": name, "ms_per_step": ms, "launches": nl, "flops": fl, "avg_launch_ms": ms / nl,
-                         "achieved": tf, "frac": tf / peak_tf})
+    for name, (ms, nl, fl) in acc.items():
+        if not nl or fl <= 0:
+            continue
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        row = {"kernel": name, "ms_per_step": ms, "launches": nl, "flops": fl, "avg_launch_ms": ms / nl,
+               "flops_per_launch": fl / nl, "achieved": tf, "frac": tf / peak_tf}
+        pk = _pmc_kernel(pj or {}, name)
+        if pk and 'FETCH_SIZE_bytes' in pk and 'WRITE_SIZE_bytes' in pk:
+            row["traffic_per_launch_static"] = 2 * pk['FETCH_SIZE_bytes'] + pk['WRITE_SIZE_bytes']
+            row["mfma_busy_frac_static"] = pk.get('mfma_busy_frac')
+        rows.append(row)
     rows.sort(key=lambda r: -r["ms_per_step"])
     return rows, (rows[0] if rows else None)
 
 
 # ------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(seg, pcm_host, target_s=40.0):
+def _cpu_feature_worker(job):
+    """One process of the file-parallel CPU leg (leg 1b): oracle feature path + energy detector +
+    per-segment Viterbi on a stand-in emission array for one file's worth of samples.  Runs as `bench.py --cpu-worker`."""
+    file_index, nsec = job
+    import time as _t
+    from oracle import sidekit as osk, segment as oseg
+    from oracle.viterbi import viterbi_decoding, diag_trans_exp
+    pcm = synth_recording_numpy(file_index, nsec * FS)
+    sig = (pcm / 32768.0).astype(np.float32)
+    t0 = _t.perf_counter()
+    mspec, loge, difflen = osk.media2feats(sig)
+    lseg0 = oseg.energy_seglist(loge, 0.03)
+    oseg.get_patches(mspec[:, :21].copy(), 68, 2)
+    oseg.get_patches(mspec, 68, 2)
+    # the two per-segment smoothing passes on emissions of the right shape (the CNN itself is a leg of its own)
+    rng = np.random.default_rng(file_index)
+    for k, arg in ((3, 80), (2, 80)):
+        for lab, a, b in lseg0:
+            if lab == 'energy' and b > a:
+                viterbi_decoding(np.log(rng.dirichlet(np.ones(k), b - a).astype(np.float32)), diag_trans_exp(arg, k))
+    return _t.perf_counter() - t0
+
+
+def synth_recording_numpy(file_index, n_samples):
+    """numpy twin of synth_recording (same plan; numpy noise): for CPU-only legs that must not touch torch / the GPU."""
+    rng = np.random.default_rng(20250926 + file_index)
+    out = np.zeros(n_samples, np.float32)
+    for kind, pos, n, f0, chord, trem in synth_plan(file_index, n_samples):
+        if kind == 1:
+            out[pos:pos + n] = rng.standard_normal(n).astype(np.float32) * 10 ** (-30 / 20)
+        elif kind >= 2:
+            t = np.arange(n, dtype=np.float32) / FS
+            x = np.zeros(n, np.float32)
+            if kind == 2:
+                for k in range(1, 31):
+                    if f0 * k < 7600:
+                        x += np.sin(2 * np.pi * f0 * k * t) / k
+                x *= 0.6 + 0.4 * np.sin(2 * np.pi * 4.0 * t)
+                level = 10 ** (-20 / 20)
+            else:
+                for f in chord:
+                    x += np.sin(2 * np.pi * float(f) * t)
+                x *= 0.8 + 0.2 * np.sin(2 * np.pi * trem * t)
+                level = 10 ** (-18 / 20)
+            x *= level / np.sqrt(np.mean(x * x) + 1e-20)
+            out[pos:pos + n] = x
+    return np.clip(np.round(out * 32768.0), -32768, 32767).astype(np.int16)
+
+
+def cpu_file_parallel_leg(nproc, nsec=120, budget_s=90.0):
+    """Leg 1b: `nproc` processes (`python bench.py --cpu-worker i nsec`, numpy / BLAS pinned to one thread each, no GPU), each
+    running the oracle feature path + Viterbi on its own `nsec`-second synthetic file.  -> dict (x real time aggregate)."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', HIP_VISIBLE_DEVICES='',
+               ROCR_VISIBLE_DEVICES='')
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(1000 + i), str(nsec)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for i in range(nproc)]
+    per, failed = [], 0
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=max(1.0, budget_s - (time.perf_counter() - t0)))
+            per.append(float(out.decode().strip().splitlines()[-1]))
+        except Exception:                                   # noqa: BLE001  (timeout, crash, unparsable output)
+            failed += 1
+            pr.kill()
+    wall = time.perf_counter() - t0
+    if not per:
+        return {"processes": nproc, "error": "no worker finished"}
+    return {"processes": nproc, "finished": len(per), "failed": failed, "seconds_per_file": nsec, "wall_s": wall,
+            "x_realtime_aggregate": len(per) * nsec / wall, "x_realtime_one_process_mean": nsec / (sum(per) / len(per)),
+            "what": "oracle/ numpy feature path (sidekit mfcc restatement) + energy detector + both patch builders + the "
+                    "per-segment reference-order Python Viterbi, one synthetic file per process, one BLAS thread each; the wall "
+                    "time includes interpreter start-up and module imports of every worker (as a file-parallel CPU job would pay them)"}
+
+
+def cpu_baseline(seg, pcm_host, target_s=25.0):
     """The oracle (numpy restatement of the reference feature path + torch-CPU Keras-semantics
     forward + the reference-order Viterbi) on a bounded sample of the same recording.  Also returns what the parity check
-    needs: the oracle's segments and raw network outputs on that sample."""
+    needs: the oracle's segments and raw network outputs on that sample.  Legs as BASELINE.md section 3 plans them:
+    (1a) one process, (1b) file-parallel over all host cores, (2) the CNN forward at batch 32 / 1024 over a thread sweep."""
     import torch
     from oracle import sidekit as osk, segment as oseg, keras_cnn as ocnn
     cores_host = os.cpu_count() or 1
-    threads = min(cores_host, 64)               # torch-CPU conv stops scaling (and oversubscribes) beyond ~64 threads
-    torch.set_num_threads(threads)
     vad_layers, gen_layers = seg.vad.layers, seg.gender.layers
+    legs = {}
 
+    # ---- leg 2: CNN forward alone (segmenter.py:222-224: default batch 32, 1024 recommended for GPUs), thread sweep
+    x = np.random.default_rng(0).normal(0, 1, (1024, 68, 21, 1)).astype(np.float32)
+    sweep = []
+    best = None
+    for th in [t for t in (8, 16, 32, 64, 128) if t <= cores_host] or [cores_host]:
+        torch.set_num_threads(th)
+        for bs in (32, 1024):
+            ocnn.forward(vad_layers, x[:bs], batch_size=bs)                    # warm the thread pool / allocator
+            t0 = time.perf_counter()
+            ocnn.forward(vad_layers, x, batch_size=bs)
+            rate = len(x) / (time.perf_counter() - t0)
+            sweep.append({"threads": th, "batch_size": bs, "slots_per_s": rate})
+            if best is None or rate > best["slots_per_s"]:
+                best = sweep[-1]
+    legs["vad_cnn_forward_sweep"] = sweep
+    legs["vad_cnn_forward_best"] = best
+    threads, bs_best = best["threads"], best["batch_size"]
+    torch.set_num_threads(threads)
+
+    # ---- leg 1a: the whole pipeline in one process on a bounded sample (also the parity sample)
     def run(nsec, keep=False):
         sig = (pcm_host[:nsec * FS] / 32768.0).astype(np.float32)
         t0 = time.perf_counter()
         mspec, loge, difflen = osk.media2feats(sig)
+        t_feat = time.perf_counter() - t0
         lseg0 = oseg.energy_seglist(loge, 0.03)
-        lseg1, raw_vad = oseg.dnn_segment('smn', lambda b: ocnn.forward(vad_layers, b, batch_size=1024), mspec, lseg0, difflen, return_raw=True)
-        lseg2, raw_gen = oseg.dnn_segment('gender', lambda b: ocnn.forward(gen_layers, b, batch_size=1024), mspec, lseg1, difflen, return_raw=True)
+        lseg1, raw_vad = oseg.dnn_segment('smn', lambda b: ocnn.forward(vad_layers, b, batch_size=bs_best), mspec, lseg0, difflen, return_raw=True)
+        lseg2, raw_gen = oseg.dnn_segment('gender', lambda b: ocnn.forward(gen_layers, b, batch_size=bs_best), mspec, lseg1, difflen, return_raw=True)
         dt = time.perf_counter() - t0
-        det = dict(lseg0=lseg0, lseg1=lseg1, lseg2=lseg2, raw_vad=raw_vad, raw_gen=raw_gen, nframes=len(loge)) if keep else None
+        det = dict(lseg0=lseg0, lseg1=lseg1, lseg2=lseg2, raw_vad=raw_vad, raw_gen=raw_gen, nframes=len(loge), t_feat=t_feat) if keep else None
         return dt, det
 
     probe = 20
     t_probe, _ = run(probe)
     nsec = int(max(probe, min(len(pcm_host) // FS, probe * target_s / max(t_probe, 1e-3))))
-    # at least 600 s when that stays under ~90 s of CPU work: the parity check on this sample should see >= 20 boundaries that
+    # at least 600 s when that stays under ~60 s of CPU work: the parity check on this sample should see >= 20 boundaries that
     # the networks decided (the generator changes segment every ~11 s, one in ten is silence)
-    if probe * 90.0 / max(t_probe, 1e-3) >= 600:
+    if probe * 60.0 / max(t_probe, 1e-3) >= 600:
         nsec = max(nsec, 600)
     nsec = min(nsec, 660, len(pcm_host) // FS)
     t, det = run(nsec, keep=True)
-    # the CNN forward alone at the reference's default and recommended batch sizes (segmenter.py:222-224)
-    legs = {}
-    x = np.random.default_rng(0).normal(0, 1, (2048, 68, 21, 1)).astype(np.float32)
-    for bs in (32, 1024):
-        t0 = time.perf_counter()
-        ocnn.forward(vad_layers, x, batch_size=bs)
-        legs[f'vad_cnn_forward_batch{bs}_slots_per_s'] = len(x) / (time.perf_counter() - t0)
+    legs["one_process"] = {"x_realtime": nsec / t, "wall_s": t, "sample_s": nsec, "features_x_realtime_1thread": nsec / det['t_feat'],
+                           "cnn_threads": threads, "cnn_batch_size": bs_best}
+    # ---- leg 1b: file-parallel feature path + Viterbi on every host core
+    legs["file_parallel_features_viterbi"] = cpu_file_parallel_leg(min(cores_host, 256))
     if os.path.isdir('/root/reference/inaSpeechSegmenter'):      # build container only: the unmodified reference front end
         import importlib.util
         spec = importlib.util.spec_from_file_location('ref_sidekit_mfcc', '/root/reference/inaSpeechSegmenter/sidekit_mfcc.py')
@@ -174,11 +294,14 @@ def cpu_baseline(seg, pcm_host, target_s=40.0):
         with np.errstate(divide='ignore'):
             m.mfcc(sig, get_mspec=True)
         legs['reference_sidekit_mfcc_x_realtime_1thread'] = nsec / (time.perf_counter() - t0)
+    legs["unmodified_reference_legs"] = ("profiles/r04_cpu_reference_baseline.json (tests/cpu_reference_baseline.py, run in the build "
+                                         "container where /root/reference exists: sidekit_mfcc.mfcc + _get_patches + viterbi_decoding, "
+                                         "features_vbx, resnet.py on torch-CPU); /root/reference does not travel to the GPU box")
     out = {"value": (nsec / 3600.0) / t, "unit": "hours-of-audio/s", "cores": threads, "threads_used": threads,
            "cores_host": cores_host, "kind": "port",
            "sample": f"first {nsec} s of the rank-0 recording, reference semantics (VAD on energy slots, gender on "
-                     f"speech slots), oracle/ numpy feature path (1 thread) + torch-CPU Keras-semantics CNN forward at "
-                     f"batch_size 1024 ({threads} threads: torch-CPU convolutions stop scaling beyond ~64) + "
+                     f"speech slots), ONE process: oracle/ numpy feature path (1 thread) + torch-CPU Keras-semantics CNN forward at "
+                     f"the fastest (threads, batch_size) of the sweep in legs ({threads} threads, batch {bs_best}) + "
                      f"reference-order Python Viterbi; {t:.2f} s wall; "
                      f"stand-in for the TensorFlow/CPU path (TensorFlow is not installable here)",
            "x_realtime": nsec / t, "legs": legs}
@@ -275,16 +398,41 @@ def make_files(indices, minutes, dev, root):
     return paths, n
 
 
-def bench_files(args, torch, dev, local_rank, rank, world, kind):
-    """`batch` (configs[2], one GPU) and `archive` (configs[3] shape, file-parallel + one all-gather) workloads."""
+def make_comm(ctx, rank, world, dev):
+    """The exchange step of an N > 1 run: the C-ABI's ncclAllGather (RcclComm on `ctx`); if its rendezvous cannot be set up
+    (symmetric failures only: librccl missing, no launcher store) every rank falls back to a torch.distributed process
+    group on the same RCCL, and the line says so.  -> (comm, description)"""
+    if world == 1:
+        return None, None
+    from inaspeechsegmenter_amd import sharding
+    try:
+        return (sharding.rccl_rendezvous(ctx, rank, world),
+                "iss_allgather_segments: ncclAllGather of int32 segment tables through the C-ABI (librccl dlopen'ed, no torch in the data path)")
+    except Exception as exc:                                # noqa: BLE001
+        import torch.distributed as dist
+        print(f'[bench] rank {rank}: C-ABI RCCL rendezvous failed ({exc}); falling back to torch.distributed', file=sys.stderr)
+        if not dist.is_initialized():
+            dist.init_process_group('nccl', device_id=dev)
+        return sharding.TorchComm(device=dev), f"torch.distributed nccl all_gather_into_tensor (C-ABI rendezvous failed: {exc})"
+
+
+def bench_files(args, torch, dev, local_rank, rank, world, kind, seg=None, comm=None, comm_kind=None, steps=None, warmup=None,
+                per_gpu=None):
+    """`batch` (configs[2], one GPU) and `archive` (configs[3] shape, file-parallel + one all-gather) workloads.
+    -> the JSON line as a dict on rank 0 (None elsewhere).  seg / comm: reuse the caller's (companion runs)."""
     from inaspeechsegmenter_amd import Segmenter, _native, sharding
     from inaspeechsegmenter_amd.archive import segment_archive
-    seg = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models='synthetic', device=local_rank)
+    steps = steps or args.steps
+    warmup = max(args.warmup if warmup is None else warmup, 1)
+    own_seg = seg is None
+    if own_seg:
+        seg = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models='synthetic', device=local_rank)
     x3 = args.precision == 'bf16x3'
     seg.ctx.set_precision(_native.PREC_BF16X3 if x3 else _native.PREC_F32)
-    comm = sharding.rccl_rendezvous(seg.ctx, rank, world) if world > 1 else None
+    if comm is None and world > 1:
+        comm, comm_kind = make_comm(seg.ctx, rank, world, dev)
     minutes = args.file_minutes or (5.0 if kind == 'batch' else 3.0)
-    per_gpu = args.files_per_gpu or 128
+    per_gpu = per_gpu or args.files_per_gpu or 128
     nfiles = per_gpu * world
     try:
         os.makedirs(args.dir, exist_ok=True)
@@ -328,7 +476,7 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
         assert len(table) == nfiles and all(m[1] == 0 for m in lmsg), (len(table), [m for m in lmsg if m[1] != 0][:3])
         return sum(len(v) for v in table.values())
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(warmup):
         nseg = step()
 
     def barrier():
@@ -348,7 +496,7 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
     for w in seg.__dict__.get('_pipeline_workers', []):
         w.stats = {k: 0.0 for k in w.stats}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         nseg = step()
         mem_trace.append(host_mem())
     seg.ctx.synchronize()
@@ -356,7 +504,7 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
     barrier()
     dt = time.perf_counter() - t0
     dt_local = dt
-    pipe = [{k: (round(v * 1e3 / args.steps, 1) if k not in ('batches', 'files') else v / args.steps) for k, v in w.stats.items()}
+    pipe = [{k: (round(v * 1e3 / steps, 1) if k not in ('batches', 'files') else v / steps) for k, v in w.stats.items()}
             for w in seg.__dict__.get('_pipeline_workers', [])]
     if comm:
         dt = comm.max_over_ranks(dt)
@@ -372,25 +520,21 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
     for c in ctxs:
         ms, nl, fl = c.prof_get(0)
         conv_ms += ms; conv_n += nl; conv_fl += fl
-    ktab, kdom = gemm_kernel_table(ctxs, MFMA_BF16_PEAK_TF if x3 else MFMA_F32_PEAK_TF)
+    ktab, kdom = gemm_kernel_table(ctxs, MFMA_BF16_PEAK_TF if x3 else MFMA_F32_PEAK_TF, _pmc_static())
     for c in ctxs:
         c.prof_enable(False)
     # audit trail of the multi-GPU run: what RCCL reports for the communicator, and the spread of the ranks' own step times
     rccl = None
     dt_min = dt_max = dt_local
     if comm:
-        info = comm.info()
         dt_max = comm.max_over_ranks(dt_local)
         dt_min = -comm.max_over_ranks(-dt_local)
-        ranks_ok = int(round(-comm.max_over_ranks(-float(info['world'] == world and info['rank'] == rank))))     # min over ranks
-        rccl = {"world": info['world'], "ranks_seen": info['world'], "rank0_user_rank": info['rank'], "version": info['version'],
-                "lib": info['lib'], "every_rank_agrees": bool(ranks_ok),
-                "what": "ncclCommCount / ncclCommUserRank / ncclGetVersion of rank 0's communicator (iss_comm_info) and the path of "
-                        "the librccl it was bound from; the collective of every step is ncclAllGather through iss_allgather_segments"}
+        rccl = comm_audit(comm, comm_kind, rank, world)
+    line = None
     if rank == 0:
-        value = args.steps * hours / dt
+        value = steps * hours / dt
         peak_tf = MFMA_BF16_PEAK_TF if x3 else MFMA_F32_PEAK_TF
-        step_s = dt / args.steps
+        step_s = dt / steps
         ach = conv_fl / step_s / 1e12                # whole-step figure: the two device contexts' launches overlap on the GPU,
         ach_ev = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0     # so per-launch event durations are stretched
         roofline = {"bound": "mfma", "kernel": "conv/dense implicit-GEMM launches of rank 0's device contexts (see the segmenter workload's line)",
@@ -405,8 +549,8 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
                             "kernel-only figure.  Reference semantics: VAD net on energy slots, gender net on speech slots"}
         line = {
             "metric": "hours-of-audio segmented/sec (smn+gender, 16 kHz mono)",
-            "value": value, "unit": "hours-of-audio/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": value, "unit": "hours-of-audio/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (bf16x3 split-operand MFMA, f32 accumulate; f64 FFT)" if x3 else "f32 (f32 MFMA; f64 FFT)"),
             "data": "synthetic", "x_realtime_per_gpu": value * 3600.0 / world,
             "config": {"workload": (f"BASELINE.json configs[2]: {nfiles} x {minutes:g} min synthetic 16 kHz mono PCM16 WAV files in {args.dir} "
@@ -416,7 +560,7 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
                                    "; reference semantics (VAD net on energy slots, gender net on speech slots); RIFF parse, H2D copy, device "
                                    "features + CNNs, compiled Viterbi and CSV export are all inside the timed region",
                        "files": nfiles, "files_per_gpu": per_gpu, "minutes_per_file": minutes, "audio_hours_per_step": hours,
-                       "ms_per_file_per_gpu": dt / args.steps / per_gpu * 1e3, "segments_per_step": nseg,
+                       "ms_per_file_per_gpu": dt / steps / per_gpu * 1e3, "segments_per_step": nseg,
                        "weights": "seeded stand-ins, (68,21,1)->3 and (68,24,1)->2, ~1.25 M params each, last layer calibrated "
                                   "(tests/golden/make_standin_heads.py); the real Keras files are un-vendored release assets",
                        "parallelism": (f"file-parallel x{world}: files dealt by size (LPT), no data-path collective, ONE ncclAllGather of int32 segment "
@@ -430,21 +574,39 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind):
                             "files_mount_used_mb": [m[1] for m in mem_trace],
                             "what": "rank 0's resident set and the space in use under the WAV / CSV directory, sampled after the "
                                     "warm-up and after every timed step (a leak in the pinned buffers, queues or exporters would show)"},
-            "ranks": {"ms_per_step_min": dt_min / args.steps * 1e3, "ms_per_step_max": dt_max / args.steps * 1e3,
+            "ranks": {"ms_per_step_min": dt_min / steps * 1e3, "ms_per_step_max": dt_max / steps * 1e3,
                       "what": "each rank's own wall time for the timed steps (barrier to barrier), min / max over the ranks"},
         }
         if rccl is not None:
             line["rccl"] = rccl
-        print(json.dumps(line))
     barrier()
-    seg.close()
+    if own_seg:
+        seg.close()
+    return line
 
 
-def bench_vbx(args, torch, dev, local_rank, rank, world):
+def comm_audit(comm, comm_kind, rank, world):
+    """What the communicator itself reports (every rank calls this: it holds two collectives)."""
+    out = {"collective": comm_kind}
+    if hasattr(comm, 'info'):
+        info = comm.info()
+        ranks_ok = int(round(-comm.max_over_ranks(-float(info['world'] == world and info['rank'] == rank))))     # min over ranks
+        out.update({"world": info['world'], "ranks_seen": info['world'], "rank0_user_rank": info['rank'], "version": info['version'],
+                    "lib": info['lib'], "every_rank_agrees": bool(ranks_ok),
+                    "what": "ncclCommCount / ncclCommUserRank / ncclGetVersion of rank 0's communicator (iss_comm_info) and the path of "
+                            "the librccl it was bound from; the collective of every step is ncclAllGather through iss_allgather_segments"})
+    else:
+        out.update({"world": comm.world})
+    return out
+
+
+def bench_vbx(args, torch, dev, local_rank, rank, world, steps=None, warmup=None, cpu_leg=True):
     """BASELINE.json configs[4]: 1 h of 16 kHz audio through get_features (VBx 64-band fbank + CMN) and the
-    ResNet-101 x-vector network (144-frame windows, hop 24) -- not the headline metric, printed for DESIGN.md."""
+    ResNet-101 x-vector network (144-frame windows, hop 24) -- not the headline metric.  -> the JSON line as a dict."""
     from inaspeechsegmenter_amd import _native, vbx as V
     from inaspeechsegmenter_amd import keras_model as KM
+    steps = steps or steps
+    warmup = args.warmup if warmup is None else warmup
     ctx = _native.Context(local_rank)
     ctx.set_precision(_native.PREC_BF16X3 if args.precision == 'bf16x3' else _native.PREC_F32)
     if args.workspace_mb:
@@ -465,12 +627,12 @@ def bench_vbx(args, torch, dev, local_rank, rank, world):
         xv = ex('utt', fea, n / FS)
         return t1 - t0, time.perf_counter() - t1, len(xv)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     ctx.synchronize()
     t0 = time.perf_counter()
     tf = tx = 0.0
-    for _ in range(args.steps):
+    for _ in range(steps):
         a, b_, nwin = step()
         tf += a
         tx += b_
@@ -481,13 +643,13 @@ def bench_vbx(args, torch, dev, local_rank, rank, world):
     step()
     conv_ms, conv_launches, conv_flops = ctx.prof_get(0)
     fb_ms, _, _ = ctx.prof_get(1)                    # vbx_fbank_kernel alone (HIP events on the library's stream)
-    ktab, kdom = gemm_kernel_table([ctx], MFMA_BF16_PEAK_TF if args.precision == 'bf16x3' else MFMA_F32_PEAK_TF)
+    ktab, kdom = gemm_kernel_table([ctx], MFMA_BF16_PEAK_TF if args.precision == 'bf16x3' else MFMA_F32_PEAK_TF, _pmc_static())
     ctx.prof_enable(False)
     # feature stage: algorithmic bytes = PCM16 in + the cached dither stream (f64) + (T, 64) f32 out
     T = n // 160
     fea_bytes = n * 2 + n * 8 + T * 64 * 4
     cpu = None
-    if not args.no_cpu_baseline:
+    if cpu_leg and not args.no_cpu_baseline:
         import torch as _t
         from oracle import vbx as ovbx
         threads = min(os.cpu_count() or 1, 64)
@@ -512,19 +674,19 @@ def bench_vbx(args, torch, dev, local_rank, rank, world):
                "sample": f"oracle get_features on {nsec} s ({c1 - c0:.2f} s, numpy, 1 thread) + torch-CPU ResNet-101 on {len(starts)} windows "
                          f"in one batch ({per_win * 1e3:.1f} ms per window, {threads} threads), extrapolated to 1 h = 14 995 windows",
                "parity_max_rel_err_vs_gpu": float(np.abs(got - emb).max() / max(np.abs(emb).max(), 1e-9))}
-    line = {"metric": "hours-of-audio through the vbx x-vector path per second", "value": args.steps * hours / dt,
-            "unit": "hours-of-audio/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "x_realtime": args.steps * hours * 3600 / dt,
+    line = {"metric": "hours-of-audio through the vbx x-vector path per second", "value": steps * hours / dt,
+            "unit": "hours-of-audio/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "x_realtime": steps * hours * 3600 / dt,
             "higher_is_better": True, "dtype": "f32 (bf16x3 split-operand MFMA; f64 fbank front end)", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[4]: {args.minutes:g} min synthetic audio, get_features + ResNet-101 on "
                                    f"{nwin} windows (seeded stand-in weights); PCM16 in page-locked host memory -> device, features stay in HBM",
-                       "features_ms_per_step": tf / args.steps * 1e3, "xvectors_ms_per_step": tx / args.steps * 1e3},
+                       "features_ms_per_step": tf / steps * 1e3, "xvectors_ms_per_step": tx / steps * 1e3},
             "roofline": {"bound": "mfma", "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0, "peak": MFMA_BF16_PEAK_TF,
                          "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF) if conv_ms else 0.0,
                          "unit": "TFLOP/s", "kernel_ms_per_step": conv_ms, "launches_per_step": conv_launches, "flops_per_step": conv_flops,
                          "dominant": kdom, "kernels": ktab,
                          "secondary": {"kernel": "vbx_fbank_kernel + vbx_cumsum_kernel + vbx_cmn_kernel (PCM16 + dither -> 64-band fbank, CMN)",
-                                       "bound": "hbm", "algorithmic_bytes": fea_bytes, "stage_ms_per_step": tf / args.steps * 1e3,
+                                       "bound": "hbm", "algorithmic_bytes": fea_bytes, "stage_ms_per_step": tf / steps * 1e3,
                                        "fbank_kernel_ms": fb_ms,
                                        "achieved": fea_bytes / (fb_ms * 1e-3) / 1e9 if fb_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": (fea_bytes / (fb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if fb_ms > 0 else 0.0,
@@ -533,19 +695,25 @@ def bench_vbx(args, torch, dev, local_rank, rank, world):
                                                "the PCM16 (2 B/sample), the sequential CMN cumsum and launch overheads"}}}
     if cpu:
         line["cpu_baseline"] = cpu
-    print(json.dumps(line))
+    ctx.close()
+    return line
 
 
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == '--cpu-worker':          # one process of cpu_file_parallel_leg: numpy only, no torch
+        print(_cpu_feature_worker((int(sys.argv[2]), int(sys.argv[3]))))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--minutes', type=float, default=60.0, help='length of each rank\'s recording')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', choices=['segmenter', 'batch', 'archive', 'vbx'], default=None,
-                    help="segmenter = the metric's workload (default for --gpus 1); archive = file-parallel configs[3] shape "
-                         "(default for --gpus > 1); batch = configs[2]; vbx = configs[4] (x-vector path)")
+    ap.add_argument('--workload', choices=['segmenter', 'batch', 'archive', 'vbx'], default='segmenter',
+                    help="segmenter = the metric's workload (default at every --gpus N, with the other configurations as "
+                         "`companions`); archive = file-parallel configs[3] shape; batch = configs[2]; vbx = configs[4] (x-vector path)")
+    ap.add_argument('--no-companions', action='store_true', help='segmenter workload: skip the archive / batch / vbx companion runs')
+    ap.add_argument('--companion-files-per-gpu', type=int, default=64, help='files per GPU of the archive companion (3 min each)')
     ap.add_argument('--files-per-gpu', type=int, default=0, help='batch / archive: files per GPU and step (default 128)')
     ap.add_argument('--file-minutes', type=float, default=0.0, help='batch / archive: minutes per file (default 5 / 3)')
     ap.add_argument('--dir', default='/dev/shm/iss_bench', help='batch / archive: where the synthetic WAV files live')
@@ -559,7 +727,6 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -572,25 +739,28 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    if args.workload is None:
-        args.workload = 'segmenter' if world == 1 else 'archive'
     if args.workload in ('batch', 'archive'):
         if args.workload == 'batch' and world > 1:
             raise SystemExit("--workload batch is the single-GPU configs[2]; use --workload archive for N > 1")
-        return bench_files(args, torch, dev, local_rank, rank, world, args.workload)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        line = bench_files(args, torch, dev, local_rank, rank, world, args.workload)
+        if rank == 0:
+            print(json.dumps(line))
+        return
+    if args.workload == 'vbx':
+        if world > 1:
+            raise SystemExit("--workload vbx is the single-GPU configs[4] (a single recording is not split over GPUs)")
+        print(json.dumps(bench_vbx(args, torch, dev, local_rank, rank, world)))
+        return
 
     from inaspeechsegmenter_amd import Segmenter, _native
-    from inaspeechsegmenter_amd.sharding import pack_segments, allgather_segment_tables
-    if args.workload == 'vbx':
-        return bench_vbx(args, torch, dev, local_rank, rank, world)
+    from inaspeechsegmenter_amd.sharding import pack_segments
 
     seg = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models='synthetic', device=local_rank)
     x3 = args.precision == 'bf16x3'
     seg.ctx.set_precision(_native.PREC_BF16X3 if x3 else _native.PREC_F32)
     if args.workspace_mb:
         seg.ctx.set_workspace_limit(args.workspace_mb << 20)
+    comm, comm_kind = make_comm(seg.ctx, rank, world, dev)
     n = int(args.minutes * 60 * FS)
     pcm = synth_recording(rank, n, dev)
     torch.cuda.synchronize()
@@ -599,83 +769,81 @@ def main():
     def step(dense=True):
         lseg = seg.segment_device_pcm(pcm.data_ptr(), n, dense=dense)
         rows = pack_segments(rank, lseg)
-        if world > 1:
-            rows = allgather_segment_tables(rows, capacity=8192, device=dev)
+        if comm:
+            rows = comm.allgather(rows, 8192)
         return lseg, rows
 
     for _ in range(args.warmup):
         step()
 
     def timed(k, dense):
-        if world > 1:
-            dist.barrier()
+        if comm:
+            comm.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
             out = step(dense)
         seg.ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if comm:
+            comm.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, out
+        dt_local = dt
+        if comm:
+            dt = comm.max_over_ranks(dt)
+        return dt, out, dt_local
 
-    dt, (lseg, rows) = timed(args.steps, True)
+    dt, (lseg, rows), dt_local = timed(args.steps, True)
     value = world * args.steps * hours / dt
+    dt_min = -comm.max_over_ranks(-dt_local) if comm else dt_local
+    rccl = comm_audit(comm, comm_kind, rank, world) if comm else None
 
     # reference-semantics rate (VAD on energy slots, gender on speech slots), one step, for the record
     step(False)
-    dt_ref, (lseg_ref, _) = timed(1, False)
-    assert lseg_ref == lseg or os.environ.get("ISS_DBG"), "dense and reference-semantics passes disagree"
+    dt_ref, (lseg_ref, _), _ = timed(1, False)
+    assert lseg_ref == lseg, "dense and reference-semantics passes disagree"
     P = (seg.ctx.T + 1) // 2
     slots = {lab: 0 for lab in ('noEnergy', 'music', 'noise', 'female', 'male')}
     for lab, a, b in lseg:
         slots[lab] = slots.get(lab, 0) + (b - a)
 
-    # ---- roofline of the dominant kernel class (conv/dense implicit GEMM on f32 MFMA), measured live
-    # with HIP events on the library's own stream around every launch of one extra dense step
+    # ---- roofline, measured live with HIP events on the library's own stream around every launch of one extra dense step
+    # (every rank runs it: the step holds the collective; rank 0's context is read)
+    pj = _pmc_static()
     seg.ctx.prof_enable(True)
     seg.ctx.prof_reset()
     step(True)
     conv_ms, conv_launches, conv_flops = seg.ctx.prof_get(0)
     sk_ms, sk_launches, _ = seg.ctx.prof_get(1)
     other_ms, other_launches, _ = seg.ctx.prof_get(2)
-    ktab, kdom = gemm_kernel_table([seg.ctx], MFMA_BF16_PEAK_TF if x3 else MFMA_F32_PEAK_TF)
-    seg.ctx.prof_enable(False)
-    achieved_tf = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    # HBM traffic per conv launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own): read from the
-    # committed summary of the latest such passes and labelled as static; `traffic` applies the guide's gfx950 correction
-    # (FETCH_SIZE reports half of a wide coalesced read: fetch x 2 + write), `traffic_raw` is the counters' own sum
-    traffic = traffic_raw = None
-    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
-    if os.path.exists(pmc_path):
-        try:
-            pj = json.load(open(pmc_path))
-            traffic_raw = pj.get('conv_hbm_bytes_per_launch_' + args.precision)
-            traffic = pj.get('conv_hbm_bytes_per_launch_corrected_' + args.precision, traffic_raw)
-        except Exception:
-            traffic = traffic_raw = None
-    sk_bytes = n * 2 + seg.ctx.T * 25 * 4                # PCM16 in + (24 mel + 1 loge) f32 out
     peak_tf = MFMA_BF16_PEAK_TF if x3 else MFMA_F32_PEAK_TF
+    ktab, kdom = gemm_kernel_table([seg.ctx], peak_tf, pj)
+    seg.ctx.prof_enable(False)
+    all_tf = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    sk_bytes = n * 2 + seg.ctx.T * 25 * 4                # PCM16 in + (24 mel + 1 loge) f32 out
+    kd = kdom or {"kernel": None, "achieved": 0.0, "frac": 0.0, "flops_per_launch": 0.0, "avg_launch_ms": 0.0, "launches": 0, "ms_per_step": 0.0}
+    traffic_src = ("static_from_profiles: profiles/pmc_latest.json = rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of "
+                   + str(pj.get('source', 'bench.py --minutes 20 --steps 1 --warmup 0 of the round-3 build'))
+                   + "; per launch of THIS instantiation, 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for 16-byte-per-lane "
+                     "reads); PMC counters cannot be collected inside a bench run")
     roofline = {"bound": "mfma",
-                "kernel": ("all conv2d/dense implicit-GEMM launches: conv_x3_ws_kernel (second conv of both nets, shared first layer), "
-                           "conv_x3_fp_kernel (3x3 layers), conv_x3_pw_kernel / conv_x3_kernel (dense head); 3 x v_mfma_f32_32x32x16_bf16 per "
-                           "k-step on bf16 hi/lo operand splits; `achieved` counts the reference's ALGORITHMIC flops: the matrix pipe "
-                           "executes 3x that, and the first layer, 1.9 % of them, is computed once per log-mel row instead of once per "
-                           "window; `dominant` is the kernel with the most time, with its own flops and fraction") if x3 else
-                          "conv_igemm_kernel (conv2d/dense implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                "dominant": kdom, "kernels": ktab,
-                "achieved": achieved_tf, "peak": peak_tf, "unit": "TFLOP/s",
-                "frac": achieved_tf / peak_tf, "traffic": traffic, "traffic_raw": traffic_raw,
-                "traffic_source": "static_from_profiles (profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                  "this build on bench.py --minutes 20; launch-weighted mean over the conv GEMM launches)",
-                "mfma_executed_tflops": achieved_tf * (3 if x3 else 1),
-                "flops_per_launch": conv_flops / max(conv_launches, 1), "avg_launch_ms": conv_ms / max(conv_launches, 1),
-                "launches_per_step": conv_launches, "kernel_ms_per_step": conv_ms,
+                "kernel": kd["kernel"],
+                "achieved": kd["achieved"], "peak": peak_tf, "unit": "TFLOP/s", "frac": kd["frac"],
+                "traffic": kd.get("traffic_per_launch_static"), "traffic_source": traffic_src,
+                "flops_per_launch": kd["flops_per_launch"], "avg_launch_ms": kd["avg_launch_ms"],
+                "launches_per_step": kd["launches"], "kernel_ms_per_step": kd["ms_per_step"],
+                "mfma_executed_tflops": kd["achieved"] * (3 if x3 else 1),
+                "what": ("the kernel INSTANTIATION with the most HIP-event time in one dense step (template arguments spelled out: "
+                         "<KH,KW,PADDED,TR,FUSED,NH,EPI>); achieved = its algorithmic flops per launch / its average launch duration. "
+                         "bf16x3: three v_mfma_f32_32x32x16_bf16 per k-step on bf16 hi/lo operand splits -- the matrix pipe executes "
+                         "3 x the algorithmic flops, so frac <= 1/3 by construction; the first layer of a fused launch (1.9 % of its "
+                         "flops) is counted as the reference computes it (once per window) although it runs once per log-mel row")
+                        if x3 else "conv_igemm_kernel (conv2d/dense implicit GEMM on v_mfma_f32_32x32x2_f32)",
+                "kernels": ktab,
+                "all_gemm_launches": {"achieved": all_tf, "frac": all_tf / peak_tf, "kernel_ms_per_step": conv_ms, "launches_per_step": conv_launches,
+                                      "flops_per_step": conv_flops,
+                                      "traffic_per_launch_static": pj.get('conv_hbm_bytes_per_launch_corrected_' + args.precision),
+                                      "traffic_per_launch_static_raw": pj.get('conv_hbm_bytes_per_launch_' + args.precision)},
                 "secondary": {"kernel": "sidekit_kernel (PCM16 -> log-energy + 24-band log-mel)", "bound": "hbm",
                               "achieved": sk_bytes / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": (sk_bytes / (sk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sk_ms > 0 else 0.0,
@@ -687,7 +855,7 @@ def main():
     if x3 and not args.no_f32_companion:
         seg.ctx.set_precision(_native.PREC_F32)
         step(True)
-        dt32, (lseg32, _) = timed(1, True)
+        dt32, (lseg32, _), _ = timed(1, True)
         seg.ctx.prof_enable(True)
         seg.ctx.prof_reset()
         step(True)
@@ -705,8 +873,24 @@ def main():
         cpu, nsec, det = cpu_baseline(seg, host)
         par = parity_check(seg, host, nsec, det)
 
-    if world > 1:
-        dist.barrier()
+    # ---- companions: the other configurations, driver-timed in the same line.  archive (configs[3] shape) at every N -- the
+    # file-based path gets its own 1 -> N curve --, batch (configs[2]) and vbx (configs[4]) on one GPU.
+    companions = None
+    if not args.no_companions:
+        del pcm
+        torch.cuda.empty_cache()
+        companions = {}
+        arch = bench_files(args, torch, dev, local_rank, rank, world, 'archive', seg=seg, comm=comm, comm_kind=comm_kind,
+                           steps=2, warmup=1, per_gpu=args.companion_files_per_gpu)
+        if rank == 0:
+            companions["archive"] = _companion_view(arch)
+        if world == 1:
+            companions["batch"] = _companion_view(bench_files(args, torch, dev, local_rank, rank, world, 'batch', seg=seg, steps=2, warmup=1))
+            vb = bench_vbx(args, torch, dev, local_rank, rank, world, steps=2, warmup=1, cpu_leg=False)
+            companions["vbx"] = _companion_view(vb)
+
+    if comm:
+        comm.barrier()
     if rank == 0:
         vad_f = seg.ctx.cnn_flops(0)
         gen_f = seg.ctx.cnn_flops(1)
@@ -719,28 +903,55 @@ def main():
             "x_realtime_per_gpu": value * 3600.0 / world,
             "config": {"workload": f"BASELINE.json configs[1] input ({args.minutes:g} min synthetic 16 kHz mono PCM16 per GPU, "
                                    "resident in HBM) through smn VAD + gender (the metric's nets; configs[1] itself lists smn only), "
-                                   "dense mode: both CNNs on 100% of the 20 ms slots",
+                                   "dense mode: both CNNs on 100% of the 20 ms slots; the same workload and code path at every --gpus N "
+                                   "(one recording per rank, one all-gather of the segment tables per step when N > 1)",
                        "audio_hours_per_step_per_gpu": hours, "slots_per_step_per_gpu": P,
                        "weights": "seeded stand-ins, (68,21,1)->3 and (68,24,1)->2, ~1.25 M params each, last layer calibrated on the generator's "
                                   "ground truth and the reference's musanmix goldens (tests/golden/make_standin_heads.py); the real "
                                   "Keras files are un-vendored release assets",
                        "vad_flops_per_slot": vad_f, "gender_flops_per_slot": gen_f,
-                       "parallelism": f"file-parallel x{world}, one all-gather of segment tables per step" if world > 1 else "single GPU",
+                       "parallelism": (f"file-parallel x{world} (one recording per rank, no data-path collective), one all-gather of int32 "
+                                       f"segment tables per step: {comm_kind}") if world > 1 else "single GPU",
                        "segments": len(lseg), "label_slots": slots, "cnn_driven_boundaries": cnn_driven_boundaries(lseg),
                        "reference_semantics": {"value": world * hours / dt_ref, "unit": "hours-of-audio/s",
                                                "ms_per_step": dt_ref * 1e3,
                                                "vad_slot_frac": 1.0 - slots['noEnergy'] / P,
                                                "gender_slot_frac": (slots['female'] + slots['male']) / P}},
             "roofline": roofline,
+            "ranks": {"ms_per_step_min": dt_min / args.steps * 1e3, "ms_per_step_max": dt / args.steps * 1e3,
+                      "what": "each rank's own wall time for the timed steps (barrier to barrier), min / max over the ranks"},
         }
+        if rccl is not None:
+            line["rccl"] = rccl
         if f32c is not None:
             line["precision_f32"] = f32c
         if cpu is not None:
             line["cpu_baseline"] = cpu
             line["parity_check"] = par
+        if companions:
+            line["companions"] = companions
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    seg.close()
+
+
+def _companion_view(line):
+    """The fields of a companion run's own line that the headline line carries (the full line is what
+    `--workload <name>` prints on its own)."""
+    if line is None:
+        return None
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "x_realtime", "x_realtime_per_gpu", "scaling", "dtype")
+    out = {k: line[k] for k in keep if k in line}
+    cfg = line.get("config", {})
+    out["config"] = {k: cfg[k] for k in ("workload", "files", "files_per_gpu", "minutes_per_file", "audio_hours_per_step", "ms_per_file_per_gpu",
+                                          "features_ms_per_step", "xvectors_ms_per_step", "parallelism") if k in cfg}
+    r = line.get("roofline", {})
+    out["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step") if k in r}
+    if r.get("dominant"):
+        out["roofline"]["dominant"] = {k: r["dominant"][k] for k in ("kernel", "ms_per_step", "launches", "achieved", "frac") if k in r["dominant"]}
+    for k in ("ranks", "rccl"):
+        if k in line:
+            out[k] = line[k]
+    return out
 
 
 if __name__ == '__main__':

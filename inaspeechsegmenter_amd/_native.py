@@ -89,6 +89,8 @@ def lib():
         'iss_prof_get': (C.c_int, [vp, C.c_int, pd, pi64, pd]),
         'iss_prof_reset': (C.c_int, [vp]),
         'iss_prof_get_row': (C.c_int, [vp, C.c_int, pd, pi64]),
+        'iss_prof_get_instance': (C.c_int, [vp, C.c_int, C.c_char_p, i32, pd, pi64, pd]),
+        'iss_set_diag': (C.c_int, [vp, C.c_uint32]),
         'iss_viterbi_f64': (C.c_int, [pd, i64, i32, pd, pi32]),
         'iss_viterbi_f32': (C.c_int, [pf, i64, i32, pd, pi32]),
         'iss_energy_viterbi': (C.c_int, [pf, i64, C.c_double, C.c_double, C.c_double, pd, pi32]),
@@ -101,6 +103,19 @@ def lib():
     L._iss_symbols = tuple(sig)
     _lib = L
     return L
+
+
+DIAG_BITS = {'no_shared_first': 0x001, 'no_flrows': 0x002, 'no_ws': 0x004, 'no_ws3': 0x008, 'no_direct1': 0x010,
+             'no_nh2': 0x020, 'no_tr': 0x040, 'no_pw': 0x080, 'no_pws': 0x100, 'no_pws2': 0x200}      # include/iss.h ISS_DIAG_*
+
+
+def diag_flags(names):
+    """'no_shared_first,no_pws2' -> ISS_DIAG_* bit mask (unknown names raise)."""
+    flags = 0
+    for nm in str(names).replace(' ', '').replace('+', ',').lower().split(','):
+        if nm:
+            flags |= DIAG_BITS[nm]
+    return flags
 
 
 def _ptr(a, ty):
@@ -177,6 +192,10 @@ class Context:
         self.comm_rank, self.comm_world = 0, 1
         self.precision = None       # last value given to set_precision / set_workspace_limit (None = library default)
         self.workspace_limit = None
+        self.diag = 0
+        env = os.environ.get('ISS_DIAG', '')
+        if env:                     # A/B tooling only (tools/ab_env.sh): the library itself never reads the environment
+            self.set_diag(diag_flags(env))
 
     def close(self):
         if getattr(self, '_h', None):
@@ -371,6 +390,14 @@ class Context:
             self.set_precision(other.precision)
         if getattr(other, 'workspace_limit', None) is not None and other.workspace_limit != getattr(self, 'workspace_limit', None):
             self.set_workspace_limit(other.workspace_limit)
+        if getattr(other, 'diag', 0) != getattr(self, 'diag', 0):
+            self.set_diag(other.diag)
+
+    def set_diag(self, flags):
+        """Kernel-selection switches (include/iss.h ISS_DIAG_*): an int, or names like 'no_shared_first,no_pws2'."""
+        flags = diag_flags(flags) if isinstance(flags, str) else int(flags)
+        self._ck(self._L.iss_set_diag(self._h, flags), 'iss_set_diag')
+        self.diag = flags
 
     def synchronize(self):
         self._ck(self._L.iss_synchronize(self._h), 'iss_synchronize')
@@ -432,6 +459,19 @@ class Context:
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         self._ck(self._L.iss_prof_get(self._h, kind, C.byref(ms), C.byref(n), C.byref(fl)), 'iss_prof_get')
         return ms.value, n.value, fl.value
+
+    def prof_instances(self):
+        """[{'kernel', 'ms', 'launches', 'flops'}] per distinct kernel instantiation launched since the last prof_reset."""
+        out = []
+        buf = C.create_string_buffer(192)
+        i = 0
+        while True:
+            ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+            if self._L.iss_prof_get_instance(self._h, i, buf, 192, C.byref(ms), C.byref(n), C.byref(fl)) != 0:
+                break
+            out.append({'kernel': buf.value.decode(), 'ms': ms.value, 'launches': n.value, 'flops': fl.value})
+            i += 1
+        return out
 
     def prof_get_row(self, row):
         """(ms, launches) of op-program row `row` since the last prof_reset (per-layer view of the same event brackets)."""

@@ -910,6 +910,13 @@ extern "C" int iss_set_precision(iss_ctx* c, int mode) {
     return ISS_OK;
 }
 
+extern "C" int iss_set_diag(iss_ctx* c, uint32_t flags) {
+    if (!c) return ISS_EINVAL;
+    if (flags & ~(uint32_t)ISS_DIAG_ALL) return iss_fail(c, ISS_EINVAL, "iss_set_diag: unknown bits 0x%x", flags & ~(uint32_t)ISS_DIAG_ALL);
+    c->diag = flags;
+    return ISS_OK;
+}
+
 extern "C" int iss_cnn_flops(iss_ctx* c, int id, double* f) {
     if (!c || id < 0 || id >= ISS_MAX_NETS || !f) return ISS_EINVAL;
     if (!c->nets[id].loaded) return iss_fail(c, ISS_ESTATE, "net %d not loaded", id);
@@ -1049,7 +1056,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         a.nblk = (unsigned)((a.M + BM - 1) / BM);
         set_fast_div(a, 0, a.pp); set_fast_div(a, 1, a.pw); set_fast_div(a, 2, a.Hq * a.Wq); set_fast_div(a, 3, a.Wq);
-        { static const int dbg = getenv("ISS_DBG") ? atoi(getenv("ISS_DBG")) : 0; a.dbg = dbg; }
+#ifdef ISS_EXPERIMENTS
+        { static const int dbg = getenv("ISS_DBG") ? atoi(getenv("ISS_DBG")) : 0; a.dbg = dbg; }     // timing-only experiment bits (never in a release build)
+#endif
         a.nblk_n = (unsigned)((a.Cout + BN - 1) / BN);
         dim3 grid(a.nblk, a.nblk_n);
         const dim3 grid1(a.nblk * a.nblk_n);          // generic kernels: 1-D, XCD-aware (gemm_tile_of_block)
@@ -1063,7 +1072,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         // weight-stationary kernel (conv_ws.h): the shared-first-layer convolution, 8..16 taps, one N tile of 64 channels
         bool ws = false;
-        static const bool no_ws = getenv("ISS_NO_WS") != nullptr;
+        const bool no_ws = (c->diag & ISS_DIAG_NO_WS) != 0;
         if (!no_ws && fp && pend >= 0 && a.H_k * a.kw >= 8 && a.H_k * a.kw <= WS_MAXNT && ws_shape_compiled(a.H_k, a.kw) &&
             a.Cin % F2_CH == 0 && a.H * a.W >= WS_PIX + 64 + (a.pt_ + 1) * a.W && ws_recip_exact(a.W, a.H * a.W + WS_PIX + a.W)) {
             const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 62);
@@ -1076,7 +1085,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         // weight-stationary kernel with two column halves per workgroup (conv_ws.h, NH = 2): unpadded 3x3 stride-1 layers with
         // a multiple of 128 output channels whose 512-row tiles fit a 1024-pixel footprint -- the 3x3 layers of the segmenter nets
         bool ws_nh2 = false;
-        static const bool no_ws3 = getenv("ISS_NO_WS3") != nullptr;
+        const bool no_ws3 = (c->diag & ISS_DIAG_NO_WS3) != 0;
         const bool nh2_pad_ok = a.pp == 1 && a.Cout % 4 == 0 && issk::epi_is_simple_tr(a);       // the padded form is compiled transposed + simple only
         if (!no_ws && !no_ws3 && pend < 0 && x3 && a.mode == 0 && (!padded || nh2_pad_ok) && a.sh == 1 && a.sw == 1 && !a.res && a.Cout % (2 * BN) == 0 &&
             issk::iss_ws_nh2_compiled(a.H_k, a.kw) && a.Cin % F2_CH == 0 && a.M < (1ll << 31) &&
@@ -1116,7 +1125,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 iss_prof_begin(c, 2, 0);
                 const dim3 rgrid((unsigned)std::min<long long>((rtot + 255) / 256, 4096));
                 const size_t rlds = (size_t)R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4;
-                static const bool no_rows = getenv("ISS_NO_FLROWS") != nullptr;       // diagnostic: the per-output kernel
+                const bool no_rows = (c->diag & ISS_DIAG_NO_FLROWS) != 0;             // diagnostic: the per-output kernel
                 // compiled for the two input widths of the reference's nets: 21 bands (smn / sm) -> 17 positions, 24 (gender) -> 20
                 const bool rows_ok = !no_rows && R1[ISS_C_KH] == 4 && R1[ISS_C_KW] == 5 && (R1[ISS_C_WO] == 17 || R1[ISS_C_WO] == 20) &&
                                      rrows * (R1[ISS_C_COUT] / 4) < (1ll << 31);
@@ -1149,12 +1158,13 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         iss_prof_tag(c, ws || ws_plain || ws_nh2 ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
         iss_prof_row(c, r);
         // one-channel 3x3 'same' first layer of a non-PATCH network: direct f32 kernel (either arithmetic mode)
-        static const bool no_direct = getenv("ISS_NO_DIRECT1") != nullptr;
+        const bool no_direct = (c->diag & ISS_DIAG_NO_DIRECT1) != 0;
         const bool direct1 = !no_direct && !patch && pend < 0 && a.Cin == 1 && a.H_k == 3 && a.kw == 3 && a.sh == 1 && a.sw == 1 && a.pt_ == 1 &&
                              a.pl_ == 1 && R[ISS_C_HO] == a.H && R[ISS_C_WO] == a.W && a.pp == 1 && !a.res && !a.ps && a.act <= 1 && a.bias &&
                              a.Cout % 4 == 0 && a.Cout <= 256 && a.M * (long long)(a.Cout / 4) < (1ll << 34);
         if (direct1) {
             iss_prof_tag(c, ISS_PROF_GATHER);
+            iss_prof_inst(c, "conv1_direct3x3_kernel<%s>", window ? "true" : "false");
             const long long items = (long long)(a.M / ((long long)a.H * a.W)) * ((a.H + 7) / 8) * a.W * (a.Cout / 4);
             if (items >= (1ll << 32)) return iss_fail(c, ISS_EINVAL, "internal: direct first layer over %lld work items", items);
             const dim3 dgrid((unsigned)std::min<long long>((items + 255) / 256, 8192));
@@ -1166,32 +1176,45 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const unsigned ngroups = (unsigned)((a.M + WS_TM - 1) / WS_TM);         // one 512-row tile per group
             const unsigned ny = (unsigned)(a.Cout / (2 * BN));
             const dim3 g2(std::min<unsigned>(ngroups, std::max(1u, 256u / ny)), ny);
+            {   // template arguments as iss_ws_launch_nh2_3x3* pick them: <KH,KW,PADDED,TR,FUSED,NH,EPI>
+                const bool trn = padded || (a.pp == 1 && a.Cout % 4 == 0);
+                const int epi = padded ? 1 : (trn ? issk::epi_is_simple_tr(a) : issk::epi_is_pool_relu(a));
+                iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,%s,false,2,%d>", a.H_k, a.kw, padded ? "true" : "false", trn ? "true" : "false", epi);
+            }
             if (padded) issk::iss_ws_launch_nh2_3x3_padded(a, g2, c->stream);
             else issk::iss_ws_launch_nh2_3x3(a, g2, c->stream, a.pp == 1 && a.Cout % 4 == 0);
         } else if (ws_plain) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const unsigned per_n = std::max(1u, 256u / grid.y);                   // one 512-thread workgroup per CU in total
+            iss_prof_inst(c, "conv_x3_ws_kernel<3,3,true,true,false,1,%d>", (int)issk::epi_is_simple_tr(a));
             issk::iss_ws_launch_plain_3x3(a, dim3(std::min<unsigned>(ngroups, per_n), grid.y), c->stream);
         } else if (ws) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);         // persistent: one 512-thread workgroup per CU
             const bool tr = a.pp == 1 && a.Cout % 4 == 0;
+            {
+                const int epi = tr ? issk::epi_is_simple_tr(a) : issk::epi_is_pool_relu(a);
+                iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,%s,true,1,%d>", a.H_k, a.kw, padded ? "true" : "false", tr ? "true" : "false", epi);
+            }
 #define ISS_WS_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_ws_launch_##KH_##x##KW_(a, wgrid, c->stream, padded, tr, fused); else
             ISS_WS_SHAPES(ISS_WS_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no weight-stationary kernel for %dx%d", a.H_k, a.kw); }
 #undef ISS_WS_CASE
         } else if (fp) {
 #define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr, fused, nh); else
             // 128 output channels per workgroup where the layer has them: one LDS footprint serves two 64-column halves
-            static const bool no_nh2 = getenv("ISS_NO_NH2") != nullptr;
+            const bool no_nh2 = (c->diag & ISS_DIAG_NO_NH2) != 0;
             const int nh = (!fused && !no_nh2 && issk::iss_fp_has_nh2(a.H_k, a.kw) && a.Cout % (2 * BN) == 0) ? 2 : 1;
             const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y / nh);     // persistent: 2 workgroups per CU
-            static const bool no_tr = getenv("ISS_NO_TR") != nullptr;       // diagnostic: row-major epilogue everywhere
+            const bool no_tr = (c->diag & ISS_DIAG_NO_TR) != 0;             // diagnostic: row-major epilogue everywhere
             const bool tr = !no_tr && a.pp == 1 && a.Cout % 4 == 0;         // float4 epilogue on transposed accumulators
+            if (fused && a.H_k * a.kw >= 12) iss_prof_inst(c, "conv_x3_fp_kernel<%d,%d,false,%s,true,1>", a.H_k, a.kw, tr ? "true" : "false");
+            else iss_prof_inst(c, "conv_x3_fp_kernel<%d,%d,%s,%s,false,%d>", a.H_k, a.kw, padded ? "true" : "false", tr ? "true" : "false", nh);
             ISS_FP_SHAPES(ISS_FP_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no footprint kernel for %dx%d", a.H_k, a.kw); }
 #undef ISS_FP_CASE
         } else if (x3 && patch && a.H_k * a.kw <= XBK && a.M < (1ll << 31)) {
             const dim3 pgrid(std::min<unsigned>(a.nblk, 512u), grid.y);     // persistent, no barriers: 2 workgroups per CU
             iss_prof_tag(c, ISS_PROF_PATCH1);
+            iss_prof_inst(c, "conv1_patch_x3_kernel<%s>", (a.pp == 1 && a.Cout % 4 == 0 && !a.res) ? "true" : "false");
             // blob offsets are multiples of 8 floats, so the float4 loads of bias / scale / shift are aligned
             if (a.pp == 1 && a.Cout % 4 == 0 && !a.res) hipLaunchKernelGGL(conv1_patch_x3_kernel<true>, pgrid, dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL(conv1_patch_x3_kernel<false>, pgrid, dim3(256), 0, c->stream, a);
@@ -1203,7 +1226,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const int ntn = 2;
             a.nblk_n = (unsigned)((a.Cout + 32 * ntn - 1) / (32 * ntn));
             const dim3 gridw(a.nblk * a.nblk_n);
-            static const bool no_pw = getenv("ISS_NO_PW") != nullptr;
+            const bool no_pw = (c->diag & ISS_DIAG_NO_PW) != 0;
             const bool pointwise = !no_pw && a.mode == 0 && tr && a.H_k == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt_ == 0 &&
                                    a.pl_ == 0 && R[ISS_C_HO] == a.H && R[ISS_C_WO] == a.W && a.Kpad == a.Cin;
             if (pointwise) iss_prof_tag(c, ISS_PROF_PW);
@@ -1211,26 +1234,34 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             // 192 columns, ~28 k rows per launch) keeps conv_x3_pw_kernel: it runs at 1.7 TB/s of activations on every tiling
             // that was built for it (deeper ring -8 %; one workgroup per 64 rows x all 192 columns +6 %, with split-K +3..+11 %,
             // with non-temporal activation loads +8 %: profiles/HISTORY.md, round 3)
-            static const bool no_pws = getenv("ISS_NO_PWS") != nullptr;          // diagnostic: the round-2 pointwise kernel everywhere
-            static const bool no_pws2 = getenv("ISS_NO_PWS2") != nullptr;        // diagnostic: 64-column tiles everywhere
+            const bool no_pws = (c->diag & ISS_DIAG_NO_PWS) != 0;                // diagnostic: the round-2 pointwise kernel everywhere
+            const bool no_pws2 = (c->diag & ISS_DIAG_NO_PWS2) != 0;              // diagnostic: 64-column tiles everywhere
             const bool pws_ok = !no_pws && a.Kpad <= 2048;
             // strided 1x1 (the shortcut projections): the 128-column kernel on a strided pixel list
             const bool pw_strided = pws_ok && !no_pws2 && a.mode == 0 && tr && a.H_k == 1 && a.kw == 1 && (a.sh > 1 || a.sw > 1) && a.pt_ == 0 &&
                                     a.pl_ == 0 && a.Kpad == a.Cin && issk::pws2_strided_supported(a, R[ISS_C_HO], R[ISS_C_WO]);
-            if (pw_strided) { iss_prof_tag(c, ISS_PROF_PW); issk::iss_pws2_launch(a, c->stream, true); }
-            else if (pointwise && pws_ok && !no_pws2 && issk::pws2_supported(a)) issk::iss_pws2_launch(a, c->stream);
-            else if (pointwise && pws_ok && issk::pws_supported(a))
+            const bool simple_pw = a.act <= 1 && !a.ps;
+            if (pw_strided) { iss_prof_tag(c, ISS_PROF_PW); iss_prof_inst(c, "conv_x3_pws2_kernel<true,true>"); issk::iss_pws2_launch(a, c->stream, true); }
+            else if (pointwise && pws_ok && !no_pws2 && issk::pws2_supported(a)) {
+                iss_prof_inst(c, "conv_x3_pws2_kernel<%s,false>", simple_pw ? "true" : "false");
+                issk::iss_pws2_launch(a, c->stream);
+            } else if (pointwise && pws_ok && issk::pws_supported(a)) {
+                iss_prof_inst(c, "conv_x3_pws_kernel<%s,%s>", a.res ? "true" : "false", simple_pw ? "true" : "false");
                 issk::iss_pws_launch(a, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), c->stream);
-            else
-            if (pointwise) hipLaunchKernelGGL(conv_x3_pw_kernel, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), dim3(256), 0, c->stream, a);
-            else
+            } else if (pointwise) {
+                iss_prof_inst(c, "conv_x3_pw_kernel");
+                hipLaunchKernelGGL(conv_x3_pw_kernel, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), dim3(256), 0, c->stream, a);
+            } else {
+            iss_prof_inst(c, "conv_x3_kernel<%d,%s,2>", a.mode, (a.mode != 2 && tr) ? "true" : "false");
             if (ntn == 4) hipLaunchKernelGGL((conv_x3_kernel<0, true, 4>), gridw, dim3(256), 0, c->stream, a);
             else if (a.mode == 0 && tr) hipLaunchKernelGGL((conv_x3_kernel<0, true, 2>), gridw, dim3(256), 0, c->stream, a);
             else if (a.mode == 0) hipLaunchKernelGGL((conv_x3_kernel<0, false, 2>), gridw, dim3(256), 0, c->stream, a);
             else if (a.mode == 1 && tr) hipLaunchKernelGGL((conv_x3_kernel<1, true, 2>), gridw, dim3(256), 0, c->stream, a);
             else if (a.mode == 1) hipLaunchKernelGGL((conv_x3_kernel<1, false, 2>), gridw, dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL((conv_x3_kernel<2, false, 2>), gridw, dim3(256), 0, c->stream, a);
+            }
         } else {
+            iss_prof_inst(c, "conv_igemm_kernel<%d>", a.mode);
             if (a.mode == 0) hipLaunchKernelGGL(conv_igemm_kernel<0>, grid1, dim3(256), 0, c->stream, a);
             else if (a.mode == 1) hipLaunchKernelGGL(conv_igemm_kernel<1>, grid1, dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL(conv_igemm_kernel<2>, grid1, dim3(256), 0, c->stream, a);
@@ -1336,7 +1367,7 @@ static int cnn_probs_impl(iss_ctx* c, int id, const int32_t* win_row, int32_t ns
     ISS_HIP(c, hipGetLastError());
     // Shared first layer (ConvArgs::f_*): decided per call from the whole window list, not per chunk, so that the result
     // does not depend on the workspace limit: on when the windows overlap at least 4-fold on average.
-    bool share = !getenv("ISS_NO_FUSE");               // read per call: the tests toggle it
+    bool share = !(c->diag & ISS_DIAG_NO_SHARED_FIRST);
     {
         int gmin = win_row[0], gmax = win_row[0];
         for (int i = 1; i < nslots; ++i) { gmin = std::min(gmin, win_row[i]); gmax = std::max(gmax, win_row[i]); }

@@ -67,7 +67,7 @@ struct ConvArgs {
     int dv_sh[4];
     unsigned nblk;           // M tiles
     unsigned nblk_n;         // N tiles (generic kernels are launched 1-D: nblk * nblk_n workgroups)
-    int dbg;                 // ISS_DBG experiment bits (0 in production)
+    int dbg;                 // experiment bits of an ISS_EXPERIMENTS build (always 0 in a release build)
 };
 
 // Host: magic constants of ConvArgs::dv_* for divisor d >= 1 (mul == 0 means d == 1).
@@ -294,7 +294,8 @@ __device__ __forceinline__ void epilogue_tr(const P& p, const floatx16& acc0, co
                 const float4 s4 = *reinterpret_cast<const float4*>(p.ps + c), t4 = *reinterpret_cast<const float4*>(p.pt + c);
                 v.x = v.x * s4.x + t4.x; v.y = v.y * s4.y + t4.y; v.z = v.z * s4.z + t4.z; v.w = v.w * s4.w + t4.w;
             }
-            if constexpr (std::is_same<P, ConvArgs>::value) {        // ISS_DBG experiments on the store tail (0 in production)
+#ifdef ISS_EXPERIMENTS                                               // store-tail experiments (make EXPERIMENTS=1): never in a release build
+            if constexpr (std::is_same<P, ConvArgs>::value) {
                 if (p.dbg & 1) {                                     // nontemporal stores
                     __builtin_nontemporal_store(v.x, orow + c); __builtin_nontemporal_store(v.y, orow + c + 1);
                     __builtin_nontemporal_store(v.z, orow + c + 2); __builtin_nontemporal_store(v.w, orow + c + 3);
@@ -302,6 +303,7 @@ __device__ __forceinline__ void epilogue_tr(const P& p, const floatx16& acc0, co
                 }
                 if ((p.dbg & 2) && g != 0) continue;                 // a quarter of the stores (wrong results: timing only)
             }
+#endif
             *reinterpret_cast<float4*>(orow + c) = v;
         }
     }

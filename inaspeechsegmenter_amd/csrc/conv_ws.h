@@ -389,7 +389,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     const int gstep = (int)gridDim.x;
     // ISS_DBG bit 2 (experiment): static priority for the second-dispatched half of the workgroup (waves 4..7 share their
     // SIMDs with waves 0..3 and lose the issue arbitration by age: MI355X_MICROARCH.md, "two waves per SIMD", item 4)
+#ifdef ISS_EXPERIMENTS
     if ((p.dbg & 4) && wv >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     bool first_chunk = true;
     for (; grp < ngroups; grp += gstep) {
         const bool last_group = grp + gstep >= ngroups;

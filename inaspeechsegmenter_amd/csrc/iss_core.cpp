@@ -314,6 +314,15 @@ void iss_prof_row(iss_ctx* c, int row) {
     if (!c->prof || c->pending.empty() || row < 0 || row >= ISS_PROF_ROWS) return;
     c->pending.back().row = row;
 }
+void iss_prof_inst(iss_ctx* c, const char* fmt, ...) {
+    if (!c->prof || c->pending.empty()) return;
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    c->pending.back().inst = buf;
+}
 void iss_prof_end(iss_ctx* c) {
     if (!c->prof || c->pending.empty()) return;
     (void)hipEventRecord(c->pending.back().b, c->stream);
@@ -325,6 +334,12 @@ void iss_prof_collect(iss_ctx* c) {      // stream must be idle
             c->prof_ms[p.kind] += ms; c->prof_launch[p.kind] += 1; c->prof_flops[p.kind] += p.flops;
             if (p.sub >= 0) { c->prof_ms[p.sub] += ms; c->prof_launch[p.sub] += 1; c->prof_flops[p.sub] += p.flops; }
             if (p.row >= 0) { c->prof_row_ms[p.row] += ms; c->prof_row_launch[p.row] += 1; }
+            if (!p.inst.empty()) {
+                iss_ctx::Inst* e = nullptr;
+                for (auto& i : c->prof_inst) if (i.name == p.inst) { e = &i; break; }
+                if (!e) { c->prof_inst.emplace_back(); e = &c->prof_inst.back(); e->name = p.inst; }
+                e->ms += ms; e->launches += 1; e->flops += p.flops;
+            }
         }
         c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b);
     }
@@ -337,6 +352,19 @@ extern "C" int iss_prof_reset(iss_ctx* c) {
     iss_prof_collect(c);
     for (int i = 0; i < ISS_PROF_KINDS; ++i) { c->prof_ms[i] = 0; c->prof_launch[i] = 0; c->prof_flops[i] = 0; }
     for (int i = 0; i < ISS_PROF_ROWS; ++i) { c->prof_row_ms[i] = 0; c->prof_row_launch[i] = 0; }
+    c->prof_inst.clear();
+    return ISS_OK;
+}
+extern "C" int iss_prof_get_instance(iss_ctx* c, int index, char* name_out, int32_t name_len, double* ms, int64_t* launches, double* flops) {
+    if (!c || index < 0) return ISS_EINVAL;
+    ISS_HIP(c, hipStreamSynchronize(c->stream));
+    iss_prof_collect(c);
+    if (index >= (int)c->prof_inst.size()) return ISS_EINVAL;          // (no error text: this is how a caller finds the end)
+    const iss_ctx::Inst& e = c->prof_inst[(size_t)index];
+    if (name_out && name_len > 0) { snprintf(name_out, (size_t)name_len, "%s", e.name.c_str()); }
+    if (ms) *ms = e.ms;
+    if (launches) *launches = e.launches;
+    if (flops) *flops = e.flops;
     return ISS_OK;
 }
 extern "C" int iss_prof_get_row(iss_ctx* c, int row, double* ms, int64_t* launches) {

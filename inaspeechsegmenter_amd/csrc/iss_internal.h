@@ -64,6 +64,7 @@ struct iss_ctx {
     IssNet nets[ISS_MAX_NETS];
     uint64_t ws_limit = 12ull << 30;
     int precision = ISS_PREC_BF16X3;
+    uint32_t diag = 0;                    // ISS_DIAG_* kernel-selection switches (iss_set_diag; 0 in production)
     std::vector<DevBuf> act;              // activation buffers (grown on demand)
     DevBuf d_winrow, d_stats, d_finite, d_out, d_in;
     DevBuf raw1;                          // shared first layer: raw conv over the log-mel rows of the current chunk
@@ -97,8 +98,11 @@ struct iss_ctx {
     double prof_flops[ISS_PROF_KINDS] = {};
     double prof_row_ms[ISS_PROF_ROWS] = {};
     int64_t prof_row_launch[ISS_PROF_ROWS] = {};
-    struct Pending { hipEvent_t a, b; int kind; int sub; int row; double flops; };
+    struct Pending { hipEvent_t a, b; int kind; int sub; int row; double flops; std::string inst; };
     std::vector<Pending> pending;
+    // per kernel INSTANTIATION (template arguments spelled out by the launcher): what bench.py's roofline.dominant reports
+    struct Inst { std::string name; double ms = 0; int64_t launches = 0; double flops = 0; };
+    std::vector<Inst> prof_inst;
     std::vector<hipEvent_t> ev_pool;
 };
 
@@ -119,6 +123,7 @@ void iss_stage_mark(iss_ctx* c, int slot);                                      
 void iss_prof_begin(iss_ctx* c, int kind, double flops);
 void iss_prof_tag(iss_ctx* c, int sub);      // kernel class (ISS_PROF_* >= 3) of the launch bracketed last: counted there too
 void iss_prof_row(iss_ctx* c, int row);      // op-program row of the launch bracketed last
+void iss_prof_inst(iss_ctx* c, const char* fmt, ...);   // kernel instantiation of the launch bracketed last (printf-style name)
 void iss_prof_end(iss_ctx* c);
 void iss_prof_collect(iss_ctx* c);
 

@@ -165,6 +165,23 @@ int iss_cnn_forward(iss_ctx* ctx, int net_id, const float* x, int32_t n, float* 
 #define ISS_PREC_F32    1
 int iss_set_precision(iss_ctx* ctx, int mode);
 
+/* Kernel-selection switches for same-box A/B measurements and for the tests that compare two device paths with each
+ * other (e.g. the shared first layer against the per-window one).  0 (default) = production selection.  The library never
+ * reads the environment for these: inaspeechsegmenter_amd/_native.py maps the ISS_DIAG environment variable (a
+ * comma-separated list of the names below, lower case, without the prefix) onto this call when a context is created.  */
+#define ISS_DIAG_NO_SHARED_FIRST 0x001u  /* per-window first layer instead of the shared one (segmenter.py:82 per window)   */
+#define ISS_DIAG_NO_FLROWS       0x002u  /* first_layer_raw_kernel instead of first_layer_rows_kernel                        */
+#define ISS_DIAG_NO_WS           0x004u  /* no weight-stationary footprint kernel (conv_x3_fp_kernel everywhere)             */
+#define ISS_DIAG_NO_WS3          0x008u  /* no NH = 2 weight-stationary kernel for the 3x3 layers                            */
+#define ISS_DIAG_NO_DIRECT1      0x010u  /* no direct f32 kernel for one-channel 3x3 first layers                            */
+#define ISS_DIAG_NO_NH2          0x020u  /* conv_x3_fp_kernel: 64 output channels per workgroup                              */
+#define ISS_DIAG_NO_TR           0x040u  /* conv_x3_fp_kernel: row-major epilogue                                            */
+#define ISS_DIAG_NO_PW           0x080u  /* 1x1 layers on the generic gather kernel                                          */
+#define ISS_DIAG_NO_PWS          0x100u  /* 1x1 layers on the round-2 pointwise kernel                                       */
+#define ISS_DIAG_NO_PWS2         0x200u  /* 1x1 layers: 64-column tiles only                                                 */
+#define ISS_DIAG_ALL             0x3ffu
+int iss_set_diag(iss_ctx* ctx, uint32_t flags);
+
 /* FLOPs (2*MAC of the conv/dense outputs actually computed) per sample of a loaded network. */
 int iss_cnn_flops(iss_ctx* ctx, int net_id, double* flops_per_sample);
 
@@ -239,6 +256,11 @@ int iss_prof_reset(iss_ctx* ctx);
  * the loaded network that a launch executed; rows of different networks share the index space) since the last reset. */
 #define ISS_PROF_ROWS      512
 int iss_prof_get_row(iss_ctx* ctx, int row, double* ms, int64_t* launches);
+/* Per kernel INSTANTIATION: entry `index` (0, 1, ... until ISS_EINVAL) of the list of distinct kernel instantiations
+ * launched since the last reset -- name with its template arguments spelled out (e.g.
+ * "conv_x3_ws_kernel<5,3,false,false,true,1,1>"), accumulated HIP-event time, launches and algorithmic flops.  This is what
+ * bench.py's roofline.dominant is computed from.                                                                        */
+int iss_prof_get_instance(iss_ctx* ctx, int index, char* name_out, int32_t name_len, double* ms, int64_t* launches, double* flops);
 
 /* ------------------------------------------------------------------ host only
  * Viterbi smoothing, replaces pyannote_viterbi.py:118-224 `viterbi_decoding` on the

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""CPU emulation of reduced-operand arithmetic modes for the conv/dense GEMMs of the segmenter nets.
+
+Every conv / dense layer behind the first convolution (which the product computes in exact f32, first_layer_rows_kernel)
+is evaluated in float64 on operands ROUNDED the way a candidate MFMA mode would round them; accumulation error is thereby
+excluded (the MFMA accumulates in f32 like the f32 mode does) and what is left is the operand-splitting error alone:
+
+  f32        a * w                                       (reference arithmetic, segmenter.py:163)
+  bf16x3     a_h w_h + a_l w_h + a_h w_l                 (shipping mode, 3 MFMAs per k-step)
+  bf16x2_w   (a_h + a_l) w_h                             (2 MFMAs: weights rounded to bf16)
+  bf16x2_a   a_h (w_h + w_l)                             (2 MFMAs: activations rounded to bf16)
+  f16x3      fp16 splits, three terms                    (3 MFMAs, 22-bit operands)
+  f16x2_a    a_h (w_h + w_l) with fp16 splits            (2 MFMAs: activations rounded to fp16)
+  f16x2_w    (a_h + a_l) w_h with fp16 splits            (2 MFMAs: weights rounded to fp16)
+  f16x1      a_h w_h with fp16                           (1 MFMA)
+
+Reported per mode against the f32 row: max |d log p|, max |dp|, slots whose arg-max differs, smallest top-2 margin of the
+f32 row at such a slot.  The judge's gate for shipping a cheaper mode: max |d log p| <= 1e-3 and no arg-max change.
+Runs on CPU only (test infrastructure: imports oracle/)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def rnd(x, kind):
+    import torch
+    if kind == 'bf16':
+        return x.to(torch.float32).to(torch.bfloat16).to(torch.float64)
+    return x.to(torch.float32).to(torch.float16).to(torch.float64)
+
+
+def split(x, kind):
+    h = rnd(x, kind)
+    l = rnd(x.to(__import__('torch').float32).to(__import__('torch').float64) - h, kind)
+    return h, l
+
+
+def fold(layers):
+    """conv/dense + following batchnorm (+ activation) -> [(kind, W f32, b f32, act, pool)] the way keras_model folds them
+    (BatchNorm in float64 into the weights when it follows the linear op directly)."""
+    out = []
+    i = 0
+    while i < len(layers):
+        L = layers[i]
+        ty = L['type']
+        if ty in ('conv2d', 'dense'):
+            W = L['W'].astype(np.float64)
+            b = np.zeros(W.shape[-1]) if L.get('b') is None else L['b'].astype(np.float64)
+            act = L.get('activation') or 'linear'
+            j = i + 1
+            if act == 'linear' and j < len(layers) and layers[j]['type'] == 'batchnorm':
+                B = layers[j]
+                sc = B['gamma'].astype(np.float64) / np.sqrt(B['var'].astype(np.float64) + B['eps'])
+                W = W * sc
+                b = (b - B['mean']) * sc + B['beta']
+                j += 1
+            if act == 'linear' and j < len(layers) and layers[j]['type'] == 'activation':
+                act = layers[j]['fn']
+                j += 1
+            out.append(dict(type=ty, W=W.astype(np.float32), b=b.astype(np.float32), act=act,
+                            strides=L.get('strides', (1, 1)), padding=L.get('padding', 'valid')))
+            i = j
+        elif ty in ('maxpool', 'flatten', 'dropout'):
+            out.append(L)
+            i += 1
+        else:
+            raise ValueError(ty)
+    return out
+
+
+def forward_mode(folded, x, mode, batch=256):
+    """x (N,H,W,1) f32 -> logits (N,C) f64 (pre-softmax) under `mode`."""
+    import torch
+    import torch.nn.functional as F
+    kind = 'bf16' if mode.startswith('bf16') else 'f16'
+    outs = []
+    with torch.no_grad():
+        for s in range(0, len(x), batch):
+            t = torch.from_numpy(np.ascontiguousarray(x[s:s + batch])).to(torch.float64).permute(0, 3, 1, 2)
+            first = True
+            flat = False
+            for L in folded:
+                ty = L['type']
+                if ty in ('conv2d', 'dense'):
+                    w = torch.from_numpy(L['W']).to(torch.float64)
+                    b = torch.from_numpy(L['b']).to(torch.float64)
+                    a32 = t.to(torch.float32).to(torch.float64)          # activations are stored as f32 between layers
+
+                    def op(a, w_):
+                        if ty == 'conv2d':
+                            return F.conv2d(a, w_.permute(3, 2, 0, 1), None, stride=tuple(L['strides']))
+                        return a @ w_
+                    if first or mode == 'f32':
+                        y = op(a32, w)
+                    else:
+                        ah, al = split(a32, kind)
+                        wh, wl = split(w, kind)
+                        if mode.endswith('x3'):
+                            y = op(ah, wh) + op(al, wh) + op(ah, wl)
+                        elif mode.endswith('x2_w'):
+                            y = op(ah + al, wh)
+                        elif mode.endswith('x2_a'):
+                            y = op(ah, wh + wl)
+                        elif mode.endswith('x1'):
+                            y = op(ah, wh)
+                        else:
+                            raise ValueError(mode)
+                    first = False
+                    y = y + (b[None, :, None, None] if ty == 'conv2d' else b)
+                    if L['act'] == 'relu':
+                        y = torch.relu(y)
+                    elif L['act'] == 'softmax':
+                        pass                                          # logits out
+                    elif L['act'] != 'linear':
+                        raise ValueError(L['act'])
+                    t = y
+                elif ty == 'maxpool':
+                    t = F.max_pool2d(t, tuple(L['pool']), tuple(L.get('strides') or L['pool']))
+                elif ty == 'flatten':
+                    t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1); flat = True
+            outs.append(t.numpy())
+    return np.concatenate(outs)
+
+
+def log_softmax(z):
+    z = z - z.max(1, keepdims=True)
+    return z - np.log(np.exp(z).sum(1, keepdims=True))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--seconds', type=int, default=90, help='seconds of the bench generator recording')
+    ap.add_argument('--modes', default='bf16x3,bf16x2_w,bf16x2_a,f16x3,f16x2_a,f16x2_w,f16x1')
+    ap.add_argument('--out', default=None)
+    args = ap.parse_args()
+    import torch
+    torch.set_num_threads(os.cpu_count() or 1)
+    import bench
+    from inaspeechsegmenter_amd import keras_model as KM
+    from oracle import sidekit as osk, segment as oseg
+    res = {}
+    srcs = {}
+    pcm = bench.synth_recording(0, args.seconds * 16000, 'cpu').numpy()
+    srcs['generator'] = (pcm / 32768.0).astype(np.float32)
+    import wave
+    w = wave.open(os.path.join(ROOT, 'tests', 'golden', 'musanmix.wav'))
+    mus = np.frombuffer(w.readframes(w.getnframes()), np.int16)
+    srcs['musanmix'] = (mus / 32768.0).astype(np.float32)
+    nets = {'smn': KM.synthetic_ina_like(21, 3, 1)[0], 'gender': KM.synthetic_ina_like(24, 2, 2)[0]}
+    for sname, sig in srcs.items():
+        mspec, loge, difflen = osk.media2feats(sig)
+        for nname, layers in nets.items():
+            nmel = 21 if nname == 'smn' else 24
+            patches, finite = oseg.get_patches(mspec[:, :nmel].copy(), 68, 2)
+            x = patches[finite][:, :, :, None].astype(np.float32)
+            folded = fold(layers)
+            ref = log_softmax(forward_mode(folded, x, 'f32'))
+            srt = np.sort(ref, 1)
+            margin = srt[:, -1] - srt[:, -2]
+            for mode in args.modes.split(','):
+                lp = log_softmax(forward_mode(folded, x, mode))
+                d = np.abs(lp - ref).max(1)
+                mism = lp.argmax(1) != ref.argmax(1)
+                r = dict(slots=int(len(x)), max_dlogp=float(d.max()), p999_dlogp=float(np.quantile(d, 0.999)),
+                         max_dp=float(np.abs(np.exp(lp) - np.exp(ref)).max()), argmax_mismatch=int(mism.sum()),
+                         min_margin_all=float(margin.min()))
+                res[f'{sname}/{nname}/{mode}'] = r
+                print(f'{sname:10s} {nname:7s} {mode:9s} max|dlogp| {r["max_dlogp"]:.2e}  p99.9 {r["p999_dlogp"]:.2e}  '
+                      f'max|dp| {r["max_dp"]:.2e}  argmax mismatches {r["argmax_mismatch"]} / {len(x)}', flush=True)
+    if args.out:
+        json.dump(res, open(args.out, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()

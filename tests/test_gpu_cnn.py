@@ -193,7 +193,7 @@ def _post_affine_net(nmel, nout, seed):
 def test_shared_first_layer(ctx, nmel, nout, kind):
     """Overlapping windows (the segmenter's every-2nd-row list with edge replicas): the first conv runs once per
     log-mel row and the second conv normalises per window (ConvArgs::f_*).  Must agree with the per-window
-    first layer (ISS_NO_FUSE=1) and with the oracle; windows straddled by one LDS footprint, non-finite and
+    first layer (iss_set_diag ISS_DIAG_NO_SHARED_FIRST) and with the oracle; windows straddled by one LDS footprint, non-finite and
     constant windows included."""
     rng = np.random.default_rng(21)
     layers, shp = KM.synthetic_ina_like(nmel, nout, seed=9) if kind == 'ina' else _post_affine_net(nmel, nout, 9)
@@ -205,11 +205,11 @@ def test_shared_first_layer(ctx, nmel, nout, kind):
     rows = np.concatenate([np.zeros(17, np.int32), np.arange(0, 700 - 68 + 1, 2, dtype=np.int32),
                            np.full(16, 632, np.int32)])
     (probs, fin), n_shared = _conv_launches(ctx, lambda: ctx.cnn_probs(3, rows))
-    os.environ['ISS_NO_FUSE'] = '1'
+    ctx.set_diag('no_shared_first')
     try:
         (probs_pw, fin_pw), n_pw = _conv_launches(ctx, lambda: ctx.cnn_probs(3, rows))
     finally:
-        del os.environ['ISS_NO_FUSE']
+        ctx.set_diag(0)
     assert n_shared < n_pw, 'the shared first layer did not run'      # one GEMM launch less per pass
     ref, rfin = _oracle_probs(layers, mspec, nmel, rows)
     assert np.array_equal(fin, rfin) and np.array_equal(fin_pw, rfin) and 30 < (~fin).sum() < len(rows) - 100
@@ -229,11 +229,11 @@ def test_shared_first_layer_needs_overlap(ctx):
     ctx.set_mspec(_mspec(rng, 3000))
     rows = np.sort(rng.integers(0, 3000 - 68, 40)).astype(np.int32)
     (a, _), n_a = _conv_launches(ctx, lambda: ctx.cnn_probs(3, rows))
-    os.environ['ISS_NO_FUSE'] = '1'
+    ctx.set_diag('no_shared_first')
     try:
         (b, _), n_b = _conv_launches(ctx, lambda: ctx.cnn_probs(3, rows))
     finally:
-        del os.environ['ISS_NO_FUSE']
+        ctx.set_diag(0)
     assert n_a == n_b and np.array_equal(a, b)
 
 
@@ -302,27 +302,19 @@ def test_pointwise_streaming_kernels(ctx, prec, case):
 @pytest.mark.parametrize('nmel,nout', [(21, 3), (24, 2)])
 def test_row_wise_first_layer_is_bit_identical(ctx, nmel, nout):
     """first_layer_rows_kernel (one thread per log-mel row and 4 channels, the input rows in registers) computes the same
-    fmaf chains as first_layer_raw_kernel (one thread per output, ISS_NO_FLROWS=1): the probabilities must not differ in a bit."""
-    import subprocess
-    import sys
-    code = f"""
-import numpy as np, sys
-sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
-from inaspeechsegmenter_amd import keras_model as KM, _native
-ctx = _native.Context(0)
-rng = np.random.default_rng(31)
-layers, shp = KM.synthetic_ina_like({nmel}, {nout}, seed=4)
-ctx.cnn_load(3, KM.compile_layers(layers, shp))
-ctx.set_mspec(rng.normal(-3, 2, (900, 24)).astype(np.float32))
-rows = np.arange(0, 900 - 68 + 1, 2, dtype=np.int32)
-p, f = ctx.cnn_probs(3, rows)
-sys.stdout.buffer.write(p.tobytes())
-"""
+    fmaf chains as first_layer_raw_kernel (one thread per output, ISS_DIAG_NO_FLROWS): the probabilities must not differ in a bit."""
+    rng = np.random.default_rng(31)
+    layers, shp = KM.synthetic_ina_like(nmel, nout, seed=4)
+    ctx.cnn_load(3, KM.compile_layers(layers, shp))
+    ctx.set_mspec(rng.normal(-3, 2, (900, 24)).astype(np.float32))
+    rows = np.arange(0, 900 - 68 + 1, 2, dtype=np.int32)
     outs = []
-    for env_extra in ({}, {'ISS_NO_FLROWS': '1'}):                # the switch is read once per process
-        env = dict(os.environ, **env_extra)
-        r = subprocess.run([sys.executable, '-c', code], capture_output=True, env=env)
-        assert r.returncode == 0, r.stderr.decode()[-2000:]
-        outs.append(np.frombuffer(r.stdout, dtype=np.float32))
-    assert outs[0].size == outs[1].size == 417 * nout
+    for diag in (0, 'no_flrows'):
+        ctx.set_diag(diag)
+        try:
+            p, f = ctx.cnn_probs(3, rows)
+        finally:
+            ctx.set_diag(0)
+        outs.append(p)
+    assert outs[0].shape == outs[1].shape == (417, nout)
     assert np.array_equal(outs[0], outs[1])

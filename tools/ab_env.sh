@@ -1,8 +1,9 @@
 #!/bin/bash
-# Same-box A/B of environment switches (ISS_NO_PWS, ISS_NO_PWS2, ISS_NO_FLROWS, ISS_NO_DIRECT1, ISS_LIB=<other build> ...) on
-# one bench workload, run on the GPU box through gpurun; every variant is run twice, interleaved:
+# Same-box A/B of kernel-selection switches (ISS_DIAG=no_pws+no_pws2 ... -> iss_set_diag, see include/iss.h; '+' separates
+# names here because ',' separates variables) or of two builds (ISS_LIB=<other .so>) on one bench workload, run on the GPU box
+# through gpurun; every variant is run twice, interleaved:
 #   bash tools/ab_env.sh segmenter|vbx  tagA[:ENV=VAL[,ENV=VAL]]  tagB[:ENV=VAL...]  ...
-#   e.g.  gpurun --timeout 400 -- 'bash tools/ab_env.sh vbx new old:ISS_NO_PWS=1'
+#   e.g.  gpurun --timeout 400 -- 'bash tools/ab_env.sh vbx new old:ISS_DIAG=no_pws'
 R=${GRAFT_REPO_ROOT:-$PWD}
 W=$1; shift
 OUT=$R/gpurun_out/ab_env
