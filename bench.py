@@ -712,6 +712,7 @@ def main():
     ap.add_argument('--workload', choices=['segmenter', 'batch', 'archive', 'vbx'], default='segmenter',
                     help="segmenter = the metric's workload (default at every --gpus N, with the other configurations as "
                          "`companions`); archive = file-parallel configs[3] shape; batch = configs[2]; vbx = configs[4] (x-vector path)")
+    ap.add_argument('--timing-only', action='store_true', help='experiment builds of the library that compute wrong results on purpose: no consistency assert')
     ap.add_argument('--no-companions', action='store_true', help='segmenter workload: skip the archive / batch / vbx companion runs')
     ap.add_argument('--companion-files-per-gpu', type=int, default=64, help='files per GPU of the archive companion (3 min each)')
     ap.add_argument('--files-per-gpu', type=int, default=0, help='batch / archive: files per GPU and step (default 128)')
@@ -801,7 +802,7 @@ def main():
     # reference-semantics rate (VAD on energy slots, gender on speech slots), one step, for the record
     step(False)
     dt_ref, (lseg_ref, _), _ = timed(1, False)
-    assert lseg_ref == lseg, "dense and reference-semantics passes disagree"
+    assert lseg_ref == lseg or args.timing_only, "dense and reference-semantics passes disagree"
     P = (seg.ctx.T + 1) // 2
     slots = {lab: 0 for lab in ('noEnergy', 'music', 'noise', 'female', 'male')}
     for lab, a, b in lseg:

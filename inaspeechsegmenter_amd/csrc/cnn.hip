@@ -23,6 +23,7 @@
 //   statpool_kernel      mean || std over time                           (resnet.py:123-127)
 #include "conv_common.h"
 #include "conv_ws.h"
+#include "conv_wq.h"
 #include "conv_pw.h"
 
 using namespace issk;
@@ -1192,6 +1193,29 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);         // persistent: one 512-thread workgroup per CU
             const bool tr = a.pp == 1 && a.Cout % 4 == 0;
+            // one-wave-per-SIMD, two-footprint variant (conv_wq.h): the dominant launch of the segmenter nets
+            bool wq = false;
+            if (!(c->diag & ISS_DIAG_NO_WQ) && fused && !padded && !tr && issk::epi_is_pool_relu(a) && a.pp == 4 && a.ph == 2 &&
+                issk::iss_wq_compiled(a.H_k, a.kw) && a.sh == 1 && a.sw == 1 && a.Cin >= 2 * F2_CH && a.M % 4 == 0 &&
+                (a.M / 4) * (long long)a.Cout * 4 < (1ll << 32)) {
+                // rows per tile: the largest multiple of 4 (<= 512) whose footprint fits the kernel's 800 pixels
+                const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 59);
+                auto it = n.fp_pix.find(key);
+                if (it == n.fp_pix.end()) {
+                    int tmr = 0;
+                    for (int cand = WS_TM; cand >= WS_TM - 32 && !tmr; cand -= 4)
+                        if (footprint_pixels(a, cand) <= issk::WQ_PIX) tmr = cand;
+                    it = n.fp_pix.emplace(key, tmr).first;
+                }
+                a.tmr = it->second;
+                wq = a.tmr > 0;
+            }
+            if (wq) {
+                const unsigned qtiles = (unsigned)((a.M + a.tmr - 1) / a.tmr);
+                const dim3 qgrid(std::min<unsigned>((qtiles + 1) / 2, 256u), grid.y);     // persistent: one 256-thread workgroup per CU
+                iss_prof_inst(c, "conv_x3_wq_kernel<%d,%d>", a.H_k, a.kw);
+                issk::iss_wq_launch_5x3(a, qgrid, c->stream);
+            } else {
             {
                 const int epi = tr ? issk::epi_is_simple_tr(a) : issk::epi_is_pool_relu(a);
                 iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,%s,true,1,%d>", a.H_k, a.kw, padded ? "true" : "false", tr ? "true" : "false", epi);
@@ -1199,6 +1223,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
 #define ISS_WS_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_ws_launch_##KH_##x##KW_(a, wgrid, c->stream, padded, tr, fused); else
             ISS_WS_SHAPES(ISS_WS_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no weight-stationary kernel for %dx%d", a.H_k, a.kw); }
 #undef ISS_WS_CASE
+            }
         } else if (fp) {
 #define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr, fused, nh); else
             // 128 output channels per workgroup where the layer has them: one LDS footprint serves two 64-column halves
@@ -1234,7 +1259,11 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             // 192 columns, ~28 k rows per launch) keeps conv_x3_pw_kernel: it runs at 1.7 TB/s of activations on every tiling
             // that was built for it (deeper ring -8 %; one workgroup per 64 rows x all 192 columns +6 %, with split-K +3..+11 %,
             // with non-temporal activation loads +8 %: profiles/HISTORY.md, round 3)
+#ifdef ISS_PW_NO_ASM_RING                        // build-time escape when tools/check_ring_regs.py rejects this compiler's cnn_pw.o (Makefile)
+            const bool no_pws = true;
+#else
             const bool no_pws = (c->diag & ISS_DIAG_NO_PWS) != 0;                // diagnostic: the round-2 pointwise kernel everywhere
+#endif
             const bool no_pws2 = (c->diag & ISS_DIAG_NO_PWS2) != 0;              // diagnostic: 64-column tiles everywhere
             const bool pws_ok = !no_pws && a.Kpad <= 2048;
             // strided 1x1 (the shortcut projections): the 128-column kernel on a strided pixel list

@@ -1,0 +1,8 @@
+// Instantiation unit of conv_x3_wq_kernel (conv_wq.h): one wave per SIMD, two LDS footprints; the fused 5x3 layer.
+#include "conv_wq.h"
+
+namespace issk {
+void iss_wq_launch_5x3(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv_x3_wq_kernel<5, 3>), grid, dim3(256), 0, st, a);
+}
+}  // namespace issk

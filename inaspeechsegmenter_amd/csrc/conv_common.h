@@ -68,6 +68,7 @@ struct ConvArgs {
     unsigned nblk;           // M tiles
     unsigned nblk_n;         // N tiles (generic kernels are launched 1-D: nblk * nblk_n workgroups)
     int dbg;                 // experiment bits of an ISS_EXPERIMENTS build (always 0 in a release build)
+    int tmr;                 // conv_x3_wq_kernel: rows per tile (<= 512, multiple of 4; 0 elsewhere)
 };
 
 // Host: magic constants of ConvArgs::dv_* for divisor d >= 1 (mul == 0 means d == 1).

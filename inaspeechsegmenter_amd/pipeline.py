@@ -282,8 +282,18 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
                     batch_q.put(('batch', cur))
                     cur = _Batch()
                     nbatch += 1
-            if cur.idx:
+            if cur.idx and not failure:
                 batch_q.put(('batch', cur))
+        except BaseException as exc:                               # noqa: B902  (MemoryError while batching, a bad array, ...)
+            # record it and keep draining the decoders -- they block on the bounded queue / the audio budget while holding
+            # their PCM -- until their end marker, exactly like the `if failure: continue` path above
+            failure.append(exc)
+            while True:
+                it = dec_q.get()
+                if it is None:
+                    break
+                if it[2] is not None:
+                    budget.release(it[2].size)
         finally:
             for _ in range(workers):
                 batch_q.put(None)

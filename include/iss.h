@@ -179,7 +179,8 @@ int iss_set_precision(iss_ctx* ctx, int mode);
 #define ISS_DIAG_NO_PW           0x080u  /* 1x1 layers on the generic gather kernel                                          */
 #define ISS_DIAG_NO_PWS          0x100u  /* 1x1 layers on the round-2 pointwise kernel                                       */
 #define ISS_DIAG_NO_PWS2         0x200u  /* 1x1 layers: 64-column tiles only                                                 */
-#define ISS_DIAG_ALL             0x3ffu
+#define ISS_DIAG_NO_WQ           0x400u  /* conv_x3_ws_kernel (two waves per SIMD) instead of conv_x3_wq_kernel for the fused 5x3 layer */
+#define ISS_DIAG_ALL             0x7ffu
 int iss_set_diag(iss_ctx* ctx, uint32_t flags);
 
 /* FLOPs (2*MAC of the conv/dense outputs actually computed) per sample of a loaded network. */

@@ -576,11 +576,11 @@ def test_pipeline_failure_drains_every_stage(tmp_path):
     src = os.path.join(GOLDEN, 'musanmix.wav')
     out = {}
 
-    def run(seg, cb, workers):
+    def run(seg, cb, workers, batch_files=1):
         try:
             with warnings.catch_warnings():
                 warnings.simplefilter('ignore')
-                pipeline.process_files(seg, [src] * 9, cb, batch_files=1, workers=workers, decode_threads=2)
+                pipeline.process_files(seg, [src] * 9, cb, batch_files=batch_files, workers=workers, decode_threads=2)
             out['exc'] = None
         except BaseException as e:                                  # noqa: B902
             out['exc'] = e
@@ -607,6 +607,21 @@ def test_pipeline_failure_drains_every_stage(tmp_path):
     th.start()
     th.join(120)
     assert not th.is_alive() and isinstance(out['exc'], OSError)
+
+    # an exception inside the packer thread itself (not on_result, not a device call): it must be re-raised by process_files
+    # instead of leaving files silently missing, with the decode threads drained
+    class BadBatch(pipeline._Batch):
+        def samples(self):
+            raise MemoryError('packing failed (simulated)')
+    orig = pipeline._Batch
+    pipeline._Batch = BadBatch
+    try:
+        th = threading.Thread(target=run, args=(make(_FakeDevice({0: predict3, 1: predict2}, {0: 21, 1: 24})), lambda *a: None, 1, 4), daemon=True)
+        th.start()
+        th.join(120)
+        assert not th.is_alive() and isinstance(out['exc'], MemoryError), out
+    finally:
+        pipeline._Batch = orig
 
 
 def test_fused_energy_detector_equals_generic_path():

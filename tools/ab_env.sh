@@ -13,7 +13,7 @@ run() {
   tag=${spec%%:*}
   envs=""
   [ "$spec" != "$tag" ] && envs=$(echo "${spec#*:}" | tr ',' ' ')
-  if [ "$W" = vbx ]; then args="--workload vbx --steps 2 --warmup 1 --no-cpu-baseline"; else args="--no-cpu-baseline --no-f32-companion --steps 4"; fi
+  if [ "$W" = vbx ]; then args="--workload vbx --steps 2 --warmup 1 --no-cpu-baseline"; else args="--no-cpu-baseline --no-f32-companion --no-companions --timing-only --steps 4 ${AB_ARGS}"; fi
   timeout 200 env $envs python $R/bench.py $args > $OUT/${W}_${tag}_$rep.json 2> $OUT/${W}_${tag}_$rep.err
   python - <<PY
 import json

@@ -7,9 +7,9 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/p_stats_$TAG -o r -- python $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/p_stats_$TAG -o r -- python $ROOT/bench.py --no-cpu-baseline --no-companions --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2>/dev/null
 python $ROOT/tools/rocprof_summary.py $(find /tmp/p_stats_$TAG -name '*.db' | head -1) $OUT/kernel_stats.md "python bench.py --no-cpu-baseline --steps 3 --warmup 1 ($*)" > /dev/null
-B="python $ROOT/bench.py --minutes 20 --steps 1 --warmup 0 --no-cpu-baseline"
+B="python $ROOT/bench.py --minutes 20 --steps 1 --warmup 0 --no-cpu-baseline --no-companions --no-f32-companion"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace -d /tmp/p_s_$TAG -o r -- $B > /dev/null 2>&1
 python $ROOT/tools/pmc_summary.py $(find /tmp/p_s_$TAG -name '*.db' | head -1) > $OUT/pmc_sq.json
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM --kernel-trace -d /tmp/p_q1_$TAG -o r -- $B > /dev/null 2>&1
