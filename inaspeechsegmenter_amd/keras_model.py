@@ -488,6 +488,9 @@ def compile_resnet101(params, feat_dim=64, frames=144, eps=1e-5, window_input=Fa
 
     def fold(conv, bn):
         W = np.asarray(params[conv + '.weight'], np.float64)                      # OIHW
+        if (bn + '.weight') not in params:            # an export with BatchNorm already folded into the conv (onnx_reader.py)
+            Wm = W.transpose(0, 2, 3, 1).reshape(W.shape[0], -1)
+            return Wm.astype(np.float32), np.asarray(params[conv + '.bias'], np.float32), W.shape[2], W.shape[3]
         sc = np.asarray(params[bn + '.weight'], np.float64) / np.sqrt(np.asarray(params[bn + '.running_var'], np.float64) + eps)
         sft = np.asarray(params[bn + '.bias'], np.float64) - np.asarray(params[bn + '.running_mean'], np.float64) * sc
         Wm = (W * sc[:, None, None, None]).transpose(0, 2, 3, 1).reshape(W.shape[0], -1)

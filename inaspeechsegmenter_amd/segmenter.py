@@ -62,15 +62,22 @@ def viterbi_decoding(emission, transition):
     return _native.viterbi(emission, transition)
 
 
+_NEP50 = int(np.__version__.split('.')[0]) >= 2      # NumPy >= 2: python-scalar / 0-d promotion by dtype, not by value
+
+
 def _energy_activity(loge, ratio):
     """segmenter.py:69-73."""
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')                 # all-silent input: mean of an empty slice
         threshold = np.mean(loge[np.isfinite(loge)]) + np.log(ratio)
     if isinstance(loge, np.ndarray) and loge.dtype == np.float32 and isinstance(threshold, np.floating):
-        # the comparison (float64, like numpy compares a float32 array with a float64 scalar), pred2logemission and the
-        # two-state Viterbi in one compiled call: same arithmetic, no (T,2) float64 emission array per file
-        return _native.energy_viterbi(loge, np.float64(threshold), _ENERGY_TRANS)
+        # the comparison, pred2logemission and the two-state Viterbi in one compiled call: same arithmetic, no (T,2) float64
+        # emission array per file.  `float32_array > float64_scalar` is a float64 comparison under NumPy >= 2 (NEP 50) and a
+        # float32 one under NumPy 1.x (value-based casting demotes the scalar): the compiled call compares in float64, so for
+        # 1.x the threshold is rounded to float32 first -- (double)x > (double)(float)t == x > (float)t -- and the labels are
+        # whatever the installed NumPy (the one the fallback line below would use) decides
+        thr = np.float64(threshold) if _NEP50 else np.float64(np.float32(threshold))
+        return _native.energy_viterbi(loge, thr, _ENERGY_TRANS)
     raw_activity = (loge > threshold)
     return viterbi_decoding(pred2logemission(raw_activity), log_trans_exp(150, cost0=-5))
 

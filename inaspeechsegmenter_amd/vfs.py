@@ -76,7 +76,12 @@ def get_femininity_score(g_preds):
 
 
 def _load_resnet_params(path):
-    """raw_81.pth (the torch checkpoint behind the reference's commented TorchBackendExtractor, :268-288)."""
+    """final.onnx -- what the reference's live backend loads (OnnxBackendExtractor, vbx_segmenter.py:249-266) -- through the
+    package's own protobuf walk (onnx_reader.py); or raw_81.pth, the torch checkpoint behind the reference's commented
+    TorchBackendExtractor (:268-288)."""
+    if path.lower().endswith('.onnx'):
+        from .onnx_reader import load_resnet101_params
+        return load_resnet101_params(path)
     import torch
     ck = torch.load(path, map_location='cpu')
     sd = ck.get('state_dict', ck)
@@ -86,7 +91,7 @@ def _load_resnet_params(path):
 class VoiceFemininityScoring:
     def __init__(self, gd_model_criteria='bgc', backend='onnx', ffmpeg='ffmpeg', device=0, models=None):
         """gd_model_criteria / backend: as vbx_segmenter.py:97-127.  models: None -> files from the
-        remote_utils search path (raw_81.pth for the x-vector net: the ONNX graph itself is not parsed here);
+        remote_utils search path (final.onnx for the x-vector net, read by onnx_reader.py; raw_81.pth if only that exists);
         'synthetic' -> seeded stand-ins; or a dict {'resnet': state_dict-like, 'mlp': (layers, in_shape),
         'vad': the `models` argument of the inner Segmenter (optional; default = its Keras files)}."""
         assert backend in ['onnx'], "Backend should be 'onnx' (or 'pytorch' if uncommented)."
@@ -110,7 +115,11 @@ class VoiceFemininityScoring:
         elif isinstance(models, dict):
             resnet, mlp = models['resnet'], models['mlp']
         else:
-            resnet = _load_resnet_params(locate_model('raw_81.pth'))
+            try:                                          # the file `get_remote` fetches by default (remote_utils.py:13, backend='onnx')
+                resnet_path = locate_model('final.onnx')
+            except FileNotFoundError:
+                resnet_path = locate_model('raw_81.pth')
+            resnet = _load_resnet_params(resnet_path)
             mlp = keras_model.load_model_file(locate_model(gd_model))
         self.features = FeatureExtractor(self.ctx)
         self.xvector_model = VBxExtractor(self.ctx, resnet)

@@ -139,7 +139,11 @@ def main():
 
     # ---- segmentation bookkeeping: the reference's own lines (ast-extracted, skimage interpreter) vs the oracle ------
     pin = f'{HERE}/segmenter_pin.npz'
-    subprocess.run(['/opt/conda/bin/python3.9', f'{HERE}/ref_segmenter_pin.py', f'{HERE}/sidekit_feats.npz', pin], check=True)
+    # one BLAS / OpenMP thread for the conda interpreter: the reference's own mfcc (a float32 matmul in its mel step) is not
+    # bit-reproducible across thread counts there, which made short_padded_mspec / patches_short_* differ by ~2e-6 between two
+    # runs of this script (round-3 review); the oracle is checked against whatever this run recorded either way
+    env1 = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1')
+    subprocess.run(['/opt/conda/bin/python3.9', f'{HERE}/ref_segmenter_pin.py', f'{HERE}/sidekit_feats.npz', pin], check=True, env=env1)
     check_segmenter_pin(np.load(pin), np.load(f'{HERE}/sidekit_feats.npz'))
 
     # ---- viterbi known-answer cases --------------------------------------------------------

@@ -114,3 +114,25 @@ def test_resident_features_handle(ctx, extractor, golden_vbx):
     assert isinstance(h, V.ResidentFeatures) and len(h) == len(fea)
     b = extractor('utt', h, len(pcm) / 16000.0)
     assert [x[:2] for x in a] == [x[:2] for x in b] and all(np.array_equal(x[2], y[2]) for x, y in zip(a, b))
+
+
+def test_final_onnx_file_through_the_product_loader(ctx, tmp_path, monkeypatch):
+    """The reference's live backend loads `final.onnx` (vbx_segmenter.py:249-266).  A file of that shape written here (seeded
+    ResNet-101, BatchNorm folded the way torch's exporter does) placed where `get_remote` would put it must be found by
+    locate_model, read by the package's own protobuf walk (onnx_reader.py) and give the oracle's x-vectors on the device."""
+    from test_onnx_reader import write_resnet_onnx
+    from inaspeechsegmenter_amd import segmenter as S
+    from inaspeechsegmenter_amd.vfs import _load_resnet_params
+    params = KM.synthetic_resnet101(5)
+    d = tmp_path / 'inaSpeechSegmenter'
+    d.mkdir()
+    write_resnet_onnx(str(d / 'final.onnx'), params, folded=True, tensor_style='raw')
+    monkeypatch.setattr(S, '_MODEL_DIRS', [str(d)])
+    got_params = _load_resnet_params(S.locate_model('final.onnx'))
+    ex = V.VBxExtractor(ctx, got_params)
+    rng = np.random.default_rng(5)
+    fea = rng.normal(0, 1, (3 * 144, 64)).astype(np.float32)
+    starts = [0, 100, 288]
+    got = ex.get_embeddings(fea, starts, 144)
+    want = ovbx.resnet101_forward(params, np.stack([fea[s:s + 144].T for s in starts]))
+    assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
