@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from inaspeechsegmenter_amd import vbx as V
+from inaspeechsegmenter_amd import vbx as V, keras_model as KM
 from oracle import vbx as ovbx
 from conftest import GOLDEN
 
