@@ -24,6 +24,7 @@
 #include "conv_common.h"
 #include "conv_ws.h"
 #include "conv_wq.h"
+#include "conv_wq3.h"
 #include "conv_pw.h"
 
 using namespace issk;
@@ -1182,6 +1183,31 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 const int epi = padded ? 1 : (trn ? issk::epi_is_simple_tr(a) : issk::epi_is_pool_relu(a));
                 iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,%s,false,2,%d>", a.H_k, a.kw, padded ? "true" : "false", trn ? "true" : "false", epi);
             }
+            // one-wave-per-SIMD variant (conv_wq3.h): unpadded, bias + relu (kind 0) or relu + 2 x 1 max-pool (kind 1)
+            int wq3_kind = -1;
+            if (!(c->diag & ISS_DIAG_NO_WQ) && !padded && a.bias && a.act == 1 && !a.ps && !a.res && a.Cin >= 2 * F2_CH &&
+                ws_recip_exact(a.W, issk::WQ3_PIX + a.W)) {
+                if (a.pp == 1 && a.M * (long long)a.Cout * 4 < 0xFFF00000ll) wq3_kind = 0;
+                else if (a.pp == 2 && a.ph == 2 && a.poolkind == 0 && (a.M / 2) * (long long)a.Cout * 4 < 0xFFF00000ll) wq3_kind = 1;
+            }
+            if (wq3_kind >= 0) {
+                const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 58);
+                auto it = n.fp_pix.find(key);
+                if (it == n.fp_pix.end()) {
+                    int tmr = 0;
+                    for (int cand = issk::WQ3_TM; cand >= issk::WQ3_TM - 64 && !tmr; cand -= 4)
+                        if (footprint_pixels(a, cand) <= issk::WQ3_PIX) tmr = cand;
+                    it = n.fp_pix.emplace(key, tmr).first;
+                }
+                a.tmr = it->second;
+                if (a.tmr <= 0) wq3_kind = -1;
+            }
+            if (wq3_kind >= 0) {
+                const unsigned qtiles = (unsigned)((a.M + a.tmr - 1) / a.tmr);
+                const dim3 qgrid(std::min<unsigned>((qtiles + 1) / 2, std::max(1u, 256u / ny)), ny);
+                iss_prof_inst(c, "conv_x3_wq3_kernel<%d>", wq3_kind);
+                issk::iss_wq3_launch(a, qgrid, c->stream, wq3_kind);
+            } else
             if (padded) issk::iss_ws_launch_nh2_3x3_padded(a, g2, c->stream);
             else issk::iss_ws_launch_nh2_3x3(a, g2, c->stream, a.pp == 1 && a.Cout % 4 == 0);
         } else if (ws_plain) {

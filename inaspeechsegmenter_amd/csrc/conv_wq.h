@@ -141,9 +141,11 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
         const int row = n0 + n;
         boff_w = 2u * ((unsigned)(row < p.Cout ? row : 0) * (unsigned)p.Kpad + (unsigned)(h * 8));      // bytes
     }
+    unsigned wdst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(sB_base + w_plane * 2048 + w_half * 1024));     // the wave's piece in tap 0's tile
     auto load_weight_tap = [&](int c0, int v) {      // v: compile-time
         const uint16_t* src = (w_plane ? p.wl : p.wh) + (v * p.Cin + c0);
-        glds16(src, boff_w, (unsigned)__builtin_amdgcn_readfirstlane((int)(sB_base + v * F2_BST + w_plane * 2048 + w_half * 1024)));
+        asm volatile("" : "+s"(wdst0));              // (one scalar add per piece instead of NT hoisted destinations)
+        glds16(src, boff_w, wdst0 + (unsigned)(v * F2_BST));
     };
     unsigned bread = sB_base + (unsigned)((2 * li + (lh ^ ((li >> 3) & 1))) * 16);
     asm volatile("" : "+v"(bread));                  // opaque base: the per-tap offsets stay immediates
