@@ -318,3 +318,40 @@ def test_row_wise_first_layer_is_bit_identical(ctx, nmel, nout):
         outs.append(p)
     assert outs[0].shape == outs[1].shape == (417, nout)
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('nmel,nout', [(21, 3), (24, 2)])
+def test_one_wave_per_simd_kernels_edge_sizes(ctx, nmel, nout):
+    """conv_x3_wq_kernel / conv_x3_wq3_kernel (one wave per SIMD, two footprints, epilogue of a tile behind the next block's MFMAs)
+    against the two-waves-per-SIMD kernels they replaced (iss_set_diag NO_WQ) and against the oracle, on window counts that hit
+    the structure's edges: fewer groups than workgroups, an odd number of tiles (a group with one tile), a last tile with a few
+    rows, one tile in all, 508-row tiles (17-column input), a window with non-finite values at a tile boundary.  Both kernel
+    families accumulate the same products in the same order: the probabilities must be bit-identical."""
+    rng = np.random.default_rng(41)
+    layers, shp = KM.synthetic_ina_like(nmel, nout, seed=3)
+    ctx.cnn_load(3, KM.compile_layers(layers, shp))
+    for T in (70, 72, 78, 100, 141, 300, 1000, 3001):
+        mspec = _mspec(rng, T)
+        if T >= 300:
+            mspec[T // 2, 3] = np.inf
+        ctx.set_mspec(mspec)
+        rows = np.arange(0, T - 68 + 1, 2, dtype=np.int32)
+        if len(rows) < 8:                                            # the shared first layer needs overlapping windows: pad the list
+            rows = np.repeat(rows, 8)[:max(len(rows) * 4, 8)]
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        p_new, f_new = ctx.cnn_probs(3, rows)
+        used = {e['kernel'] for e in ctx.prof_instances()}
+        ctx.prof_enable(False)
+        ctx.set_diag('no_wq')
+        try:
+            p_old, f_old = ctx.cnn_probs(3, rows)
+        finally:
+            ctx.set_diag(0)
+        assert np.array_equal(f_new, f_old)
+        ref, rfin = _oracle_probs(layers, mspec, nmel, rows)
+        assert np.array_equal(f_new, rfin)
+        assert np.abs(p_new - ref).max() < 1e-4, (T, np.abs(p_new - ref).max())
+        assert np.array_equal(p_new, p_old), (T, sorted(used), np.abs(p_new - p_old).max())
+        if T >= 141:
+            assert any(k.startswith('conv_x3_wq_kernel') for k in used) and any(k.startswith('conv_x3_wq3_kernel') for k in used), (T, used)
