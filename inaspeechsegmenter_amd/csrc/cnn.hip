@@ -1223,7 +1223,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             bool wq = false;
             if (!(c->diag & ISS_DIAG_NO_WQ) && fused && !padded && !tr && issk::epi_is_pool_relu(a) && a.pp == 4 && a.ph == 2 &&
                 issk::iss_wq_compiled(a.H_k, a.kw) && a.sh == 1 && a.sw == 1 && a.Cin >= 2 * F2_CH && a.M % 4 == 0 &&
-                (a.M / 4) * (long long)a.Cout * 4 < (1ll << 32)) {
+                (a.M / 4) * (long long)a.Cout * 4 < 0xFFF00000ll && a.Cout <= 256) {
                 // rows per tile: the largest multiple of 4 (<= 512) whose footprint fits the kernel's 800 pixels
                 const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 59);
                 auto it = n.fp_pix.find(key);

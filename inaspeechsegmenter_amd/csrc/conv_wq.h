@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
     // Stores go through a buffer descriptor over `out`: an offset beyond its size is dropped by the hardware, so rows beyond
     // the tile (tmr) or the launch (M) and columns >= Cout need a select on the offset, not a branch.
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(ep.out, 0, (int)((unsigned)(M >> 2) * (unsigned)ep.cout * 4u), 0x00020000);
-    constexpr unsigned E_INVALID = 0x80000000u;      // (the host keeps the output below 2^31 bytes)
+    constexpr unsigned E_INVALID = 0xFFFF0000u;      // + the largest scalar offset below (< 16 KB) stays below 2^32: no wrap-around;
+                                                     // the host keeps the output below 0xFFF00000 bytes
     const int wrow = wv * 128 + 4 * lh;              // first row of the wave's pool windows of register group 0 inside the tile
     int rowb = ep.cout * 4;                          // bytes per pooled output row
     float e_x;
