@@ -355,3 +355,24 @@ def test_one_wave_per_simd_kernels_edge_sizes(ctx, nmel, nout):
         assert np.array_equal(p_new, p_old), (T, sorted(used), np.abs(p_new - p_old).max())
         if T >= 141:
             assert any(k.startswith('conv_x3_wq_kernel') for k in used) and any(k.startswith('conv_x3_wq3_kernel') for k in used), (T, used)
+    # irregular window lists (what the VAD-gated gender pass hands over): gaps, runs, repeats -- a footprint then spans two
+    # windows whose first rows are unrelated
+    mspec = _mspec(rng, 6000)
+    mspec[4000, 5] = np.nan
+    ctx.set_mspec(mspec)
+    for n, dense_runs in ((8, False), (333, False), (1531, True), (2500, True)):
+        if dense_runs:                                               # runs of consecutive slots with gaps between them
+            starts = np.sort(rng.choice(6000 - 68 - 40, n // 25 + 1, replace=False))
+            rows = np.concatenate([np.arange(s, s + rng.integers(1, 40)) for s in starts])[:n].astype(np.int32)
+        else:
+            rows = np.sort(rng.integers(0, 6000 - 68 + 1, n)).astype(np.int32)
+        p_new, f_new = ctx.cnn_probs(3, rows)
+        ctx.set_diag('no_wq')
+        try:
+            p_old, f_old = ctx.cnn_probs(3, rows)
+        finally:
+            ctx.set_diag(0)
+        ref, rfin = _oracle_probs(layers, mspec, nmel, rows)
+        assert np.array_equal(f_new, rfin) and np.array_equal(f_new, f_old)
+        assert np.abs(p_new - ref).max() < 1e-4, (n, np.abs(p_new - ref).max())
+        assert np.array_equal(p_new, p_old), (n, np.abs(p_new - p_old).max())

@@ -47,6 +47,12 @@ def test_topology_parity(ctx, name):
         ref, rfin = _oracle_probs(layers, mspec, nmel, rows)
         assert np.array_equal(fin, rfin), (name, net)
         err = np.abs(probs - ref).max()
+        ctx.set_diag('no_wq')                                            # the one-wave-per-SIMD kernels (where the topology takes them)
+        try:                                                             # accumulate what the kernels they replaced do: same bits
+            p_old, f_old = ctx.cnn_probs(5, rows)
+        finally:
+            ctx.set_diag(0)
+        assert np.array_equal(p_old, probs) and np.array_equal(f_old, fin), (name, net, np.abs(p_old - probs).max())
         scat = np.sort(rng.integers(0, T - 68, 64)).astype(np.int32)     # scattered: per-window first layer
         p2, f2 = ctx.cnn_probs(5, scat)
         r2, rf2 = _oracle_probs(layers, mspec, nmel, scat)
