@@ -25,7 +25,7 @@ def main():
     for o, k, cn, v, d in rows:
         e = disp.setdefault(o, {'k': k, 'us': d / 1e3})
         e[cn] = e.get(cn, 0.0) + v
-    seq = [e for _, e in sorted(disp.items()) if 'conv_' in e['k']]
+    seq = [e for _, e in sorted(disp.items()) if 'conv' in e['k']]
     comp = KM.compile_resnet101(KM.synthetic_resnet101(0), V.FEAT_DIM, V.WINLEN, window_input=True)
     prog = np.asarray(comp.prog).reshape(-1, N.PROG_COLS)
     convs = [r for r in prog if r[N.C_OP] == N.OP_CONV]
