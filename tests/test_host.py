@@ -701,3 +701,15 @@ def test_asm_load_kernels_keep_their_ring_registers(tmp_path):
                        capture_output=True, text=True)
     assert c.returncode == 0, c.stdout
     assert c.stdout.count("ok ") >= 7, c.stdout
+
+
+def test_bench_cpu_file_parallel_leg_runs_without_a_gpu():
+    """bench.py's file-parallel CPU leg (leg 1b) spawns `bench.py --cpu-worker` processes that use numpy and
+    the oracle only: it has to work on a host without a GPU or torch device, and a worker that dies is counted, not waited for."""
+    import bench
+    leg = bench.cpu_file_parallel_leg(2, nsec=4, budget_s=120.0)
+    assert leg['processes'] == 2 and leg['finished'] == 2 and leg['failed'] == 0, leg
+    assert leg['x_realtime_aggregate'] > 0 and leg['x_realtime_one_process_mean'] > 1.0, leg
+    pcm = bench.synth_recording_numpy(3, 5 * bench.FS)
+    assert pcm.dtype == np.int16 and pcm.shape == (5 * bench.FS,) and np.abs(pcm).max() > 0
+    assert np.array_equal(pcm, bench.synth_recording_numpy(3, 5 * bench.FS))          # seeded: the same file every time
