@@ -605,7 +605,7 @@ def bench_vbx(args, torch, dev, local_rank, rank, world, steps=None, warmup=None
     ResNet-101 x-vector network (144-frame windows, hop 24) -- not the headline metric.  -> the JSON line as a dict."""
     from inaspeechsegmenter_amd import _native, vbx as V
     from inaspeechsegmenter_amd import keras_model as KM
-    steps = steps or steps
+    steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
     ctx = _native.Context(local_rank)
     ctx.set_precision(_native.PREC_BF16X3 if args.precision == 'bf16x3' else _native.PREC_F32)

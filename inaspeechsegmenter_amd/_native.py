@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('ISS_LIB') or os.path.join(_HERE, 'libiss_hip.so')    
 PROG_COLS = 32
 OP_CONV, OP_POOL, OP_SOFTMAX, OP_STATPOOL = 1, 2, 3, 4
 (C_OP, C_IN, C_OUT, C_RES, C_H, C_W, C_CIN, C_HO, C_WO, C_COUT, C_KH, C_KW, C_SH, C_SW, C_PT, C_PL,
- C_ACT, C_WOFF, C_BOFF, C_PSOFF, C_PTOFF, C_INMODE, C_POOLKIND, C_ORDER, C_FPOOLH, C_FPOOLW) = range(26)
+ C_ACT, C_WOFF, C_BOFF, C_PSOFF, C_PTOFF, C_INMODE, C_POOLKIND, C_ORDER, C_FPOOLH, C_FPOOLW, C_DUALW, C_DUALB) = range(28)
 PREC_BF16X3, PREC_F32 = 0, 1
 K_ALIGN = 32          # conv weight rows are padded to a multiple of this many k
 BUF_INPUT = -2
@@ -106,7 +106,8 @@ def lib():
 
 
 DIAG_BITS = {'no_shared_first': 0x001, 'no_flrows': 0x002, 'no_ws': 0x004, 'no_ws3': 0x008, 'no_direct1': 0x010,
-             'no_nh2': 0x020, 'no_tr': 0x040, 'no_pw': 0x080, 'no_pws': 0x100, 'no_pws2': 0x200, 'no_wq': 0x400}      # include/iss.h ISS_DIAG_*
+             'no_nh2': 0x020, 'no_tr': 0x040, 'no_pw': 0x080, 'no_pws': 0x100, 'no_pws2': 0x200, 'no_wq': 0x400,
+             'no_dual': 0x800}                                                                                         # include/iss.h ISS_DIAG_*
 
 
 def diag_flags(names):

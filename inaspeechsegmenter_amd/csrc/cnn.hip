@@ -859,6 +859,29 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
                 }
             }
             flops += 2.0 * K * R[ISS_C_COUT] * (double)(R[ISS_C_HO] / fph * fph) * (double)(R[ISS_C_WO] / fpw * fpw);
+            if (R[ISS_C_DUALW] != 0 || R[ISS_C_DUALB] != 0) {     // projection shortcut (row r - 1) + expansion (row r) as one GEMM
+                if (r < 1) return bad("ISS_C_DUALW on the first row");
+                const int32_t* P = &n.prog[(size_t)(r - 1) * ISS_PROG_COLS];
+                int pph, ppw;
+                fused_pool_of(P, pph, ppw);
+                const bool shapes = P[ISS_C_OP] == ISS_OP_CONV && P[ISS_C_KH] == 1 && P[ISS_C_KW] == 1 && R[ISS_C_KH] == 1 && R[ISS_C_KW] == 1 &&
+                                    R[ISS_C_SH] == 1 && R[ISS_C_SW] == 1 && P[ISS_C_SH] >= 1 && P[ISS_C_SW] >= 1 &&
+                                    R[ISS_C_PT] == 0 && R[ISS_C_PL] == 0 && P[ISS_C_PT] == 0 && P[ISS_C_PL] == 0 &&
+                                    R[ISS_C_INMODE] == 0 && P[ISS_C_INMODE] == 0 && fph * fpw == 1 && pph * ppw == 1 &&
+                                    R[ISS_C_HO] == R[ISS_C_H] && R[ISS_C_WO] == R[ISS_C_W] && P[ISS_C_HO] == R[ISS_C_HO] &&
+                                    P[ISS_C_WO] == R[ISS_C_WO] && P[ISS_C_COUT] == R[ISS_C_COUT] &&
+                                    (P[ISS_C_HO] - 1) * P[ISS_C_SH] < P[ISS_C_H] && (P[ISS_C_WO] - 1) * P[ISS_C_SW] < P[ISS_C_W] &&
+                                    R[ISS_C_CIN] % 32 == 0 && P[ISS_C_CIN] % 32 == 0;
+                const bool chain = R[ISS_C_RES] >= 0 && R[ISS_C_RES] == P[ISS_C_OUT] && R[ISS_C_OUT] == R[ISS_C_RES] &&
+                                   R[ISS_C_IN] != P[ISS_C_OUT] && P[ISS_C_IN] != P[ISS_C_OUT] && P[ISS_C_RES] < 0 && P[ISS_C_ACT] == 0 &&
+                                   P[ISS_C_PSOFF] < 0 && R[ISS_C_PSOFF] < 0 && P[ISS_C_BOFF] >= 0 && R[ISS_C_BOFF] >= 0;
+                const int64_t wo = (int64_t)R[ISS_C_DUALW] - 1, bo = (int64_t)R[ISS_C_DUALB] - 1;
+                const bool offs = wo >= 0 && bo >= 0 && (wo & 7) == 0 &&
+                                  wo + (int64_t)R[ISS_C_COUT] * (R[ISS_C_CIN] + P[ISS_C_CIN]) <= blob_floats && bo + R[ISS_C_COUT] <= blob_floats;
+                if (!shapes || !chain || !offs)
+                    return bad("ISS_C_DUALW / ISS_C_DUALB: rows r - 1, r are not a linear 1x1 projection and the in-place 1x1 expansion it is added to, "
+                               "or the concatenated parameters lie outside the blob (include/iss.h)");
+            }
         } else if (R[ISS_C_OP] != ISS_OP_POOL && R[ISS_C_OP] != ISS_OP_SOFTMAX && R[ISS_C_OP] != ISS_OP_STATPOOL) {
             return bad("unknown op");
         }
@@ -1014,7 +1037,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         return true;
     };
-    std::function<int(int, int)> conv_row = [&](int r, int pend) -> int {
+    constexpr int kDualDeclined = -12345;                        // conv_row(r, -1, r - 1): the two-source launch is not possible for this call
+    std::function<int(int, int, int)> conv_row = [&](int r, int pend, int dual) -> int {
         const int32_t* R = &n.prog[(size_t)r * ISS_PROG_COLS];
         const float* in = R[ISS_C_IN] == ISS_BUF_INPUT ? d_input : (const float*)c->act[R[ISS_C_IN]].p;
         float* out = (float*)c->act[R[ISS_C_OUT]].p;
@@ -1065,6 +1089,27 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         dim3 grid(a.nblk, a.nblk_n);
         const dim3 grid1(a.nblk * a.nblk_n);          // generic kernels: 1-D, XCD-aware (gemm_tile_of_block)
         double fl = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * a.Cin * (double)a.Cout * (double)a.M;
+        if (dual >= 0) {
+            // rows `dual` (a linear 1x1 projection, any stride) and r (the in-place 1x1 expansion it is added to) as ONE GEMM over
+            // both inputs on the concatenated weights (ISS_C_DUALW; validated by iss_cnn_load): row `dual`'s output never exists
+            const int32_t* P = &n.prog[(size_t)dual * ISS_PROG_COLS];
+            a.in2 = P[ISS_C_IN] == ISS_BUF_INPUT ? d_input : (const float*)c->act[P[ISS_C_IN]].p;
+            a.Cin2 = P[ISS_C_CIN]; a.H2 = P[ISS_C_H]; a.W2 = P[ISS_C_W]; a.sh2 = P[ISS_C_SH]; a.sw2 = P[ISS_C_SW];
+            const int64_t wo = (int64_t)R[ISS_C_DUALW] - 1;
+            a.w = n.d_blob + wo; a.wh = n.d_wh + wo; a.wl = n.d_wl + wo;
+            a.bias = n.d_blob + (R[ISS_C_DUALB] - 1);
+            a.res = nullptr;
+            a.Kpad = a.Cin + a.Cin2;
+            if (!x3 || a.mode != 0 || !in || !a.in2 || !issk::pws2_dual_supported(a)) return kDualDeclined;
+            fl += 2.0 * a.Cin2 * (double)a.Cout * (double)a.M;
+            iss_prof_begin(c, 0, fl);
+            iss_prof_tag(c, ISS_PROF_PW);
+            iss_prof_row(c, r);
+            iss_prof_inst(c, "conv_x3_pws2_kernel<true,false,dual>");
+            issk::iss_pws2_launch(a, c->stream, false, true);
+            iss_prof_end(c);
+            return ISS_OK;
+        }
         bool fp = false;                               // LDS-footprint kernel usable
         if (x3 && a.mode == 0 && fp_shape_compiled(a.H_k, a.kw) && a.M < (1ll << 31)) {
             const long long key = ((long long)r << 32) | (unsigned)bc;
@@ -1116,7 +1161,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         if (!fused && (long long)bc * a.img_stride >= (1ll << 32)) fp = false;        // 32-bit offsets into the input batch
         if (pend >= 0) {
             if (!fused) {                                    // the deferred first layer runs on its own after all
-                const int rc = conv_row(pend, -1);
+                const int rc = conv_row(pend, -1, -1);
                 if (rc) return rc;
             } else {
                 const int32_t* R1 = &n.prog[(size_t)pend * ISS_PROG_COLS];
@@ -1332,7 +1377,20 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         const int op = R[ISS_C_OP];
         if (op == ISS_OP_CONV) {
             if (pending < 0 && can_defer(r)) { pending = r; *result = out; continue; }
-            const int rc = conv_row(r, pending);
+            // projection shortcut followed by its expansion (ISS_C_DUALW on the next row): one two-source launch when the split-bf16
+            // streaming kernels are in use (the diagnostic switches that move 1x1 layers elsewhere keep their meaning)
+            if (pending < 0 && x3mode && r + 1 < n.nrows && n.prog[(size_t)(r + 1) * ISS_PROG_COLS + ISS_C_DUALW] > 0 &&
+                !(c->diag & (ISS_DIAG_NO_DUAL | ISS_DIAG_NO_PW | ISS_DIAG_NO_PWS | ISS_DIAG_NO_PWS2))) {
+                const int rc2 = conv_row(r + 1, -1, r);
+                if (rc2 == ISS_OK) {
+                    ISS_HIP(c, hipGetLastError());
+                    ++r;
+                    *result = (float*)c->act[n.prog[(size_t)r * ISS_PROG_COLS + ISS_C_OUT]].p;
+                    continue;
+                }
+                if (rc2 != kDualDeclined) return rc2;
+            }
+            const int rc = conv_row(r, pending, -1);
             pending = -1;
             if (rc) return rc;
         } else if (op == ISS_OP_POOL) {

@@ -69,6 +69,11 @@ struct ConvArgs {
     unsigned nblk_n;         // N tiles (generic kernels are launched 1-D: nblk * nblk_n workgroups)
     int dbg;                 // experiment bits of an ISS_EXPERIMENTS build (always 0 in a release build)
     int tmr;                 // conv_x3_wq_kernel: rows per tile (<= 512, multiple of 4; 0 elsewhere)
+    // ---- second input of a two-source 1x1 GEMM (conv_x3_pws2_kernel<.., DUAL>): out = act([in | in2 at stride] . [W | W2]^T + b).
+    // `in` is the row's own NHWC pixel list (Cin channels); GEMM row (b, oy, ox) reads pixel (b, oy * sh2, ox * sw2) of the
+    // (H2, W2, Cin2) images behind `in2`.  wh / wl / Kpad describe the concatenated [Cout][Cin + Cin2] matrix.
+    const float* in2;
+    int Cin2, H2, W2, sh2, sw2;
 };
 
 // Host: magic constants of ConvArgs::dv_* for divisor d >= 1 (mul == 0 means d == 1).

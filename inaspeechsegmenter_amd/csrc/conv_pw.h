@@ -301,8 +301,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pws_kernel(const ConvArgs p) {
 // consumed, with one more barrier per tile before the next k-step's conversion may overwrite it.
 // STRIDED: a 1x1 convolution with stride > 1 (the ResNet shortcut projections, resnet.py:60-64) -- the same GEMM on a
 // strided pixel list: only the per-tile row addresses change (map_row32 once per tile), the k loop does not.
-template <bool SIMPLE, bool STRIDED = false>
+// DUAL: two A sources (ConvArgs::in2 ...): the k-tiles of `in` (Cin / 32 of them) are followed by those of `in2` on its own,
+// possibly strided, pixel list -- a projection shortcut and the expansion it is added to as ONE GEMM over the concatenated K
+// (resnet.py:60-75: relu(bn3(conv3(r)) + bn_s(conv_s(x)))): the shortcut's output (as large as the block's) is neither written
+// nor read back.  Only the per-tile row addresses and the source of a k-step change; the weights are concatenated at load time.
+template <bool SIMPLE, bool STRIDED = false, bool DUAL = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_pws2_kernel(const ConvArgs p) {
+    static_assert(!(STRIDED && DUAL), "");
     constexpr int BN2 = 128;
     constexpr int ABUF = 2 * BM * XLD * 2;           // bytes of one A buffer: hi | lo
     constexpr int WBUF = 2 * BN2 * XLD * 2;          // bytes of one W buffer: hi | lo
@@ -323,7 +328,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pws2_kernel(const ConvArgs p) 
     const int li = lane & 31, lh = lane >> 5;
     const int er = lane >> 3, ec = (lane & 7) * 4;
 
-    struct Tile { long long m0; int n0; bool full; const float* abase; unsigned ao[4]; unsigned wo[2]; };
+    struct Tile { long long m0; int n0; bool full; const float* abase; unsigned ao[4]; unsigned wo[2]; const float* abase2; unsigned ao2[4]; };
+    const int nk1 = p.Cin / XBK;                     // DUAL: k-tiles of the first source
     auto coords = [&](unsigned tt) {
         Tile T;
         unsigned mt, nt;
@@ -332,6 +338,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pws2_kernel(const ConvArgs p) 
         T.n0 = (int)nt * BN2;
         const int left = (int)(p.M - T.m0 < BM ? p.M - T.m0 : BM);
         T.full = left == BM;                         // Cout % 128 == 0: no column edge
+        T.abase2 = nullptr;
+        T.ao2[0] = T.ao2[1] = T.ao2[2] = T.ao2[3] = 0u;
+        if (DUAL) {                                  // second source: GEMM row m = (b, oy, ox) -> pixel (b, oy * sh2, ox * sw2) of in2
+            auto pix2 = [&](int m) {
+                int b, oy, ox;
+                map_row32(p, m, b, oy, ox);
+                return ((long long)b * p.H2 + oy * p.sh2) * p.W2 + ox * p.sw2;
+            };
+            const long long p0 = pix2((int)T.m0);
+            T.abase2 = p.in2 + p0 * p.Cin2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                T.ao2[j] = (unsigned)((pix2((int)T.m0 + (lr + 32 * j < left ? lr + 32 * j : left - 1)) - p0) * p.Cin2 + k8 * 4) * 4u;
+        }
         if (STRIDED) {                               // GEMM row m = output pixel (b, oy, ox) -> input pixel (b, oy * sh, ox * sw)
             auto pix = [&](int m) {
                 int b, oy, ox;
@@ -374,11 +394,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pws2_kernel(const ConvArgs p) 
 
 #define ISS_PWS2_GATHER(I)                                                                                           \
     {                                                                                                                \
-        const float* sa_ = TL.abase + ktl * XBK;                                                                     \
+        const bool s2_ = DUAL && ktl >= nk1;         /* wave-uniform: which source this k-tile comes from */         \
+        const float* sa_ = s2_ ? TL.abase2 + (ktl - nk1) * XBK : TL.abase + ktl * XBK;                               \
         const uint16_t* sh_ = p.wh + ktl * XBK;                                                                      \
         const uint16_t* sl_ = p.wl + ktl * XBK;                                                                      \
-        ISS_PWS_LD(ra[I][0], TL.ao[0], sa_); ISS_PWS_LD(ra[I][1], TL.ao[1], sa_);                                    \
-        ISS_PWS_LD(ra[I][2], TL.ao[2], sa_); ISS_PWS_LD(ra[I][3], TL.ao[3], sa_);                                    \
+        const unsigned o0_ = s2_ ? TL.ao2[0] : TL.ao[0], o1_ = s2_ ? TL.ao2[1] : TL.ao[1];                           \
+        const unsigned o2_ = s2_ ? TL.ao2[2] : TL.ao[2], o3_ = s2_ ? TL.ao2[3] : TL.ao[3];                           \
+        ISS_PWS_LD(ra[I][0], o0_, sa_); ISS_PWS_LD(ra[I][1], o1_, sa_);                                              \
+        ISS_PWS_LD(ra[I][2], o2_, sa_); ISS_PWS_LD(ra[I][3], o3_, sa_);                                              \
         ISS_PWS_LD(rh[I][0], TL.wo[0], sh_); ISS_PWS_LD(rl[I][0], TL.wo[0], sl_);                                    \
         ISS_PWS_LD(rh[I][1], TL.wo[1], sh_); ISS_PWS_LD(rl[I][1], TL.wo[1], sl_);                                    \
         issued += 8; mark[I] = issued;                                                                               \
@@ -529,6 +552,14 @@ inline bool pws2_strided_supported(const ConvArgs& a, int Ho, int Wo) {
            ((long long)(BM / ((long long)Ho * Wo) + 2) * a.img_stride * 4 < (1ll << 31));
 }
 void iss_pws_launch(const ConvArgs& a, dim3 grid, hipStream_t st);               // cnn_pw.hip
-void iss_pws2_launch(const ConvArgs& a, hipStream_t st, bool strided = false);   // 128 x 128 tiles: sets its own column tiling and grid
+// two-source form (ConvArgs::in2): a = the row that carries the residual, with res cleared, bias / wh / wl / Kpad of the
+// concatenated matrix; every byte offset of a tile relative to its first pixel stays below 2^31 in both sources
+inline bool pws2_dual_supported(const ConvArgs& a) {
+    return a.bias != nullptr && !a.res && !a.ps && a.act <= 1 && a.pp == 1 && a.Cout % 128 == 0 && a.Cin % XBK == 0 && a.Cin2 % XBK == 0 &&
+           a.Kpad == a.Cin + a.Cin2 && a.Kpad <= 2048 && a.M < (1ll << 31) && a.sh2 >= 1 && a.sw2 >= 1 &&
+           (long long)BM * a.Cin * 4 < (1ll << 31) && (long long)a.Cout * a.Kpad * 2 < (1ll << 31) && (long long)BM * a.Cout * 4 < (1ll << 31) &&
+           ((long long)(BM / ((long long)a.Hq * a.Wq) + 2) * a.H2 * a.W2 * a.Cin2 * 4 < (1ll << 31));
+}
+void iss_pws2_launch(const ConvArgs& a, hipStream_t st, bool strided = false, bool dual = false);   // 128 x 128 tiles: sets its own column tiling and grid
 
 }  // namespace issk

@@ -228,6 +228,19 @@ class _Builder:
         self.use_buf(dst, ho * wo * cout)
         return (ho, wo, cout)
 
+    def dual(self, Wm_proj, b_proj, Wm_exp, b_exp):
+        """Mark the last two rows -- a linear 1x1 projection and the in-place 1x1 expansion whose residual it is -- as fusable
+        into ONE two-source GEMM (include/iss.h ISS_C_DUALW / ISS_C_DUALB): appends the concatenated matrix [W_exp | W_proj] and
+        the summed bias to the blob.  The two rows stay as they are (the library falls back to them whenever it has to)."""
+        rp, re = self.rows[-2], self.rows[-1]
+        assert rp[N.C_OP] == re[N.C_OP] == N.OP_CONV and re[N.C_RES] == rp[N.C_OUT] == re[N.C_OUT] and rp[N.C_ACT] == 0
+        assert Wm_exp.shape == (re[N.C_COUT], re[N.C_CIN]) and Wm_proj.shape == (rp[N.C_COUT], rp[N.C_CIN]) and rp[N.C_COUT] == re[N.C_COUT]
+        if re[N.C_CIN] % N.K_ALIGN or rp[N.C_CIN] % N.K_ALIGN:
+            return False
+        re[N.C_DUALW] = 1 + self.add_blob(np.concatenate([Wm_exp, Wm_proj], axis=1))
+        re[N.C_DUALB] = 1 + self.add_blob(np.asarray(b_exp, np.float32) + np.asarray(b_proj, np.float32))
+        return True
+
     def pool(self, src, dst, shape_in, kh, kw, sh, sw, pt, pl, ho, wo, kind):
         h, w, c = shape_in
         r = [0] * N.PROG_COLS
@@ -516,6 +529,9 @@ def compile_resnet101(params, feat_dim=64, frames=144, eps=1e-5, window_input=Fa
             if (p + '.shortcut.0.weight') in params:
                 conv(cur, spare, shape, p + '.shortcut.0', p + '.shortcut.1', s, 0, 0)
                 shape = conv(Cc, spare, s2, p + '.conv3', p + '.bn3', 1, 0, 1, res=spare)   # in-place add + relu
+                Wp, bp, _, _ = fold(p + '.shortcut.0', p + '.shortcut.1')                  # both as ONE GEMM over [conv2 out | block input]
+                We, be, _, _ = fold(p + '.conv3', p + '.bn3')
+                B.dual(Wp, bp, We, be)
                 cur, spare = spare, cur
             else:
                 shape = conv(Cc, cur, s2, p + '.conv3', p + '.bn3', 1, 0, 1, res=cur)

@@ -121,6 +121,15 @@ enum {
                                                            the epilogue (0/1 = none; FPOOLH*FPOOLW in {2,4};
                                                            kind in ISS_C_POOLKIND).  HO/WO stay the conv's own
                                                            output size; OUT holds (HO/FPOOLH, WO/FPOOLW, COUT) */
+    ISS_C_DUALW, ISS_C_DUALB,                           /* CONV, optional (0 = absent, else 1 + blob offset): row r is a 1x1
+                                                           stride-1 conv whose residual (RES == OUT) is the output of row
+                                                           r - 1, a LINEAR 1x1 conv (any stride, no bias-free form) of the
+                                                           same output shape -- a projection shortcut and the expansion it
+                                                           is added to (resnet.py:60-75).  DUALW: the concatenated matrix
+                                                           [COUT][CIN(r) + CIN(r-1)] = [W(r) | W(r-1)], DUALB: b(r) + b(r-1).
+                                                           The library may then compute both rows as ONE GEMM over the two
+                                                           inputs (row r - 1's output is never materialised); it falls back
+                                                           to the two rows whenever it cannot.  Both CIN % 32 == 0. */
 };
 #define ISS_BUF_INPUT  (-2)   /* IN: the network input (patch source or iss_cnn_forward input) */
 
@@ -180,7 +189,8 @@ int iss_set_precision(iss_ctx* ctx, int mode);
 #define ISS_DIAG_NO_PWS          0x100u  /* 1x1 layers on the round-2 pointwise kernel                                       */
 #define ISS_DIAG_NO_PWS2         0x200u  /* 1x1 layers: 64-column tiles only                                                 */
 #define ISS_DIAG_NO_WQ           0x400u  /* conv_x3_ws_kernel (two waves per SIMD) instead of conv_x3_wq_kernel for the fused 5x3 layer */
-#define ISS_DIAG_ALL             0x7ffu
+#define ISS_DIAG_NO_DUAL         0x800u  /* projection shortcut + expansion as two launches (ISS_C_DUALW ignored)            */
+#define ISS_DIAG_ALL             0xfffu
 int iss_set_diag(iss_ctx* ctx, uint32_t flags);
 
 /* FLOPs (2*MAC of the conv/dense outputs actually computed) per sample of a loaded network. */

@@ -83,6 +83,37 @@ def test_batched_equals_single(extractor):
     assert np.array_equal(a, b)
 
 
+def test_projection_shortcut_and_expansion_as_one_gemm(ctx, extractor):
+    """The first Bottleneck of each stage (resnet.py:60-75: relu(bn3(conv3(r)) + bn_s(conv_s(x)))) runs as ONE two-source GEMM
+    over [r | x at the block's stride] on the concatenated weights (ISS_C_DUALW, conv_x3_pws2_kernel<.., DUAL>): same
+    x-vectors as the two launches it replaces (the f32 sum is re-associated: 1e-5 of the embedding scale), at 144 frames and
+    on a tail window, four such launches per pass, none with the switch off; the exact-f32 mode never takes it."""
+    rng = np.random.default_rng(9)
+    for frames, nwin in ((144, 11), (65, 3)):
+        fea = rng.normal(0, 1, (frames + 24 * nwin, 64)).astype(np.float32)
+        starts = list(range(0, 24 * nwin, 24))
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        a = extractor.get_embeddings(fea, starts, frames)
+        inst = {e['kernel']: e['launches'] for e in ctx.prof_instances()}
+        ctx.set_diag('no_dual')
+        try:
+            ctx.prof_reset()
+            b = extractor.get_embeddings(fea, starts, frames)
+            inst_off = {e['kernel']: e['launches'] for e in ctx.prof_instances()}
+        finally:
+            ctx.set_diag(0)
+            ctx.prof_enable(False)
+        dual = [k for k in inst if 'dual' in k]
+        passes = -(-nwin // extractor.batch_windows)
+        assert dual and inst[dual[0]] == 4 * passes, inst
+        assert not [k for k in inst_off if 'dual' in k], inst_off
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= 1e-5 * scale, (frames, np.abs(a - b).max(), scale)
+        ref = np.stack([ovbx.resnet101_forward(extractor.params, fea[s:s + frames].T[None])[0] for s in starts[:3]])
+        assert np.abs(a[:3] - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
 def test_pcm16_path_and_device_window_gather(ctx, extractor, golden_vbx):
     """PCM16 entry + cached dither == the int32 + per-call dither entry (bit-identical); x-vectors from the
     device-side window gather (iss_vbx_embed) == the host-stacked windows through iss_cnn_forward."""

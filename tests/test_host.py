@@ -713,3 +713,25 @@ def test_bench_cpu_file_parallel_leg_runs_without_a_gpu():
     pcm = bench.synth_recording_numpy(3, 5 * bench.FS)
     assert pcm.dtype == np.int16 and pcm.shape == (5 * bench.FS,) and np.abs(pcm).max() > 0
     assert np.array_equal(pcm, bench.synth_recording_numpy(3, 5 * bench.FS))          # seeded: the same file every time
+
+
+def test_resnet_compile_marks_projection_blocks_for_the_two_source_gemm():
+    """compile_resnet101 leaves the projection shortcut and the expansion as two rows and adds, on the second, the blob offsets
+    (+ 1) of the concatenated matrix [W_exp | W_proj] and the summed bias (include/iss.h ISS_C_DUALW / ISS_C_DUALB): one per stage."""
+    from inaspeechsegmenter_amd import keras_model as KM, _native as N
+    comp = KM.compile_resnet101(KM.synthetic_resnet101(3), 64, 144, window_input=True)
+    prog = np.asarray(comp.prog).reshape(-1, N.PROG_COLS)
+    blob = np.asarray(comp.blob)
+    rows = [i for i, r in enumerate(prog) if r[N.C_DUALW] > 0]
+    assert len(rows) == 4
+    for i in rows:
+        r, p = prog[i], prog[i - 1]
+        assert r[N.C_RES] == p[N.C_OUT] == r[N.C_OUT] and p[N.C_ACT] == 0 and r[N.C_ACT] == 1 and p[N.C_KH] == r[N.C_KH] == 1
+        k = r[N.C_CIN] + p[N.C_CIN]
+        W = blob[r[N.C_DUALW] - 1:r[N.C_DUALW] - 1 + r[N.C_COUT] * k].reshape(r[N.C_COUT], k)
+        We = blob[r[N.C_WOFF]:r[N.C_WOFF] + r[N.C_COUT] * r[N.C_CIN]].reshape(r[N.C_COUT], -1)
+        Wp = blob[p[N.C_WOFF]:p[N.C_WOFF] + p[N.C_COUT] * p[N.C_CIN]].reshape(p[N.C_COUT], -1)
+        assert np.array_equal(W, np.concatenate([We, Wp], axis=1)) and (r[N.C_DUALW] - 1) % 8 == 0
+        b = blob[r[N.C_DUALB] - 1:r[N.C_DUALB] - 1 + r[N.C_COUT]]
+        assert np.array_equal(b, blob[r[N.C_BOFF]:r[N.C_BOFF] + r[N.C_COUT]] + blob[p[N.C_BOFF]:p[N.C_BOFF] + r[N.C_COUT]])
+    assert all(r[N.C_DUALW] == 0 and r[N.C_DUALB] == 0 for i, r in enumerate(prog) if i not in rows)

@@ -37,19 +37,34 @@ def main():
     for name, body in kernels(path):
         if filt not in name:
             continue
-        ins = []
+        ins, addr, target = [], [], []                # mnemonic + operands, byte offset in the kernel, branch target offset (or None)
+        base = None
         for l in body:
-            l = l.split('//')[0].strip()
-            if not l:
+            code, _, cmt = l.partition('//')
+            code = code.strip()
+            if not code:
                 continue
-            parts = l.replace(',', ' ').split()
+            parts = code.replace(',', ' ').split()
+            ma = re.match(r'\s*([0-9A-Fa-f]+):', cmt)
+            a0 = int(ma.group(1), 16) if ma else None
+            if base is None and a0 is not None:
+                base = a0
+            mt = re.search(r'<[^>]*\+0x([0-9a-fA-F]+)>', cmt) if parts[0].startswith(('s_branch', 's_cbranch')) else None
             ins.append((parts[0], parts[1:]))
+            addr.append(a0 - base if a0 is not None and base is not None else None)
+            target.append(int(mt.group(1), 16) if mt else None)
+        # offsets below which the code runs once (no branch further down jumps back to or above them): copies of a ring register
+        # there, BEFORE the first load into it, move its zero-initialisation around -- not data in flight
+        back = [t for a, t in zip(addr, target) if t is not None and a is not None and t <= a]
+        once_below = min(back) if back else (1 << 62)
         ring = set()
         for op, a in ins:
             if op == 'global_load_dwordx4' and len(a) >= 3 and a[2].startswith('s['):      # the asm loads: SGPR base + 32-bit VGPR offset
                 ring |= regs(a[0])
         readers, writers = Counter(), Counter()
-        for op, a in ins:
+        loaded = set()                                # ring registers an asm load has targeted so far (in program order)
+        init_copies = 0
+        for (op, a), off in zip(ins, addr):
             if not a:
                 continue
             dst, src = regs(a[0]), set()
@@ -58,7 +73,11 @@ def main():
             if op.startswith(('global_store', 'ds_write')):
                 src |= dst
                 dst = set()
-            if src & ring:
+            if op == 'global_load_dwordx4' and len(a) >= 3 and a[2].startswith('s['):
+                loaded |= regs(a[0])
+            if src & ring and op.startswith('v_mov_b') and not (src & ring & loaded) and off is not None and off < once_below:
+                init_copies += 1                      # the zero value of a not-yet-loaded ring register, in the run-once prologue
+            elif src & ring:
                 readers[op] += 1
             if dst & ring and not (op == 'global_load_dwordx4' and a[2].startswith('s[')):
                 writers[op] += 1
@@ -69,7 +88,7 @@ def main():
         verdict = 'ok' if not bad_r and not bad_w and not scratch and n_init * 2 <= len(ring) + 1 else 'CHECK'
         ok &= verdict == 'ok'
         show = (lambda d: dict(d) if len(d) <= 8 else {**dict(list(d.items())[:8]), '...': len(d)})
-        print(f"{verdict:5s} {name[:70]:70s} ring regs {len(ring):3d} readers {show(readers)} writers {show(writers)} scratch {scratch}")
+        print(f"{verdict:5s} {name[:70]:70s} ring regs {len(ring):3d} readers {show(readers)} writers {show(writers)} init copies {init_copies} scratch {scratch}")
     sys.exit(0 if ok else 1)
 
 
