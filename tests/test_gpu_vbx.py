@@ -112,6 +112,17 @@ def test_projection_shortcut_and_expansion_as_one_gemm(ctx, extractor):
         assert np.abs(a - b).max() <= 1e-5 * scale, (frames, np.abs(a - b).max(), scale)
         ref = np.stack([ovbx.resnet101_forward(extractor.params, fea[s:s + frames].T[None])[0] for s in starts[:3]])
         assert np.abs(a[:3] - ref).max() <= 1e-4 * np.abs(ref).max()
+    from inaspeechsegmenter_amd import _native as N
+    ctx.set_precision(N.PREC_F32)
+    try:
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        c = extractor.get_embeddings(fea, starts, frames)
+        assert not [e for e in ctx.prof_instances() if 'dual' in e['kernel']]
+        assert np.abs(c - a).max() <= 1e-4 * np.abs(a).max()
+    finally:
+        ctx.prof_enable(False)
+        ctx.set_precision(N.PREC_BF16X3)
 
 
 def test_pcm16_path_and_device_window_gather(ctx, extractor, golden_vbx):
