@@ -42,6 +42,7 @@ def main():
     print("| row | kh kw s | Cin | Cout | Ho x Wo | res | launches | us / 512 win | alg TFLOP/s | act GB/s | bound us (6 TB/s / 833 TF) | x bound |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
     agg = {}
+    carry = None
     tot = tb = 0.0
     for i, r in enumerate(prog):
         if r[N.C_OP] != N.OP_CONV:
@@ -51,6 +52,14 @@ def main():
         res = r[N.C_RES] >= 0
         fl = 2.0 * ho * wo * cout * kh * kw * cin * 512
         by = 4.0 * (h * w * cin + ho * wo * cout * (2 if res else 1)) * 512
+        if nl == 0 and i + 1 < len(prog) and prog[i + 1][N.C_DUALW] > 0:      # projection shortcut computed inside the next row's two-source GEMM
+            carry = (fl, 4.0 * ho * wo * cin * 512)                            # its flops; the (strided) pixels it reads
+            print(f"| {i} | {kh} {kw} {sh} | {cin} | {cout} | {ho}x{wo} | 0 | 0 | (one GEMM with row {i + 1}) | | | | |")
+            continue
+        if r[N.C_DUALW] > 0 and carry is not None:
+            fl += carry[0]
+            by = 4.0 * (h * w * cin + ho * wo * cout) * 512 + carry[1]                # two inputs, one output, no residual read
+            carry = None
         us = ms * 1e3 * 512 / bw
         bound = max(by / 6e12, fl / 833e12) * 1e6
         print(f"| {i} | {kh} {kw} {sh} | {cin} | {cout} | {ho}x{wo} | {int(res)} | {nl} | {us:.1f} | {fl / max(us, 1e-9) / 1e6:.1f} | {by / max(us, 1e-9) / 1e3:.0f} | {bound:.1f} | {us / bound:.2f} |")
