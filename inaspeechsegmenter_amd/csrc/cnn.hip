@@ -25,6 +25,7 @@
 #include "conv_ws.h"
 #include "conv_wq.h"
 #include "conv_wq3.h"
+#include "conv_pwc.h"
 #include "conv_pw.h"
 
 using namespace issk;
@@ -1037,8 +1038,28 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         return true;
     };
+    // rows r, r + 1: an in-place 1x1 stride-1 expansion with identity residual and relu, then a plain 1x1 stride-1 convolution to
+    // 128 channels that reads it (the next Bottleneck's reduction, resnet.py:48-58) -- the pair conv_x3_pwc_kernel computes
+    auto chain_pair = [&](int r) {
+        if (r + 1 >= n.nrows) return false;
+        const int32_t* R1 = &n.prog[(size_t)r * ISS_PROG_COLS];
+        const int32_t* R2 = &n.prog[(size_t)(r + 1) * ISS_PROG_COLS];
+        int ph, pw, ph2, pw2;
+        fused_pool_of(R1, ph, pw);
+        fused_pool_of(R2, ph2, pw2);
+        auto plain1x1 = [](const int32_t* R) {
+            return R[ISS_C_OP] == ISS_OP_CONV && R[ISS_C_KH] == 1 && R[ISS_C_KW] == 1 && R[ISS_C_SH] == 1 && R[ISS_C_SW] == 1 &&
+                   R[ISS_C_PT] == 0 && R[ISS_C_PL] == 0 && R[ISS_C_INMODE] == 0 && R[ISS_C_PSOFF] < 0 && R[ISS_C_BOFF] >= 0 &&
+                   R[ISS_C_HO] == R[ISS_C_H] && R[ISS_C_WO] == R[ISS_C_W];
+        };
+        return plain1x1(R1) && plain1x1(R2) && ph * pw == 1 && ph2 * pw2 == 1 && R1[ISS_C_DUALW] == 0 &&
+               R1[ISS_C_RES] >= 0 && R1[ISS_C_RES] == R1[ISS_C_OUT] && R1[ISS_C_IN] != R1[ISS_C_OUT] && R1[ISS_C_IN] != ISS_BUF_INPUT &&
+               R1[ISS_C_ACT] == 1 && R2[ISS_C_IN] == R1[ISS_C_OUT] && R2[ISS_C_RES] < 0 && R2[ISS_C_OUT] != R1[ISS_C_OUT] &&
+               R2[ISS_C_OUT] != R1[ISS_C_IN] && R2[ISS_C_ACT] <= 1 && R2[ISS_C_CIN] == R1[ISS_C_COUT] && R2[ISS_C_COUT] == issk::PWC_C3 &&
+               R2[ISS_C_H] == R1[ISS_C_HO] && R2[ISS_C_W] == R1[ISS_C_WO] && n.kpad[r] == R1[ISS_C_CIN] && n.kpad[r + 1] == R2[ISS_C_CIN];
+    };
     constexpr int kDualDeclined = -12345;                        // conv_row(r, -1, r - 1): the two-source launch is not possible for this call
-    std::function<int(int, int, int)> conv_row = [&](int r, int pend, int dual) -> int {
+    std::function<int(int, int, int, int)> conv_row = [&](int r, int pend, int dual, int chain) -> int {
         const int32_t* R = &n.prog[(size_t)r * ISS_PROG_COLS];
         const float* in = R[ISS_C_IN] == ISS_BUF_INPUT ? d_input : (const float*)c->act[R[ISS_C_IN]].p;
         float* out = (float*)c->act[R[ISS_C_OUT]].p;
@@ -1089,6 +1110,24 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         dim3 grid(a.nblk, a.nblk_n);
         const dim3 grid1(a.nblk * a.nblk_n);          // generic kernels: 1-D, XCD-aware (gemm_tile_of_block)
         double fl = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * a.Cin * (double)a.Cout * (double)a.M;
+        if (chain >= 0) {
+            // row r (in-place 1x1 expansion + identity residual + relu) and row `chain` = r + 1 (the next Bottleneck's 1x1 reduction
+            // to 128 channels, which reads row r's output) as ONE launch: the reduction consumes x' out of LDS (conv_pwc.h)
+            const int32_t* Q = &n.prog[(size_t)chain * ISS_PROG_COLS];
+            a.wh2 = n.d_wh + Q[ISS_C_WOFF]; a.wl2 = n.d_wl + Q[ISS_C_WOFF];
+            a.bias2 = Q[ISS_C_BOFF] >= 0 ? n.d_blob + Q[ISS_C_BOFF] : nullptr;
+            a.out2 = (float*)c->act[Q[ISS_C_OUT]].p;
+            a.act2 = Q[ISS_C_ACT];
+            if (!x3 || a.mode != 0 || !in || !issk::pwc_supported(a)) return kDualDeclined;
+            fl += 2.0 * Q[ISS_C_CIN] * (double)Q[ISS_C_COUT] * (double)a.M;
+            iss_prof_begin(c, 0, fl);
+            iss_prof_tag(c, ISS_PROF_PW);
+            iss_prof_row(c, r);
+            iss_prof_inst(c, "conv_x3_pwc_kernel<%d>", a.Cin / 32);
+            issk::iss_pwc_launch(a, c->stream);
+            iss_prof_end(c);
+            return ISS_OK;
+        }
         if (dual >= 0) {
             // rows `dual` (a linear 1x1 projection, any stride) and r (the in-place 1x1 expansion it is added to) as ONE GEMM over
             // both inputs on the concatenated weights (ISS_C_DUALW; validated by iss_cnn_load): row `dual`'s output never exists
@@ -1161,7 +1200,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         if (!fused && (long long)bc * a.img_stride >= (1ll << 32)) fp = false;        // 32-bit offsets into the input batch
         if (pend >= 0) {
             if (!fused) {                                    // the deferred first layer runs on its own after all
-                const int rc = conv_row(pend, -1, -1);
+                const int rc = conv_row(pend, -1, -1, -1);
                 if (rc) return rc;
             } else {
                 const int32_t* R1 = &n.prog[(size_t)pend * ISS_PROG_COLS];
@@ -1377,11 +1416,10 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         const int op = R[ISS_C_OP];
         if (op == ISS_OP_CONV) {
             if (pending < 0 && can_defer(r)) { pending = r; *result = out; continue; }
-            // projection shortcut followed by its expansion (ISS_C_DUALW on the next row): one two-source launch when the split-bf16
-            // streaming kernels are in use (the diagnostic switches that move 1x1 layers elsewhere keep their meaning)
-            if (pending < 0 && x3mode && r + 1 < n.nrows && n.prog[(size_t)(r + 1) * ISS_PROG_COLS + ISS_C_DUALW] > 0 &&
-                !(c->diag & (ISS_DIAG_NO_DUAL | ISS_DIAG_NO_PW | ISS_DIAG_NO_PWS | ISS_DIAG_NO_PWS2))) {
-                const int rc2 = conv_row(r + 1, -1, r);
+            // identity-residual expansion followed by the next block's reduction to 128 channels: one chained launch (conv_pwc.h)
+            if (pending < 0 && x3mode && chain_pair(r) &&
+                !(c->diag & (ISS_DIAG_NO_CHAIN | ISS_DIAG_NO_PW | ISS_DIAG_NO_PWS | ISS_DIAG_NO_PWS2))) {
+                const int rc2 = conv_row(r, -1, -1, r + 1);
                 if (rc2 == ISS_OK) {
                     ISS_HIP(c, hipGetLastError());
                     ++r;
@@ -1390,7 +1428,20 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 }
                 if (rc2 != kDualDeclined) return rc2;
             }
-            const int rc = conv_row(r, pending, -1);
+            // projection shortcut followed by its expansion (ISS_C_DUALW on the next row): one two-source launch when the split-bf16
+            // streaming kernels are in use (the diagnostic switches that move 1x1 layers elsewhere keep their meaning)
+            if (pending < 0 && x3mode && r + 1 < n.nrows && n.prog[(size_t)(r + 1) * ISS_PROG_COLS + ISS_C_DUALW] > 0 &&
+                !(c->diag & (ISS_DIAG_NO_DUAL | ISS_DIAG_NO_PW | ISS_DIAG_NO_PWS | ISS_DIAG_NO_PWS2))) {
+                const int rc2 = conv_row(r + 1, -1, r, -1);
+                if (rc2 == ISS_OK) {
+                    ISS_HIP(c, hipGetLastError());
+                    ++r;
+                    *result = (float*)c->act[n.prog[(size_t)r * ISS_PROG_COLS + ISS_C_OUT]].p;
+                    continue;
+                }
+                if (rc2 != kDualDeclined) return rc2;
+            }
+            const int rc = conv_row(r, pending, -1, -1);
             pending = -1;
             if (rc) return rc;
         } else if (op == ISS_OP_POOL) {

@@ -1,0 +1,10 @@
+// Instantiation unit of conv_x3_pwc_kernel (conv_pwc.h): chained expansion + reduction of two consecutive Bottlenecks.
+#include "conv_pwc.h"
+
+namespace issk {
+void iss_pwc_launch(const ConvArgs& a, hipStream_t st) {
+    const dim3 grid(std::min<unsigned>(a.nblk, 256u));       // one workgroup per CU (155 KB of LDS)
+    if (a.Cin == 64) hipLaunchKernelGGL((conv_x3_pwc_kernel<2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_x3_pwc_kernel<4>), grid, dim3(256), 0, st, a);
+}
+}  // namespace issk

@@ -190,7 +190,8 @@ int iss_set_precision(iss_ctx* ctx, int mode);
 #define ISS_DIAG_NO_PWS2         0x200u  /* 1x1 layers: 64-column tiles only                                                 */
 #define ISS_DIAG_NO_WQ           0x400u  /* conv_x3_ws_kernel (two waves per SIMD) instead of conv_x3_wq_kernel for the fused 5x3 layer */
 #define ISS_DIAG_NO_DUAL         0x800u  /* projection shortcut + expansion as two launches (ISS_C_DUALW ignored)            */
-#define ISS_DIAG_ALL             0xfffu
+#define ISS_DIAG_NO_CHAIN        0x1000u /* identity-residual expansion and the next block's reduction as two launches       */
+#define ISS_DIAG_ALL             0x1fffu
 int iss_set_diag(iss_ctx* ctx, uint32_t flags);
 
 /* FLOPs (2*MAC of the conv/dense outputs actually computed) per sample of a loaded network. */

@@ -125,6 +125,35 @@ def test_projection_shortcut_and_expansion_as_one_gemm(ctx, extractor):
         ctx.set_precision(N.PREC_BF16X3)
 
 
+def test_expansion_and_next_reduction_as_one_chained_launch(ctx, extractor):
+    """conv_x3_pwc_kernel: the in-place 1x1 expansion of an identity Bottleneck (+ residual, relu) and the next Bottleneck's 1x1
+    reduction to 128 channels in one launch -- the reduction reads x' out of LDS instead of HBM.  Same x-vectors as the two
+    launches (1e-5 of the embedding scale: the first GEMM sums its k-steps in two accumulators), on full and tail windows and on
+    a window count that leaves a partial last row tile; 21 + 1 such launches per pass (stage 3, and the stage 2 -> 3 transition)."""
+    rng = np.random.default_rng(10)
+    for frames, nwin in ((144, 5), (65, 3), (144, 1)):
+        fea = rng.normal(0, 1, (frames + 24 * nwin, 64)).astype(np.float32)
+        starts = list(range(0, 24 * nwin, 24))
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        a = extractor.get_embeddings(fea, starts, frames)
+        inst = {e['kernel']: e['launches'] for e in ctx.prof_instances()}
+        ctx.set_diag('no_chain')
+        try:
+            ctx.prof_reset()
+            b = extractor.get_embeddings(fea, starts, frames)
+            inst_off = {e['kernel']: e['launches'] for e in ctx.prof_instances()}
+        finally:
+            ctx.set_diag(0)
+            ctx.prof_enable(False)
+        assert inst.get('conv_x3_pwc_kernel<4>') == 21 and inst.get('conv_x3_pwc_kernel<2>') == 1, inst
+        assert not [k for k in inst_off if 'pwc' in k], inst_off
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= 1e-5 * scale, (frames, nwin, np.abs(a - b).max(), scale)
+        ref = np.stack([ovbx.resnet101_forward(extractor.params, fea[s:s + frames].T[None])[0] for s in starts[:2]])
+        assert np.abs(a[:2] - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
 def test_pcm16_path_and_device_window_gather(ctx, extractor, golden_vbx):
     """PCM16 entry + cached dither == the int32 + per-call dither entry (bit-identical); x-vectors from the
     device-side window gather (iss_vbx_embed) == the host-stacked windows through iss_cnn_forward."""
