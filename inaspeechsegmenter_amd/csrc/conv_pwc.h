@@ -26,6 +26,11 @@
 namespace issk {
 
 constexpr int PWC_C3 = 128;                          // output channels of the second GEMM (one 128-column block)
+#ifndef ISS_PWC_EXP                                  // timing-only experiment builds (wrong results), never set by the Makefile:
+#define ISS_PWC_EXP 0                                // 1 no MFMAs, 2 no stores, 4 no barriers, 8 no residual loads, 16 no weight loads
+#endif
+constexpr bool PWC_X_NOMFMA = ISS_PWC_EXP & 1, PWC_X_NOST = ISS_PWC_EXP & 2, PWC_X_NOBAR = ISS_PWC_EXP & 4, PWC_X_NORES = ISS_PWC_EXP & 8,
+               PWC_X_NOW = ISS_PWC_EXP & 16;
 
 template <int K1T>                                   // C1 = 32 K1T input channels of the first GEMM
 __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
@@ -106,19 +111,21 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
         const uint16_t* el_ = p.wl + (size_t)(32 * (SW)) * p.Kpad;                                                   \
         const uint16_t* rh_ = p.wh2 + 32 * (SW);                                                                     \
         const uint16_t* rl_ = p.wl2 + 32 * (SW);                                                                     \
+        if (!PWC_X_NOW) {                                                                                            \
         _Pragma("unroll") for (int i = 0; i < NWE; ++i) { ISS_PWS_LD(W.weh[i], weo[i], eh_); ISS_PWS_LD(W.wel[i], weo[i], el_); } \
         ISS_PWS_LD(W.wrh[0], wro[0], rh_); ISS_PWS_LD(W.wrl[0], wro[0], rl_);                                        \
         ISS_PWS_LD(W.wrh[1], wro[1], rh_); ISS_PWS_LD(W.wrl[1], wro[1], rl_);                                        \
-        issued += 2 * NWE + 4; markW = issued;                                                                       \
+        issued += 2 * NWE + 4; } markW = issued;                                                                     \
     }
 #define ISS_PWC_GATHER_X(X)                       /* residual block and bias of the cursor's step; the cursor advances */ \
     {                                                                                                                \
         const float* xs_ = p.res + (size_t)tl * BM * C2 + 32 * sl;                                                   \
         const float* bs_ = p.bias + 32 * sl;                                                                         \
+        if (!PWC_X_NORES) {                                                                                          \
         ISS_PWS_LD(X.res[0], OL.x[0], xs_); ISS_PWS_LD(X.res[1], OL.x[1], xs_);                                      \
         ISS_PWS_LD(X.res[2], OL.x[2], xs_); ISS_PWS_LD(X.res[3], OL.x[3], xs_);                                      \
         ISS_PWS_LD(X.b1, bo, bs_);                                                                                   \
-        issued += 5;                                                                                                 \
+        issued += 5; }                                                                                               \
         if (++sl == nsteps) {                                                                                        \
             sl = 0;                                                                                                  \
             tl = tl + gridDim.x < ntiles ? tl + gridDim.x : tl;                                                      \
@@ -188,7 +195,8 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
                 const bf16x8 rl = *reinterpret_cast<const bf16x8*>(&sRl[kt][aoff + ks * 16]);
                 const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&sWeh[weoff + kt * XBK + ks * 16]);
                 const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&sWel[weoff + kt * XBK + ks * 16]);
-                if (ks == 0) {
+                if (PWC_X_NOMFMA) { a1[0] += (float)rh[0] + (float)wl[0]; b1[0] += (float)rl[0] + (float)wh[0]; }
+                else if (ks == 0) {
                     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, rl, a1, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, rh, a1, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, rh, a1, 0, 0, 0);
@@ -217,14 +225,15 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
                 v = v + X.b1;
                 v = v + X.res[j];
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                if (full) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xo) + OC.x[j]) = v;
+                if (PWC_X_NOST) { if (v[0] == 123.456f) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xo) + OC.x[j]) = v; }
+                else if (full) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xo) + OC.x[j]) = v;
                 else if (row < left) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(xo) + OC.x[j]) = v;
                 bf16x4 h, l;
                 pws_split4(v, h, l);
                 *reinterpret_cast<bf16x4*>(&sAh[row * XLD + ec]) = h;
                 *reinterpret_cast<bf16x4*>(&sAl[row * XLD + ec]) = l;
             }
-            if (full) issued += 4;
+            if (full && !PWC_X_NOST) issued += 4;
         }
         __builtin_amdgcn_sched_barrier(0);
         ISS_PWC_GATHER_X(X)                          // the set's registers are free: the residual of step + 2
@@ -242,6 +251,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
                     bh[c] = *reinterpret_cast<const bf16x8*>(&sWrh[boff_s + (c0 + c) * 32 * XLD + ks * 16]);
                     bl[c] = *reinterpret_cast<const bf16x8*>(&sWrl[boff_s + (c0 + c) * 32 * XLD + ks * 16]);
                 }
+                if (PWC_X_NOMFMA) { acc2[c0][0] += (float)bh[0][0] + (float)al[0]; acc2[c0 + 1][0] += (float)bl[1][0] + (float)ah[0] + (float)bh[1][0] + (float)bl[0][0]; continue; }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) acc2[c0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[c], al, acc2[c0 + c], 0, 0, 0);
 #pragma unroll
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
 #define ISS_PWC_STEP(X)                                                                                               \
     {                                                                                                                \
         __builtin_amdgcn_s_waitcnt(0xc07f);          /* lgkmcnt(0): this wave's LDS reads of the previous step */     \
-        __builtin_amdgcn_s_barrier();                /* every wave is done with the previous weight slices (tile start: sR complete) */ \
+        if (!PWC_X_NOBAR) __builtin_amdgcn_s_barrier();                /* every wave is done with the previous weight slices (tile start: sR complete) */ \
         pws_wait_outstanding(issued - markW);        /* this step's weight slices -- and its residual block, which is older */ \
         asm volatile("" : "+v"(W.wrh[0]), "+v"(W.wrl[0]), "+v"(W.wrh[1]), "+v"(W.wrl[1]), "+v"(X.res[0]), "+v"(X.res[1]),   \
                           "+v"(X.res[2]), "+v"(X.res[3]), "+v"(X.b1));                                               \
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
         __builtin_amdgcn_s_waitcnt(0xc07f);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         { const int sw_ = sc + 1 == nsteps ? 0 : sc + 1; ISS_PWC_GATHER_W(sw_) }       /* the next step's slices */  \
-        __builtin_amdgcn_s_barrier();                                                                                \
+        if (!PWC_X_NOBAR) __builtin_amdgcn_s_barrier();                                                                              \
         step_body(X);                                                                                                \
     }
     while (true) {
