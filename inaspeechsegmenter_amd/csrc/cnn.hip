@@ -1039,7 +1039,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         return true;
     };
     // rows r, r + 1: an in-place 1x1 stride-1 expansion with identity residual and relu, then a plain 1x1 stride-1 convolution to
-    // 128 channels that reads it (the next Bottleneck's reduction, resnet.py:48-58) -- the pair conv_x3_pwc_kernel computes
+    // 32 / 64 / 128 channels that reads it (the next Bottleneck's reduction, resnet.py:48-58) -- the pair conv_x3_pwc_kernel computes
     auto chain_pair = [&](int r) {
         if (r + 1 >= n.nrows) return false;
         const int32_t* R1 = &n.prog[(size_t)r * ISS_PROG_COLS];
@@ -1055,7 +1055,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         return plain1x1(R1) && plain1x1(R2) && ph * pw == 1 && ph2 * pw2 == 1 && R1[ISS_C_DUALW] == 0 &&
                R1[ISS_C_RES] >= 0 && R1[ISS_C_RES] == R1[ISS_C_OUT] && R1[ISS_C_IN] != R1[ISS_C_OUT] && R1[ISS_C_IN] != ISS_BUF_INPUT &&
                R1[ISS_C_ACT] == 1 && R2[ISS_C_IN] == R1[ISS_C_OUT] && R2[ISS_C_RES] < 0 && R2[ISS_C_OUT] != R1[ISS_C_OUT] &&
-               R2[ISS_C_OUT] != R1[ISS_C_IN] && R2[ISS_C_ACT] <= 1 && R2[ISS_C_CIN] == R1[ISS_C_COUT] && R2[ISS_C_COUT] == issk::PWC_C3 &&
+               R2[ISS_C_OUT] != R1[ISS_C_IN] && R2[ISS_C_ACT] <= 1 && R2[ISS_C_CIN] == R1[ISS_C_COUT] && issk::pwc_compiled(R1[ISS_C_CIN], R2[ISS_C_COUT]) &&
                R2[ISS_C_H] == R1[ISS_C_HO] && R2[ISS_C_W] == R1[ISS_C_WO] && n.kpad[r] == R1[ISS_C_CIN] && n.kpad[r + 1] == R2[ISS_C_CIN];
     };
     constexpr int kDualDeclined = -12345;                        // conv_row(r, -1, r - 1): the two-source launch is not possible for this call
@@ -1117,13 +1117,13 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             a.wh2 = n.d_wh + Q[ISS_C_WOFF]; a.wl2 = n.d_wl + Q[ISS_C_WOFF];
             a.bias2 = Q[ISS_C_BOFF] >= 0 ? n.d_blob + Q[ISS_C_BOFF] : nullptr;
             a.out2 = (float*)c->act[Q[ISS_C_OUT]].p;
-            a.act2 = Q[ISS_C_ACT];
+            a.act2 = Q[ISS_C_ACT]; a.Cout2 = Q[ISS_C_COUT];
             if (!x3 || a.mode != 0 || !in || !issk::pwc_supported(a)) return kDualDeclined;
             fl += 2.0 * Q[ISS_C_CIN] * (double)Q[ISS_C_COUT] * (double)a.M;
             iss_prof_begin(c, 0, fl);
             iss_prof_tag(c, ISS_PROF_PW);
             iss_prof_row(c, r);
-            iss_prof_inst(c, "conv_x3_pwc_kernel<%d>", a.Cin / 32);
+            iss_prof_inst(c, "conv_x3_pwc_kernel<%d,%d>", a.Cin / 32, a.Cout2 / 32);
             issk::iss_pwc_launch(a, c->stream);
             iss_prof_end(c);
             return ISS_OK;

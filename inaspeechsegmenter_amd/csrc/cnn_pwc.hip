@@ -4,7 +4,10 @@
 namespace issk {
 void iss_pwc_launch(const ConvArgs& a, hipStream_t st) {
     const dim3 grid(std::min<unsigned>(a.nblk, 256u));       // one workgroup per CU (155 KB of LDS)
-    if (a.Cin == 64) hipLaunchKernelGGL((conv_x3_pwc_kernel<2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_x3_pwc_kernel<4>), grid, dim3(256), 0, st, a);
+    if (a.Cin == 32 && a.Cout2 == 32) hipLaunchKernelGGL((conv_x3_pwc_kernel<1, 1>), grid, dim3(256), 0, st, a);
+    else if (a.Cin == 32) hipLaunchKernelGGL((conv_x3_pwc_kernel<1, 2>), grid, dim3(256), 0, st, a);
+    else if (a.Cin == 64 && a.Cout2 == 64) hipLaunchKernelGGL((conv_x3_pwc_kernel<2, 2>), grid, dim3(256), 0, st, a);
+    else if (a.Cin == 64) hipLaunchKernelGGL((conv_x3_pwc_kernel<2, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_x3_pwc_kernel<4, 4>), grid, dim3(256), 0, st, a);
 }
 }  // namespace issk

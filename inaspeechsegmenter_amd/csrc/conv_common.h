@@ -75,11 +75,11 @@ struct ConvArgs {
     const float* in2;
     int Cin2, H2, W2, sh2, sw2;
     // ---- second GEMM of a chained pair (conv_x3_pwc_kernel): q = act2(x' . W2^T + bias2), x' = this launch's own output
-    const uint16_t* wh2;     // [128][Cout] bf16 hi / lo parts of the next row's weights
+    const uint16_t* wh2;     // [Cout2][Cout] bf16 hi / lo parts of the next row's weights
     const uint16_t* wl2;
     const float* bias2;
     float* out2;
-    int act2;
+    int act2, Cout2;
 };
 
 // Host: magic constants of ConvArgs::dv_* for divisor d >= 1 (mul == 0 means d == 1).

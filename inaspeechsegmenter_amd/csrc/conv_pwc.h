@@ -25,24 +25,26 @@
 
 namespace issk {
 
-constexpr int PWC_C3 = 128;                          // output channels of the second GEMM (one 128-column block)
 #ifndef ISS_PWC_EXP                                  // timing-only experiment builds (wrong results), never set by the Makefile:
 #define ISS_PWC_EXP 0                                // 1 no MFMAs, 2 no stores, 4 no barriers, 8 no residual loads, 16 no weight loads
 #endif
 constexpr bool PWC_X_NOMFMA = ISS_PWC_EXP & 1, PWC_X_NOST = ISS_PWC_EXP & 2, PWC_X_NOBAR = ISS_PWC_EXP & 4, PWC_X_NORES = ISS_PWC_EXP & 8,
                PWC_X_NOW = ISS_PWC_EXP & 16;
 
-template <int K1T>                                   // C1 = 32 K1T input channels of the first GEMM
+template <int K1T, int NC3>                          // C1 = 32 K1T input channels of the first GEMM, C3 = 32 NC3 outputs of the second
 __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
     constexpr int C1 = 32 * K1T;
+    constexpr int C3 = 32 * NC3;
+    constexpr int NWR = NC3 >= 2 ? NC3 / 2 : 1;      // 16-byte pieces of a Wr-slice plane per thread (C3 rows x 4 pieces)
+    static_assert(NC3 == 1 || NC3 == 2 || NC3 == 4, "");
     constexpr int WLD = C1 + 8;                      // padded row of the We slice (bf16)
     constexpr int NWE = C1 >= 64 ? C1 / 64 : 1;      // 16-byte pieces of a We-slice plane per thread (32 rows x C1 / 8 pieces)
     __shared__ __attribute__((aligned(16))) uint16_t sRh[K1T][BM * XLD];
     __shared__ __attribute__((aligned(16))) uint16_t sRl[K1T][BM * XLD];
     __shared__ __attribute__((aligned(16))) uint16_t sWeh[32 * WLD];
     __shared__ __attribute__((aligned(16))) uint16_t sWel[32 * WLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sWrh[PWC_C3 * XLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sWrl[PWC_C3 * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sWrh[C3 * XLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sWrl[C3 * XLD];
     __shared__ __attribute__((aligned(16))) uint16_t sAh[BM * XLD];
     __shared__ __attribute__((aligned(16))) uint16_t sAl[BM * XLD];
     __shared__ __attribute__((aligned(16))) float sE[4 * 32 * PWS_ELD];
@@ -70,14 +72,15 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
     // a wait longer than necessary.  Register budget: everything that is in flight must stay in the 256 architectural VGPRs
     // (hipcc parks surplus values in AGPRs with a copy right behind the load, i.e. before the data has arrived;
     // tools/check_ring_regs.py looks for exactly that), so the r rows of the next tile are NOT requested ahead.
-    struct WSet { u32x4 weh[NWE], wel[NWE], wrh[2], wrl[2]; };
+    struct WSet { u32x4 weh[NWE], wel[NWE], wrh[NWR], wrl[NWR]; };
     struct XSet { f32x4 res[4]; f32x4 b1; };
     auto rows_left = [&](unsigned tt) { const long long m0 = (long long)tt * BM; return (int)(p.M - m0 < BM ? p.M - m0 : BM); };
-    unsigned weo[NWE], wro[2];                       // per-lane byte offsets of the weight pieces (the same for every step)
+    unsigned weo[NWE], wro[NWR];                     // per-lane byte offsets of the weight pieces (the same for every step)
+    const bool wr_on = br < C3;                      // (C3 = 32: the first 128 threads carry the Wr slice)
 #pragma unroll
     for (int i = 0; i < NWE; ++i) weo[i] = (unsigned)(wer * p.Kpad + ((C1 >= 64 || wes < C1 / 8) ? wes * 8 + 64 * i : 0)) * 2u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) wro[i] = (unsigned)((br + 64 * i) * C2 + bseg * 8) * 2u;
+    for (int i = 0; i < NWR; ++i) wro[i] = (unsigned)((wr_on ? br + 64 * i : 0) * C2 + bseg * 8) * 2u;
     const unsigned bo = (unsigned)ec * 4u;
     struct RowOff { unsigned x[4]; };                // per-lane byte offsets into a tile of x (residual / store layout)
     auto row_offsets = [&](unsigned tt) {
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < NWE; ++i) { W.weh[i] = W.wel[i] = u32x4{0, 0, 0, 0}; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { W.wrh[i] = W.wrl[i] = u32x4{0, 0, 0, 0}; }
+    for (int i = 0; i < NWR; ++i) { W.wrh[i] = W.wrl[i] = u32x4{0, 0, 0, 0}; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { X0.res[j] = X1.res[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     X0.b1 = X1.b1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -113,9 +116,8 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
         const uint16_t* rl_ = p.wl2 + 32 * (SW);                                                                     \
         if (!PWC_X_NOW) {                                                                                            \
         _Pragma("unroll") for (int i = 0; i < NWE; ++i) { ISS_PWS_LD(W.weh[i], weo[i], eh_); ISS_PWS_LD(W.wel[i], weo[i], el_); } \
-        ISS_PWS_LD(W.wrh[0], wro[0], rh_); ISS_PWS_LD(W.wrl[0], wro[0], rl_);                                        \
-        ISS_PWS_LD(W.wrh[1], wro[1], rh_); ISS_PWS_LD(W.wrl[1], wro[1], rl_);                                        \
-        issued += 2 * NWE + 4; } markW = issued;                                                                     \
+        _Pragma("unroll") for (int i = 0; i < NWR; ++i) { ISS_PWS_LD(W.wrh[i], wro[i], rh_); ISS_PWS_LD(W.wrl[i], wro[i], rl_); } \
+        issued += 2 * NWE + 2 * NWR; } markW = issued;                                                                     \
     }
 #define ISS_PWC_GATHER_X(X)                       /* residual block and bias of the cursor's step; the cursor advances */ \
     {                                                                                                                \
@@ -161,10 +163,10 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
             }
     };
 
-    floatx16 acc2[4];
-    f32x4 bias2[4];                                  // second GEMM's bias in the store layout: the same for every tile
+    floatx16 acc2[NC3];
+    f32x4 bias2[NC3];                                // second GEMM's bias in the store layout: the same for every tile
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC3; ++c) {
         bias2[c] = *reinterpret_cast<const f32x4*>(p.bias2 + 32 * c + ec);
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc2[c][i] = 0.f;
@@ -244,27 +246,28 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sAh[aoff + ks * 16]);
             const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sAl[aoff + ks * 16]);
 #pragma unroll
-            for (int c0 = 0; c0 < 4; c0 += 2) {
-                bf16x8 bh[2], bl[2];
+            for (int c0 = 0; c0 < NC3; c0 += 2) {
+                constexpr int NB = NC3 >= 2 ? 2 : 1;
+                bf16x8 bh[NB], bl[NB];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                for (int c = 0; c < NB; ++c) {
                     bh[c] = *reinterpret_cast<const bf16x8*>(&sWrh[boff_s + (c0 + c) * 32 * XLD + ks * 16]);
                     bl[c] = *reinterpret_cast<const bf16x8*>(&sWrl[boff_s + (c0 + c) * 32 * XLD + ks * 16]);
                 }
-                if (PWC_X_NOMFMA) { acc2[c0][0] += (float)bh[0][0] + (float)al[0]; acc2[c0 + 1][0] += (float)bl[1][0] + (float)ah[0] + (float)bh[1][0] + (float)bl[0][0]; continue; }
+                if (PWC_X_NOMFMA) { acc2[c0][0] += (float)bh[0][0] + (float)al[0] + (float)bl[0][0] + (float)ah[0]; continue; }
 #pragma unroll
-                for (int c = 0; c < 2; ++c) acc2[c0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[c], al, acc2[c0 + c], 0, 0, 0);
+                for (int c = 0; c < NB; ++c) acc2[c0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[c], al, acc2[c0 + c], 0, 0, 0);
 #pragma unroll
-                for (int c = 0; c < 2; ++c) acc2[c0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[c], ah, acc2[c0 + c], 0, 0, 0);
+                for (int c = 0; c < NB; ++c) acc2[c0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[c], ah, acc2[c0 + c], 0, 0, 0);
 #pragma unroll
-                for (int c = 0; c < 2; ++c) acc2[c0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[c], ah, acc2[c0 + c], 0, 0, 0);
+                for (int c = 0; c < NB; ++c) acc2[c0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[c], ah, acc2[c0 + c], 0, 0, 0);
             }
         }
         if (++sc == nsteps) {                        // tile complete: second epilogue (bias, activation), 32 channels at a time
-            float* const qo = p.out2 + (size_t)t * BM * PWC_C3;
+            float* const qo = p.out2 + (size_t)t * BM * C3;
             const int left = full ? BM : rows_left(t);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NC3; ++c) {
                 const f32x4 bias = bias2[c];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -278,14 +281,14 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(&E[(8 * j + er) * PWS_ELD + ec]);
                     v = v + bias;
                     if (p.act2 == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                    float* const dst = qo + (size_t)row * PWC_C3 + 32 * c + ec;
+                    float* const dst = qo + (size_t)row * C3 + 32 * c + ec;
                     if (full) *reinterpret_cast<f32x4*>(dst) = v;
                     else if (row < left) *reinterpret_cast<f32x4*>(dst) = v;
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc2[c][i] = 0.f;
             }
-            if (full) issued += 16;
+            if (full) issued += 4 * NC3;
             sc = 0;
             t += gridDim.x;
             if (t >= ntiles) done = true;
@@ -304,8 +307,8 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
         __builtin_amdgcn_s_waitcnt(0xc07f);          /* lgkmcnt(0): this wave's LDS reads of the previous step */     \
         if (!PWC_X_NOBAR) __builtin_amdgcn_s_barrier();                /* every wave is done with the previous weight slices (tile start: sR complete) */ \
         pws_wait_outstanding(issued - markW);        /* this step's weight slices -- and its residual block, which is older */ \
-        asm volatile("" : "+v"(W.wrh[0]), "+v"(W.wrl[0]), "+v"(W.wrh[1]), "+v"(W.wrl[1]), "+v"(X.res[0]), "+v"(X.res[1]),   \
-                          "+v"(X.res[2]), "+v"(X.res[3]), "+v"(X.b1));                                               \
+        asm volatile("" : "+v"(X.res[0]), "+v"(X.res[1]), "+v"(X.res[2]), "+v"(X.res[3]), "+v"(X.b1));               \
+        _Pragma("unroll") for (int i = 0; i < NWR; ++i) asm volatile("" : "+v"(W.wrh[i]), "+v"(W.wrl[i]));           \
         _Pragma("unroll") for (int i = 0; i < NWE; ++i) {                                                            \
             asm volatile("" : "+v"(W.weh[i]), "+v"(W.wel[i]));                                                       \
             if (C1 >= 64 || wes < C1 / 8) {                                                                          \
@@ -313,9 +316,11 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
                 *reinterpret_cast<u32x4*>(&sWel[wer * WLD + wes * 8 + 64 * i]) = W.wel[i];                           \
             }                                                                                                        \
         }                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                              \
-            *reinterpret_cast<u32x4*>(&sWrh[(br + 64 * i) * XLD + bseg * 8]) = W.wrh[i];                             \
-            *reinterpret_cast<u32x4*>(&sWrl[(br + 64 * i) * XLD + bseg * 8]) = W.wrl[i];                             \
+        _Pragma("unroll") for (int i = 0; i < NWR; ++i) {                                                            \
+            if (wr_on) {                                                                                             \
+                *reinterpret_cast<u32x4*>(&sWrh[(br + 64 * i) * XLD + bseg * 8]) = W.wrh[i];                         \
+                *reinterpret_cast<u32x4*>(&sWrl[(br + 64 * i) * XLD + bseg * 8]) = W.wrl[i];                         \
+            }                                                                                                        \
         }                                                                                                            \
         __builtin_amdgcn_s_waitcnt(0xc07f);                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -337,9 +342,13 @@ __global__ __launch_bounds__(256, 1) void conv_x3_pwc_kernel(const ConvArgs p) {
 
 // host: rows j (expansion, in place, relu, residual) and j + 1 (reduction to 128 channels) of an op program as one launch.
 // a: ConvArgs of row j with wh2 / wl2 / bias2 / out2 / act2 of row j + 1.
+// (C1, C3) pairs the kernel is instantiated for: ResNet-101's stages 1-3 and the transitions between them (cnn_pwc.hip)
+inline bool pwc_compiled(int c1, int c3) {
+    return (c1 == 32 && (c3 == 32 || c3 == 64)) || (c1 == 64 && (c3 == 64 || c3 == 128)) || (c1 == 128 && c3 == 128);
+}
 inline bool pwc_supported(const ConvArgs& a) {
     return a.bias && a.bias2 && a.res && a.res == a.out && !a.ps && a.act == 1 && a.act2 <= 1 && a.pp == 1 && a.Kpad == a.Cin &&
-           (a.Cin == 64 || a.Cin == 128) && a.Cout % 32 == 0 && a.Cout >= 128 && a.Cout <= 2048 &&
+           pwc_compiled(a.Cin, a.Cout2) && a.Cout % 32 == 0 && a.Cout >= 128 && a.Cout <= 2048 &&
            a.M * (long long)a.Cout < (1ll << 40);
 }
 void iss_pwc_launch(const ConvArgs& a, hipStream_t st);

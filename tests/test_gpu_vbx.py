@@ -127,9 +127,9 @@ def test_projection_shortcut_and_expansion_as_one_gemm(ctx, extractor):
 
 def test_expansion_and_next_reduction_as_one_chained_launch(ctx, extractor):
     """conv_x3_pwc_kernel: the in-place 1x1 expansion of an identity Bottleneck (+ residual, relu) and the next Bottleneck's 1x1
-    reduction to 128 channels in one launch -- the reduction reads x' out of LDS instead of HBM.  Same x-vectors as the two
-    launches (1e-5 of the embedding scale: the first GEMM sums its k-steps in two accumulators), on full and tail windows and on
-    a window count that leaves a partial last row tile; 21 + 1 such launches per pass (stage 3, and the stage 2 -> 3 transition)."""
+    reduction (to 32 / 64 / 128 channels) in one launch -- the reduction reads x' out of LDS instead of HBM.  Same x-vectors as the
+    two launches (1e-5 of the embedding scale: the first GEMM sums its k-steps in two accumulators), on full and tail windows and
+    on a window count that leaves a partial last row tile; 26 such launches per pass (stages 1-3 and the transitions between them)."""
     rng = np.random.default_rng(10)
     for frames, nwin in ((144, 5), (65, 3), (144, 1)):
         fea = rng.normal(0, 1, (frames + 24 * nwin, 64)).astype(np.float32)
@@ -146,7 +146,9 @@ def test_expansion_and_next_reduction_as_one_chained_launch(ctx, extractor):
         finally:
             ctx.set_diag(0)
             ctx.prof_enable(False)
-        assert inst.get('conv_x3_pwc_kernel<4>') == 21 and inst.get('conv_x3_pwc_kernel<2>') == 1, inst
+        want = {'conv_x3_pwc_kernel<4,4>': 21, 'conv_x3_pwc_kernel<2,4>': 1, 'conv_x3_pwc_kernel<2,2>': 2,
+                'conv_x3_pwc_kernel<1,2>': 1, 'conv_x3_pwc_kernel<1,1>': 1}       # <C1 / 32, C3 / 32>: stages 3, 2 -> 3, 2, 1 -> 2, 1
+        assert {k: v for k, v in inst.items() if 'pwc' in k} == want, inst
         assert not [k for k in inst_off if 'pwc' in k], inst_off
         scale = np.abs(b).max()
         assert np.abs(a - b).max() <= 1e-5 * scale, (frames, nwin, np.abs(a - b).max(), scale)
