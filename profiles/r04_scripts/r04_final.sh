@@ -19,3 +19,4 @@ for k in r["kernels"]: print("   ", k["kernel"], round(k["ms_per_step"],2), k["l
 print("cpu", j["cpu_baseline"]["x_realtime"], "parity", {k: v for k, v in j["parity_check"].items() if k not in ("what", "classes_present")})
 for k, v in j.get("companions", {}).items(): print("companion", k, v.get("value"), v.get("ms_per_step"), v.get("x_realtime"))
 PY
+timeout 300 python tools/layer_prof.py --minutes 20 --reps 3 > $OUT/r04_vbx_layer_times.md 2> $OUT/layer_prof.err; tail -2 $OUT/r04_vbx_layer_times.md

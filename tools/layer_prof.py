@@ -42,35 +42,43 @@ def main():
     print("| row | kh kw s | Cin | Cout | Ho x Wo | res | launches | us / 512 win | alg TFLOP/s | act GB/s | bound us (6 TB/s / 833 TF) | x bound |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
     agg = {}
-    carry = None
     tot = tb = 0.0
+    rows = []                                        # one entry per conv row: shape, time, algorithmic flops / activation bytes
     for i, r in enumerate(prog):
         if r[N.C_OP] != N.OP_CONV:
             continue
         ms, nl = ctx.prof_get_row(i)
         h, w, cin, ho, wo, cout, kh, kw, sh = [int(r[c]) for c in (N.C_H, N.C_W, N.C_CIN, N.C_HO, N.C_WO, N.C_COUT, N.C_KH, N.C_KW, N.C_SH)]
         res = r[N.C_RES] >= 0
-        fl = 2.0 * ho * wo * cout * kh * kw * cin * 512
-        by = 4.0 * (h * w * cin + ho * wo * cout * (2 if res else 1)) * 512
-        if nl == 0 and i + 1 < len(prog) and prog[i + 1][N.C_DUALW] > 0:      # projection shortcut computed inside the next row's two-source GEMM
-            carry = (fl, 4.0 * ho * wo * cin * 512)                            # its flops; the (strided) pixels it reads
-            print(f"| {i} | {kh} {kw} {sh} | {cin} | {cout} | {ho}x{wo} | 0 | 0 | (one GEMM with row {i + 1}) | | | | |")
+        rows.append(dict(i=i, kh=kh, kw=kw, sh=sh, cin=cin, cout=cout, ho=ho, wo=wo, res=int(res), nl=nl, us=ms * 1e3 * 512 / bw,
+                         fl=2.0 * ho * wo * cout * kh * kw * cin * 512, rd=4.0 * h * w * cin * 512, rr=4.0 * ho * wo * cout * 512 * int(res),
+                         wr=4.0 * ho * wo * cout * 512, dual=r[N.C_DUALW] > 0, note=''))
+    for k, e in enumerate(rows):                     # launches that compute two rows: account them together
+        if e['nl'] == 0 and k + 1 < len(rows) and rows[k + 1]['dual'] and rows[k + 1]['nl']:
+            t = rows[k + 1]                          # projection shortcut inside the next row's two-source GEMM: its output never exists
+            t['fl'] += e['fl']; t['rd'] += 4.0 * e['ho'] * e['wo'] * e['cin'] * 512; t['rr'] = 0.0
+            e['note'] = f"(one GEMM with row {t['i']})"; t['note'] = 'two-source'
+        elif e['nl'] == 0 and k > 0 and rows[k - 1]['nl'] and e['kh'] == 1 and e['cin'] == rows[k - 1]['cout']:
+            t = rows[k - 1]                          # reduction chained behind the previous row's expansion: x' is not read back
+            t['fl'] += e['fl']; t['wr'] += e['wr']
+            e['note'] = f"(chained launch with row {t['i']})"; t['note'] = 'chained'
+    for e in rows:
+        if e['nl'] == 0:
+            print(f"| {e['i']} | {e['kh']} {e['kw']} {e['sh']} | {e['cin']} | {e['cout']} | {e['ho']}x{e['wo']} | {e['res']} | 0 | {e['note']} | | | | |")
             continue
-        if r[N.C_DUALW] > 0 and carry is not None:
-            fl += carry[0]
-            by = 4.0 * (h * w * cin + ho * wo * cout) * 512 + carry[1]                # two inputs, one output, no residual read
-            carry = None
-        us = ms * 1e3 * 512 / bw
-        bound = max(by / 6e12, fl / 833e12) * 1e6
-        print(f"| {i} | {kh} {kw} {sh} | {cin} | {cout} | {ho}x{wo} | {int(res)} | {nl} | {us:.1f} | {fl / max(us, 1e-9) / 1e6:.1f} | {by / max(us, 1e-9) / 1e3:.0f} | {bound:.1f} | {us / bound:.2f} |")
-        k = (kh, kw, sh, cin, cout, ho, wo, int(res))
+        by = e['rd'] + e['rr'] + e['wr']
+        bound = max(by / 6e12, e['fl'] / 833e12) * 1e6
+        us = e['us']
+        print(f"| {e['i']} | {e['kh']} {e['kw']} {e['sh']} | {e['cin']} | {e['cout']} | {e['ho']}x{e['wo']} | {e['res']} | {e['nl']} | {us:.1f} {e['note']} | "
+              f"{e['fl'] / max(us, 1e-9) / 1e6:.1f} | {by / max(us, 1e-9) / 1e3:.0f} | {bound:.1f} | {us / bound:.2f} |")
+        k = (e['kh'], e['kw'], e['sh'], e['cin'], e['cout'], e['ho'], e['wo'], e['res'], e['note'])
         a = agg.setdefault(k, [0, 0.0, 0.0, 0.0, 0.0])
-        a[0] += 1; a[1] += us; a[2] += fl; a[3] += by; a[4] += bound
+        a[0] += 1; a[1] += us; a[2] += e['fl']; a[3] += by; a[4] += bound
     print("\n## grouped by shape\n")
     print("| kh kw s Cin Cout HoxWo res | n | total us | alg TFLOP/s | act GB/s | bound us | x bound |")
     print("|---|---|---|---|---|---|---|")
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print(f"| {k[0]} {k[1]} {k[2]} {k[3]} {k[4]} {k[5]}x{k[6]} {k[7]} | {a[0]} | {a[1]:.0f} | {a[2] / a[1] / 1e6:.1f} | {a[3] / a[1] / 1e3:.0f} | {a[4]:.0f} | {a[1] / a[4]:.2f} |")
+        print(f"| {k[0]} {k[1]} {k[2]} {k[3]} {k[4]} {k[5]}x{k[6]} {k[7]} {k[8]} | {a[0]} | {a[1]:.0f} | {a[2] / a[1] / 1e6:.1f} | {a[3] / a[1] / 1e3:.0f} | {a[4]:.0f} | {a[1] / a[4]:.2f} |")
         tot += a[1]; tb += a[4]
     print(f"\nconv total {tot:.0f} us per 512 windows; roofline bound (max of 6 TB/s activations, 833 TFLOP/s algorithmic) {tb:.0f} us")
 
