@@ -701,6 +701,13 @@ def test_asm_load_kernels_keep_their_ring_registers(tmp_path):
                        capture_output=True, text=True)
     assert c.returncode == 0, c.stdout
     assert c.stdout.count("ok ") >= 7, c.stdout
+    # the chained kernel (conv_pwc.h): its r-row registers are ring registers only across a tile boundary, so the per-load rule
+    # applies -- the first instruction touching every load's destination is a consumer behind a wait (no AGPR parking)
+    r = subprocess.run(['bash', os.path.join(root, 'tools', 'kernel_meta.sh'), 'cnn_pwc.hip', 'pwc'], capture_output=True, text=True)
+    assert r.returncode == 0 and all('spill v0 s0' in l for l in r.stdout.strip().splitlines()), r.stdout + r.stderr
+    c = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_ring_regs.py'), '/tmp/iss_meta/cnn_pwc.s', 'pwc'],
+                       capture_output=True, text=True)
+    assert c.returncode == 0 and c.stdout.count("ok ") == 5 and "BEFORE A WAIT" not in c.stdout, c.stdout
 
 
 def test_bench_cpu_file_parallel_leg_runs_without_a_gpu():
