@@ -1058,6 +1058,11 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                R2[ISS_C_OUT] != R1[ISS_C_IN] && R2[ISS_C_ACT] <= 1 && R2[ISS_C_CIN] == R1[ISS_C_COUT] && issk::pwc_compiled(R1[ISS_C_CIN], R2[ISS_C_COUT]) &&
                R2[ISS_C_H] == R1[ISS_C_HO] && R2[ISS_C_W] == R1[ISS_C_WO] && n.kpad[r] == R1[ISS_C_CIN] && n.kpad[r + 1] == R2[ISS_C_CIN];
     };
+#ifdef ISS_PW_NO_ASM_RING                            // build-time escape (Makefile): none of the asm-load kernels of conv_pw.h / conv_pwc.h
+    constexpr bool asm_ring_ok = false;
+#else
+    constexpr bool asm_ring_ok = true;
+#endif
     constexpr int kDualDeclined = -12345;                        // conv_row(r, -1, r - 1): the two-source launch is not possible for this call
     std::function<int(int, int, int, int)> conv_row = [&](int r, int pend, int dual, int chain) -> int {
         const int32_t* R = &n.prog[(size_t)r * ISS_PROG_COLS];
@@ -1416,8 +1421,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         const int op = R[ISS_C_OP];
         if (op == ISS_OP_CONV) {
             if (pending < 0 && can_defer(r)) { pending = r; *result = out; continue; }
-            // identity-residual expansion followed by the next block's reduction to 128 channels: one chained launch (conv_pwc.h)
-            if (pending < 0 && x3mode && chain_pair(r) &&
+            // identity-residual expansion followed by the next block's reduction: one chained launch (conv_pwc.h)
+            if (asm_ring_ok && pending < 0 && x3mode && chain_pair(r) &&
                 !(c->diag & (ISS_DIAG_NO_CHAIN | ISS_DIAG_NO_PW | ISS_DIAG_NO_PWS | ISS_DIAG_NO_PWS2))) {
                 const int rc2 = conv_row(r, -1, -1, r + 1);
                 if (rc2 == ISS_OK) {
@@ -1430,7 +1435,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             }
             // projection shortcut followed by its expansion (ISS_C_DUALW on the next row): one two-source launch when the split-bf16
             // streaming kernels are in use (the diagnostic switches that move 1x1 layers elsewhere keep their meaning)
-            if (pending < 0 && x3mode && r + 1 < n.nrows && n.prog[(size_t)(r + 1) * ISS_PROG_COLS + ISS_C_DUALW] > 0 &&
+            if (asm_ring_ok && pending < 0 && x3mode && r + 1 < n.nrows && n.prog[(size_t)(r + 1) * ISS_PROG_COLS + ISS_C_DUALW] > 0 &&
                 !(c->diag & (ISS_DIAG_NO_DUAL | ISS_DIAG_NO_PW | ISS_DIAG_NO_PWS | ISS_DIAG_NO_PWS2))) {
                 const int rc2 = conv_row(r + 1, -1, r, -1);
                 if (rc2 == ISS_OK) {
