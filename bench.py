@@ -398,22 +398,56 @@ def make_files(indices, minutes, dev, root):
     return paths, n
 
 
-def make_comm(ctx, rank, world, dev):
-    """The exchange step of an N > 1 run: the C-ABI's ncclAllGather (RcclComm on `ctx`); if its rendezvous cannot be set up
-    (symmetric failures only: librccl missing, no launcher store) every rank falls back to a torch.distributed process
-    group on the same RCCL, and the line says so.  -> (comm, description)"""
+def make_comm(ctx, rank, world, dev, kind='rccl'):
+    """The exchange step of an N > 1 run.  -> (comm, description).  `kind` is what the command line asked for -- there is no
+    silent fallback from one backend to another (north_star: no dual backend):
+      rccl   the C-ABI's ncclAllGather (RcclComm on `ctx`, librccl dlopen'ed): the only data path of a multi-GPU run; a rendezvous
+             that cannot be set up is an error on every rank;
+      torch  a torch.distributed "nccl" process group on the same RCCL (callers that already run one; asked for explicitly);
+      gloo   a torch.distributed "gloo" group over host memory: the single-GPU REHEARSAL of the N-rank path (RCCL refuses two
+             ranks on one device) and the CPU tests -- never a multi-GPU result, and the line says so."""
     if world == 1:
         return None, None
     from inaspeechsegmenter_amd import sharding
-    try:
-        return (sharding.rccl_rendezvous(ctx, rank, world),
-                "iss_allgather_segments: ncclAllGather of int32 segment tables through the C-ABI (librccl dlopen'ed, no torch in the data path)")
-    except Exception as exc:                                # noqa: BLE001
-        import torch.distributed as dist
-        print(f'[bench] rank {rank}: C-ABI RCCL rendezvous failed ({exc}); falling back to torch.distributed', file=sys.stderr)
+    if kind == 'rccl':
+        try:
+            comm = sharding.rccl_rendezvous(ctx, rank, world)
+        except Exception as exc:                            # noqa: BLE001
+            raise SystemExit(f"[bench] rank {rank}: the C-ABI RCCL rendezvous failed ({exc}); no fallback is taken -- "
+                             "run with --comm torch (torch.distributed on the same RCCL) or --comm gloo (single-GPU rehearsal) "
+                             "if that is what you want") from exc
+        return comm, ("iss_allgather_segments: ncclAllGather of int32 segment tables through the C-ABI (librccl dlopen'ed, no torch "
+                      "in the data path)")
+    import torch.distributed as dist
+    if kind == 'torch':
         if not dist.is_initialized():
             dist.init_process_group('nccl', device_id=dev)
-        return sharding.TorchComm(device=dev), f"torch.distributed nccl all_gather_into_tensor (C-ABI rendezvous failed: {exc})"
+        return sharding.TorchComm(device=dev), "torch.distributed nccl all_gather_into_tensor (--comm torch)"
+    if kind == 'gloo':
+        if not dist.is_initialized():
+            dist.init_process_group('gloo')
+        return sharding.TorchComm(device=None), ("torch.distributed gloo all_gather_into_tensor over host memory (--comm gloo: "
+                                                 "rehearsal of the N-rank path, NOT an RCCL / xGMI exchange)")
+    raise SystemExit(f"--comm {kind}: unknown")
+
+
+def self_spawn(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver's own command line does
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`), and
+    hand back the launcher's exit status.  Rank 0 of the child job prints the JSON line on our stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on these hosts (RCCL across processes)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] --gpus {n} without a launcher: spawning {' '.join(cmd)}", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
 
 
 def bench_files(args, torch, dev, local_rank, rank, world, kind, seg=None, comm=None, comm_kind=None, steps=None, warmup=None,
@@ -430,7 +464,7 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind, seg=None, comm=
     x3 = args.precision == 'bf16x3'
     seg.ctx.set_precision(_native.PREC_BF16X3 if x3 else _native.PREC_F32)
     if comm is None and world > 1:
-        comm, comm_kind = make_comm(seg.ctx, rank, world, dev)
+        comm, comm_kind = make_comm(seg.ctx, rank, world, dev, args.comm)
     minutes = args.file_minutes or (5.0 if kind == 'batch' else 3.0)
     per_gpu = per_gpu or args.files_per_gpu or 128
     nfiles = per_gpu * world
@@ -501,9 +535,9 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind, seg=None, comm=
         mem_trace.append(host_mem())
     seg.ctx.synchronize()
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0                  # this rank's own steps, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
-    dt_local = dt
     pipe = [{k: (round(v * 1e3 / steps, 1) if k not in ('batches', 'files') else v / steps) for k, v in w.stats.items()}
             for w in seg.__dict__.get('_pipeline_workers', [])]
     if comm:
@@ -699,6 +733,63 @@ def bench_vbx(args, torch, dev, local_rank, rank, world, steps=None, warmup=None
     return line
 
 
+def make_step(segment, rank, comm):
+    """One step of the segmenter workload on this rank: `segment(dense)` -> slot-unit segments of the rank's recording, packed as
+    int32 rows and (N > 1) all-gathered so that every rank holds every rank's table."""
+    from inaspeechsegmenter_amd.sharding import pack_segments
+
+    def step(dense=True):
+        lseg = segment(dense)
+        rows = pack_segments(rank, lseg)
+        if comm:
+            rows = comm.allgather(rows, 8192)
+        return lseg, rows
+    return step
+
+
+def timed_steps(step, k, comm, sync):
+    """The contract's timed region: barrier + device sync, EXACTLY k steps, device sync + barrier; the job's time is the MAX over the
+    ranks.  -> (seconds for the job, the last step's output, this rank's own seconds)."""
+    if comm:
+        comm.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        out = step()
+    sync()
+    dt_own = time.perf_counter() - t0                    # this rank's k steps, before it waits for the others
+    if comm:
+        comm.barrier()
+    dt = time.perf_counter() - t0
+    dt = comm.max_over_ranks(dt) if comm else dt
+    return dt, out, dt_own
+
+
+def main_fake_device(args, rank, world):
+    """Tests only (`--fake-device module:factory`): the launcher / rank / communicator / timing / line-assembly code of an N-rank
+    run with the Segmenter replaced by `factory(rank)` (an object with segment_device_pcm(ptr, n, dense=...)), so that the N > 1
+    branch of this file executes on a machine without a GPU.  The line it prints is labelled a self-test and carries no metric."""
+    import importlib
+    mod, fn = args.fake_device.split(':')
+    fake = getattr(importlib.import_module(mod), fn)(rank)
+    comm, comm_kind = make_comm(None, rank, world, None, args.comm)
+    n = int(args.minutes * 60 * FS)
+    step = make_step(lambda dense: fake.segment_device_pcm(0, n, dense=dense), rank, comm)
+    for _ in range(args.warmup):
+        step()
+    dt, (lseg, rows), dt_local = timed_steps(step, args.steps, comm, lambda: None)
+    dt_min = -comm.max_over_ranks(-dt_local) if comm else dt_local
+    if comm:
+        comm.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "SELF-TEST of bench.py's N-rank path on a fake device (no audio was segmented)", "value": None,
+                          "unit": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "data": "fake-device", "scaling": "weak",
+                          "config": {"parallelism": f"x{world}: {comm_kind}", "rows_gathered": int(len(rows)),
+                                     "files_seen": sorted({int(r[0]) for r in rows})},
+                          "ranks": {"ms_per_step_min": dt_min / args.steps * 1e3, "ms_per_step_max": dt / args.steps * 1e3}}))
+
+
 def main():
     if len(sys.argv) == 4 and sys.argv[1] == '--cpu-worker':          # one process of cpu_file_parallel_leg: numpy only, no torch
         print(_cpu_feature_worker((int(sys.argv[2]), int(sys.argv[3]))))
@@ -725,21 +816,40 @@ def main():
     ap.add_argument('--workspace-mb', type=int, default=0, help='activation workspace cap (0 = library default)')
     ap.add_argument('--precision', choices=['bf16x3', 'f32'], default='bf16x3',
                     help='conv/dense GEMM arithmetic: split-bf16 MFMA (default) or exact-f32 MFMA')
+    ap.add_argument('--comm', choices=['rccl', 'torch', 'gloo'], default='rccl',
+                    help="N > 1 exchange step: rccl = iss_allgather_segments (ncclAllGather through the C-ABI; the default and the only "
+                         "multi-GPU data path -- a failed rendezvous is an error, there is no fallback); torch = a torch.distributed nccl "
+                         "group, asked for explicitly; gloo = host-memory group, which also lets the N ranks SHARE the visible GPUs "
+                         "(single-GPU rehearsal of the N-rank code path; the line is labelled, it is not a scaling result)")
+    ap.add_argument('--fake-device', default='', help=argparse.SUPPRESS)      # tests only: 'module:factory' replacing the Segmenter
     args = ap.parse_args()
 
-    import torch
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:             # no launcher: become one (the driver's own command line)
+        raise SystemExit(self_spawn(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if args.fake_device:
+        return main_fake_device(args, rank, world)
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    shared = None
+    if local_rank >= ndev:
+        if args.comm != 'gloo':
+            raise SystemExit(f"--gpus {args.gpus}: local rank {local_rank} has no device of its own ({ndev} visible) and RCCL refuses two "
+                             "ranks on one device; --comm gloo rehearses the N-rank path on the visible device(s)")
+    if args.comm == 'gloo' and world > ndev:
+        shared = f"{world} ranks on {ndev} visible device(s): rank r runs on device r % {ndev}"
+        local_rank = local_rank % ndev                               # from here on: the device index of this rank
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    args.shared_devices = shared
     if args.workload in ('batch', 'archive'):
         if args.workload == 'batch' and world > 1:
             raise SystemExit("--workload batch is the single-GPU configs[2]; use --workload archive for N > 1")
@@ -754,45 +864,29 @@ def main():
         return
 
     from inaspeechsegmenter_amd import Segmenter, _native
-    from inaspeechsegmenter_amd.sharding import pack_segments
 
     seg = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models='synthetic', device=local_rank)
     x3 = args.precision == 'bf16x3'
     seg.ctx.set_precision(_native.PREC_BF16X3 if x3 else _native.PREC_F32)
     if args.workspace_mb:
         seg.ctx.set_workspace_limit(args.workspace_mb << 20)
-    comm, comm_kind = make_comm(seg.ctx, rank, world, dev)
+    comm, comm_kind = make_comm(seg.ctx, rank, world, dev, args.comm)
     n = int(args.minutes * 60 * FS)
     pcm = synth_recording(rank, n, dev)
     torch.cuda.synchronize()
     hours = n / FS / 3600.0
 
-    def step(dense=True):
-        lseg = seg.segment_device_pcm(pcm.data_ptr(), n, dense=dense)
-        rows = pack_segments(rank, lseg)
-        if comm:
-            rows = comm.allgather(rows, 8192)
-        return lseg, rows
+    step = make_step(lambda dense: seg.segment_device_pcm(pcm.data_ptr(), n, dense=dense), rank, comm)
+
+    def sync():
+        seg.ctx.synchronize()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
 
     def timed(k, dense):
-        if comm:
-            comm.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            out = step(dense)
-        seg.ctx.synchronize()
-        torch.cuda.synchronize()
-        if comm:
-            comm.barrier()
-        dt = time.perf_counter() - t0
-        dt_local = dt
-        if comm:
-            dt = comm.max_over_ranks(dt)
-        return dt, out, dt_local
+        return timed_steps(lambda: step(dense), k, comm, sync)
 
     dt, (lseg, rows), dt_local = timed(args.steps, True)
     value = world * args.steps * hours / dt
@@ -924,6 +1018,11 @@ def main():
         }
         if rccl is not None:
             line["rccl"] = rccl
+        if args.comm == 'gloo' and world > 1:
+            line["rehearsal"] = {"comm": "gloo", "shared_devices": args.shared_devices,
+                                 "what": "the N-rank code path of this file (launcher, ranks, barriers, max-over-ranks timing, one all-gather "
+                                         "of the segment tables per step, archive companion at N) executed with a host-memory exchange; when "
+                                         "shared_devices is set the ranks time-share the GPU(s), so `value` is NOT a scaling figure"}
         if f32c is not None:
             line["precision_f32"] = f32c
         if cpu is not None:

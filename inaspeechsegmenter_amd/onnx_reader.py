@@ -8,10 +8,10 @@ message and only a handful of fields matter here, so this module walks the wire 
     TensorProto: dims (1), data_type (2), float_data (4), int64_data (7), name (8), raw_data (9), double_data (10)
 
 `load_resnet101_params(path)` returns a dict keyed like resnet.py's state_dict ('conv1.weight', 'layer3.7.bn2.running_var',
-'embedding.weight', ...) -- what `keras_model.compile_resnet101` lowers.  A torch -> ONNX export lists its Conv nodes in
-execution order (resnet.py:48-75,105-135: conv1; per Bottleneck conv1, conv2, conv3, then the shortcut projection), so the
-initializer NAMES are not relied on (constant folding renames them to `onnx::Conv_123`): the n-th Conv node is the n-th
-convolution of the topology, checked against the expected (out, in, kh, kw).  Two export styles are understood:
+'embedding.weight', ...) -- what `keras_model.compile_resnet101` lowers.  Initializer NAMES are not relied on (constant folding
+renames them to `onnx::Conv_123`) and neither is the node ORDER (conv3 and the shortcut projection of a stage's first block
+have the same weight shape): the Conv nodes are assigned to resnet.py:48-75,105-135's convolutions by walking the graph
+(`_order_convs_by_connectivity`), then checked against the expected (out, in, kh, kw), strides, pads and group.  Two export styles are understood:
 BatchNormalization nodes kept (their four tensors become bnX.weight / bias / running_mean / running_var) or folded into the
 convolutions (Conv carries a bias: returned as '<conv>.bias' with no bn entries; compile_resnet101 then uses it as is)."""
 import struct
@@ -178,6 +178,94 @@ def resnet101_conv_names(m_channels=32, num_blocks=(3, 4, 23, 3)):
     return out
 
 
+_PASS_THROUGH = ('BatchNormalization', 'Relu', 'Identity', 'Cast')
+
+
+def _order_convs_by_connectivity(path, nodes, convs, produced, consumers):
+    """The Conv nodes in the order of `resnet101_conv_names()`, found by walking the GRAPH, not by trusting the node order: in
+    the first block of a stage conv3 and the shortcut projection have the same weight shape (layer1.0: both (128, 32, 1, 1)), so
+    an exporter / simplifier that lists them the other way round would swap them silently if only order + shape were used.
+    Rules (resnet.py:60-75): a Bottleneck's conv1 and its shortcut projection read the SAME tensor (the block input); conv1 is
+    the one whose output reaches another Conv (conv2) through BatchNormalization / Relu, the shortcut's reaches the Add; conv2
+    reads conv1's output, conv3 conv2's; the Add both branches meet in produces the next block's input."""
+    def source(t):                                    # the Conv / Add / graph input a tensor comes from (through BN / Relu / ...)
+        seen = 0
+        while True:
+            n = produced.get(t)
+            if n is None or n['op_type'] not in _PASS_THROUGH or not n['input']:
+                return id(n) if n is not None else None
+            t = n['input'][0]
+            seen += 1
+            if seen > 64:
+                raise ValueError(f'{path}: pass-through chain too long behind {t!r}')
+
+    by_source = {}
+    for c in convs:
+        by_source.setdefault(source(c['input'][0]), []).append(c)
+
+    def next_join(c):                                 # the Add a conv's output reaches through BN / Relu (or None)
+        t = c['output'][0]
+        for _ in range(64):
+            cs = consumers.get(t, [])
+            adds = [n for n in cs if n['op_type'] == 'Add']
+            if adds:
+                return adds[0]
+            nxt = [n for n in cs if n['op_type'] in _PASS_THROUGH]
+            if not nxt:
+                return None
+            t = nxt[0]['output'][0]
+        return None
+
+    stem = by_source.get(None, [])
+    if len(stem) != 1:
+        raise ValueError(f'{path}: {len(stem)} Conv nodes read the graph input, expected the one 3x3 stem convolution')
+    ordered = [stem[0]]
+    x = id(stem[0])                                   # what the next block's convolutions must come from
+    nblocks = sum((3, 4, 23, 3))
+    for b in range(nblocks):
+        heads = by_source.get(x, [])
+        c1 = [c for c in heads if by_source.get(id(c))]              # its output feeds another Conv: conv1
+        sc = [c for c in heads if not by_source.get(id(c))]          # ... feeds the Add: the shortcut projection
+        if len(c1) != 1 or len(sc) > 1:
+            raise ValueError(f'{path}: block {b}: {len(heads)} Conv nodes read the block input ({len(c1)} feeding a Conv); '
+                             'this is not the Bottleneck of resnet.py')
+        c2 = by_source[id(c1[0])]
+        c3 = by_source.get(id(c2[0]), []) if len(c2) == 1 else []
+        if len(c2) != 1 or len(c3) != 1:
+            raise ValueError(f'{path}: block {b}: conv1 -> conv2 -> conv3 chain not found')
+        ordered += [c1[0], c2[0], c3[0]] + sc
+        join = next_join(c3[0])
+        if join is None:
+            raise ValueError(f'{path}: block {b}: conv3 does not reach a residual Add')
+        if sc and next_join(sc[0]) is not join:
+            raise ValueError(f'{path}: block {b}: the shortcut projection and conv3 do not meet in the same Add')
+        x = id(join)
+    if len(ordered) != len(convs) or len({id(c) for c in ordered}) != len(convs):
+        raise ValueError(f'{path}: {len(convs)} Conv nodes but the Bottleneck walk found {len(ordered)}')
+    return ordered
+
+
+def _check_conv_geometry(path, convs, want):
+    """strides / pads / group of every Conv against resnet.py:48-75,95-113 (stage strides 1, 2, 2, 2 on conv2 and on the
+    shortcut projection; 3x3 padded by 1, 1x1 unpadded; no grouped convolution)."""
+    stage_stride = {1: 1, 2: 2, 3: 2, 4: 2}
+    for node, (cname, _, shape) in zip(convs, want):
+        a = node['attr']
+        k = shape[2]
+        stride = 1
+        if cname != 'conv1':
+            li, bi, leaf = cname[5:].split('.', 2)
+            if bi == '0' and (leaf == 'conv2' or leaf.startswith('shortcut')):
+                stride = stage_stride[int(li)]
+        st = a.get('strides') or [1, 1]
+        pd = a.get('pads') or [0, 0, 0, 0]
+        st = [st] * 2 if isinstance(st, int) else list(st)
+        pd = [pd] * 4 if isinstance(pd, int) else list(pd)
+        if st != [stride, stride] or pd != [k // 2] * 4 or (a.get('group') or 1) != 1 or (a.get('dilations') or [1, 1]) in ([2, 2],):
+            raise ValueError(f'{path}: {cname}: strides {st} pads {pd} group {a.get("group")}, resnet.py has strides '
+                             f'{[stride, stride]} pads {[k // 2] * 4} group 1')
+
+
 def load_resnet101_params(path):
     """`final.onnx` -> state_dict-like {name: float32 ndarray} (see the module docstring)."""
     nodes, inits = read_graph(path)
@@ -190,6 +278,8 @@ def load_resnet101_params(path):
     want = resnet101_conv_names()
     if len(convs) != len(want):
         raise ValueError(f'{path}: {len(convs)} Conv nodes, the ResNet-101 of resnet.py has {len(want)}')
+    convs = _order_convs_by_connectivity(path, nodes, convs, produced, consumers)
+    _check_conv_geometry(path, convs, want)
     params = {}
 
     def tensor_of(name):

@@ -254,10 +254,12 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
     def packer():
         cur = _Batch()
         nbatch = 0
+        ended = False                                              # the decoders' end marker has been read
         try:
             while True:
                 it = dec_q.get()
                 if it is None:
+                    ended = True
                     break
                 i, src, sig, err = it
                 if sig is not None:
@@ -288,8 +290,8 @@ def process_files(seg, linput, on_result, skip=None, nbtry=1, trydelay=2., batch
             # record it and keep draining the decoders -- they block on the bounded queue / the audio budget while holding
             # their PCM -- until their end marker, exactly like the `if failure: continue` path above
             failure.append(exc)
-            while True:
-                it = dec_q.get()
+            while not ended:                                       # (an exception AFTER the marker was read: nothing left to drain --
+                it = dec_q.get()                                   #  a second get() would block forever)
                 if it is None:
                     break
                 if it[2] is not None:

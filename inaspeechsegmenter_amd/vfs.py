@@ -82,6 +82,9 @@ def _load_resnet_params(path):
     if path.lower().endswith('.onnx'):
         from .onnx_reader import load_resnet101_params
         return load_resnet101_params(path)
+    if path.lower().endswith('.npz'):                     # locate_model also accepts a flat '<stem>.npz' export of either file
+        with np.load(path) as z:
+            return {k: np.asarray(z[k]) for k in z.files}
     import torch
     ck = torch.load(path, map_location='cpu')
     sd = ck.get('state_dict', ck)
@@ -116,10 +119,14 @@ class VoiceFemininityScoring:
             resnet, mlp = models['resnet'], models['mlp']
         else:
             try:                                          # the file `get_remote` fetches by default (remote_utils.py:13, backend='onnx')
-                resnet_path = locate_model('final.onnx')
-            except FileNotFoundError:
-                resnet_path = locate_model('raw_81.pth')
-            resnet = _load_resnet_params(resnet_path)
+                resnet = _load_resnet_params(locate_model('final.onnx'))
+            except (FileNotFoundError, ValueError, NotImplementedError) as exc:
+                # no final.onnx, or one this package's reader does not recognise as resnet.py's graph: the torch checkpoint
+                # of the same network (remote_utils.py:14) if it is there, else the first error
+                try:
+                    resnet = _load_resnet_params(locate_model('raw_81.pth'))
+                except FileNotFoundError:
+                    raise exc
             mlp = keras_model.load_model_file(locate_model(gd_model))
         self.features = FeatureExtractor(self.ctx)
         self.xvector_model = VBxExtractor(self.ctx, resnet)

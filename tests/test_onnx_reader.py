@@ -175,3 +175,32 @@ def test_reader_rejects_other_graphs(tmp_path):
     open(path, 'wb').write(b'\x08\x08')
     with pytest.raises(ValueError):
         OR.load_resnet101_params(path)
+
+
+def test_reordered_export_is_matched_by_connectivity_not_by_order(tmp_path, monkeypatch):
+    """layer1.0's conv3 and shortcut projection are both (128, 32, 1, 1): an exporter that lists the shortcut FIRST must still
+    give each its own weights (the reader walks the graph); wrong strides / pads are refused."""
+    params = KM.synthetic_resnet101(5)
+    path = str(tmp_path / 'final.onnx')
+    write_resnet_onnx(path, params, False)
+    nodes, inits = OR.read_graph(path)
+    # permute the node list: every shortcut Conv (+ its BatchNormalization) moves in front of its block's conv1, and the whole
+    # list of the first block is reversed on top (readers must not depend on topological order either)
+    conv_idx = [i for i, n in enumerate(nodes) if n['op_type'] == 'Conv']
+    order = list(range(len(nodes)))
+    sc_conv = conv_idx[4]                              # stem, l1.0.conv1, conv2, conv3, shortcut
+    blk = order[conv_idx[1]:sc_conv + 2]
+    order[conv_idx[1]:sc_conv + 2] = blk[-2:] + blk[:-2]
+    shuffled = [nodes[i] for i in order]
+    monkeypatch.setattr(OR, 'read_graph', lambda p: (shuffled, inits))
+    got = OR.load_resnet101_params(path)
+    for k in ('layer1.0.conv3.weight', 'layer1.0.shortcut.0.weight', 'layer1.0.bn3.bias', 'layer1.0.shortcut.1.bias'):
+        assert np.array_equal(got[k], params[k]), k
+    assert not np.array_equal(params['layer1.0.conv3.weight'], params['layer1.0.shortcut.0.weight'])
+    # geometry: a stride-1 stage-2 shortcut is not resnet.py's network
+    for n in shuffled:
+        n['attr'] = dict(n['attr'])
+    stage2_sc = [n for n in nodes if n['op_type'] == 'Conv'][1 + 3 * 3 + 1 + 3]       # layer2.0.shortcut.0
+    stage2_sc['attr']['strides'] = [1, 1]
+    with pytest.raises(ValueError, match='strides'):
+        OR.load_resnet101_params(path)

@@ -157,3 +157,50 @@ print('rank', rank, 'ok')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                         '--master-port', str(_free_port()), str(script)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'rank 0 ok' in r.stdout and 'rank 1 ok' in r.stdout, r.stdout + r.stderr
+
+
+def _run_bench(argv, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + argv, capture_output=True, text=True, timeout=timeout, env=env,
+                       cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_2_spawns_its_own_ranks_on_a_fake_device():
+    """`python bench.py --gpus 2` with no launcher in the environment (how a driver calls it at N = 1) must not exit: it starts
+    its own two ranks under torch.distributed.run, and the N > 1 branch of the file -- communicator, barriers, max-over-ranks
+    timing, one all-gather per step, line assembly on rank 0 only -- runs (here with a fake device and the gloo exchange)."""
+    r, lines = _run_bench(['--gpus', '2', '--steps', '3', '--warmup', '1', '--minutes', '1', '--comm', 'gloo',
+                           '--fake-device', 'tests.fake_bench_device:make'])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'spawning' in r.stderr and 'torch.distributed.run' in r.stderr
+    assert len(lines) == 1, r.stdout                                   # rank 0 only
+    line = lines[0]
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['data'] == 'fake-device' and line['value'] is None
+    assert line['config']['files_seen'] == [0, 1] and line['config']['rows_gathered'] == 3 + 4      # both ranks' tables on rank 0
+    assert 'gloo' in line['config']['parallelism']
+    assert line['ranks']['ms_per_step_min'] < line['ranks']['ms_per_step_max']                      # rank 1 sleeps twice as long
+    assert 18.0 <= line['ranks']['ms_per_step_max'] and line['ms_per_step'] >= line['ranks']['ms_per_step_max'] - 1e-6
+
+
+def test_bench_has_no_silent_comm_fallback():
+    """north_star: no dual backend.  The default exchange is the C-ABI's RCCL all-gather; when its rendezvous cannot be set up
+    the run fails and names the explicit alternatives, it does not quietly continue on torch.distributed."""
+    import bench
+
+    class NoRccl:
+        def comm_unique_id(self):
+            raise RuntimeError('librccl.so: cannot open shared object file')
+
+    with pytest.raises(SystemExit) as ei:
+        bench.make_comm(NoRccl(), 0, 2, None, 'rccl')
+    assert 'no fallback' in str(ei.value) and '--comm torch' in str(ei.value) and '--comm gloo' in str(ei.value)
+    assert bench.make_comm(NoRccl(), 0, 1, None, 'rccl') == (None, None)
+    r, lines = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--minutes', '1', '--fake-device', 'tests.fake_bench_device:make'])
+    assert r.returncode != 0 and not lines and 'no fallback' in r.stderr, r.stdout + r.stderr       # default --comm rccl, no device

@@ -35,10 +35,13 @@ def kernels(path):
 
 def main():
     path, filt = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'pws')
+    expect = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # at least this many kernels must match the filter
     ok = True
+    checked = 0
     for name, body in kernels(path):
         if filt not in name:
             continue
+        checked += 1
         ins, addr, target = [], [], []                # mnemonic + operands, byte offset in the kernel, branch target offset (or None)
         base = None
         for l in body:
@@ -130,6 +133,9 @@ def main():
         ok &= verdict == 'ok'
         show = (lambda d: dict(d) if len(d) <= 8 else {**dict(list(d.items())[:8]), '...': len(d)})
         print(f"{verdict:5s} {name[:70]:70s} ring regs {len(ring):3d} readers {show(readers)} writers {show(writers)} init copies {init_copies} scratch {scratch} | per load: {dict(first)}")
+    if checked < expect:                              # an empty / renamed disassembly must not pass vacuously
+        print(f"CHECK {path}: {checked} kernel(s) match {filt!r}, expected at least {expect}")
+        ok = False
     sys.exit(0 if ok else 1)
 
 
