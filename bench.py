@@ -425,7 +425,18 @@ def make_comm(ctx, rank, world, dev, kind='rccl'):
         return sharding.TorchComm(device=dev), "torch.distributed nccl all_gather_into_tensor (--comm torch)"
     if kind == 'gloo':
         if not dist.is_initialized():
-            dist.init_process_group('gloo')
+            # gloo's transport prints "[Gloo] Rank r is connected to ..." on STDOUT when the mesh is built: keep the one-JSON-line
+            # contract by pointing fd 1 at stderr while the group comes up (first collective included)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group('gloo')
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
         return sharding.TorchComm(device=None), ("torch.distributed gloo all_gather_into_tensor over host memory (--comm gloo: "
                                                  "rehearsal of the N-rank path, NOT an RCCL / xGMI exchange)")
     raise SystemExit(f"--comm {kind}: unknown")
@@ -590,15 +601,15 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind, seg=None, comm=
             "config": {"workload": (f"BASELINE.json configs[2]: {nfiles} x {minutes:g} min synthetic 16 kHz mono PCM16 WAV files in {args.dir} "
                                     "through Segmenter.batch_process" if kind == 'batch' else
                                     f"BASELINE.json configs[3] shape: {nfiles} x {minutes:g} min synthetic WAV files ({per_gpu} per GPU, weak scaling), "
-                                    "file-parallel through archive.segment_archive, one RCCL all-gather of the segment tables per step") +
+                                    "file-parallel through archive.segment_archive, one all-gather of the segment tables per step") +
                                    "; reference semantics (VAD net on energy slots, gender net on speech slots); RIFF parse, H2D copy, device "
                                    "features + CNNs, compiled Viterbi and CSV export are all inside the timed region",
                        "files": nfiles, "files_per_gpu": per_gpu, "minutes_per_file": minutes, "audio_hours_per_step": hours,
                        "ms_per_file_per_gpu": dt / steps / per_gpu * 1e3, "segments_per_step": nseg,
                        "weights": "seeded stand-ins, (68,21,1)->3 and (68,24,1)->2, ~1.25 M params each, last layer calibrated "
                                   "(tests/golden/make_standin_heads.py); the real Keras files are un-vendored release assets",
-                       "parallelism": (f"file-parallel x{world}: files dealt by size (LPT), no data-path collective, ONE ncclAllGather of int32 segment "
-                                       "tables per step through the C-ABI (iss_allgather_segments)") if world > 1 else "single GPU"},
+                       "parallelism": (f"file-parallel x{world}: files dealt by size (LPT), no data-path collective, ONE all-gather of int32 segment "
+                                       f"tables per step: {comm_kind}") if world > 1 else "single GPU"},
             "roofline": roofline,
             "pipeline_workers_ms_per_step": {"workers": pipe,
                                              "what": "wall ms per step each device worker thread spent packing PCM into its page-locked buffer, in "

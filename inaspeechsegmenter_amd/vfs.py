@@ -6,10 +6,14 @@ get_features (csrc/vbx.hip) -> ResNet-101 x-vectors on every 144-frame window (e
 x-vectors whose midpoint lies in speech and that overlap speech by >= vad_thresh (:129-145, 28-52) -> gender MLP
 (a Keras Dense stack, run on the same engine) -> share of windows with p >= 0.5 (:55-61).
 
-The reference does the interval arithmetic with pyannote.core (Annotation / Timeline.crop); speech segments coming
-out of the segmenter are disjoint, so plain interval intersection gives the same numbers.  PARITY UNPINNED: the only
-reference test of this tail (run_test.py:177-187, score 0.534884 on lamartine.wav) needs the un-vendored weights
-(final.onnx / raw_81.pth, interspeech2023_*.hdf5); tests here check the host logic against a literal restatement.
+The reference does the interval arithmetic with pyannote.core (Annotation / Timeline.crop / Timeline.duration).  The helpers
+below follow that package's rules on plain tuples -- a segment of <= 1e-6 s is empty, a timeline is a SET of segments,
+crop() and duration() work on the SUPPORT (touching / overlapping segments merged), `intersects` wants more than 1e-6 s of
+overlap -- and tests/test_vfs.py compares them with a class-by-class restatement of the package (oracle/pyannote_core.py)
+running the reference's own statements, on random timelines incl. equal boundaries, overlaps, duplicates and empty
+segments.  PARITY UNPINNED against the package itself (absent here) and against the only reference test of this tail
+(run_test.py:177-187, score 0.534884 on lamartine.wav), which needs the un-vendored weights (final.onnx / raw_81.pth,
+interspeech2023_*.hdf5).
 Known divergence: add_needed_vectors (:40-52) reads `s.stop` on a pyannote Segment, which has no such attribute --
 the branch would raise in the reference; here it does what the code evidently intends (append (key, (start, end), x)).
 """
@@ -25,9 +29,40 @@ from .vbx import FeatureExtractor, VBxExtractor, SR
 _MLP_NET = 3          # engine net id of the gender MLP (0/1: VAD / gender CNNs, 4..: ResNet programs)
 
 
+PRECISION = 1e-6     # pyannote.core's SEGMENT_PRECISION: a segment with end - start <= 1e-6 s is EMPTY (dropped / ignored)
+
+
+def _nonempty(s, e):
+    return (e - s) > PRECISION
+
+
+def _intersects(a0, a1, b0, b1):
+    """pyannote.core Segment.intersects: more than PRECISION of overlap, or equal starts."""
+    return (a0 < b0 and b0 < a1 - PRECISION) or (a0 > b0 and a0 < b1 - PRECISION) or (a0 == b0)
+
+
+def _support(intervals):
+    """pyannote.core Timeline.support(): the distinct non-empty segments in (start, end) order, neighbours merged unless a gap
+    of more than PRECISION separates them."""
+    segs = sorted({(s, e) for s, e in intervals if _nonempty(s, e)})
+    out = []
+    for s, e in segs:
+        if out and not _nonempty(min(e, out[-1][1]), max(s, out[-1][0])):       # `segment ^ new_segment` is empty: no gap
+            out[-1] = (min(s, out[-1][0]), max(e, out[-1][1]))
+        else:
+            out.append((s, e))
+    return out
+
+
 def speech_intervals(vad_tuples):
-    """get_annot_VAD (vbx_segmenter.py:64-69): the 'speech' segments."""
-    return [(float(s), float(e)) for lab, s, e in vad_tuples if lab == 'speech']
+    """get_annot_VAD (vbx_segmenter.py:64-69): the 'speech' segments as an Annotation keeps them -- one entry per distinct
+    non-empty Segment(start, end), in (start, end) order."""
+    return sorted({(s, e) for lab, s, e in vad_tuples if lab == 'speech' and _nonempty(s, e)})
+
+
+def speech_duration(speech):
+    """annot_vad.label_duration("speech") (vbx_segmenter.py:163): the duration of the SUPPORT of the speech timeline."""
+    return sum(e - s for s, e in _support(speech))
 
 
 def is_mid_speech(start, stop, speech):
@@ -36,10 +71,23 @@ def is_mid_speech(start, stop, speech):
     return any(s < m < e for s, e in speech)
 
 
+def cropped_duration(start, stop, speech):
+    """Timeline([Segment(start, stop)]).crop(vad.get_timeline()).duration()  (vbx_segmenter.py:138-142; crop mode
+    'intersection'): the support of the speech timeline is taken first, every support segment that `intersects` the window
+    contributes window & segment unless that piece is empty, and the pieces' own support is summed in time order."""
+    if not _nonempty(start, stop):
+        return 0
+    pieces = set()
+    for s, e in _support(speech):
+        if (s, e) <= (stop, stop) and _intersects(start, stop, s, e):
+            p = (max(start, s), min(stop, e))
+            if _nonempty(*p):
+                pieces.add(p)
+    return sum(e - s for s, e in _support(pieces))
+
+
 def overlap_ratio(start, stop, speech):
-    """Timeline([Segment(start, stop)]).crop(vad.get_timeline()).duration() / (stop - start)  (:138-140)."""
-    ov = sum(max(0.0, min(stop, e) - max(start, s)) for s, e in speech)
-    return ov / (stop - start)
+    return cropped_duration(start, stop, speech) / (stop - start)
 
 
 def add_needed_vectors(xvectors, t_mid):
@@ -67,11 +115,12 @@ def apply_vad(xvectors, speech, vad_thresh):
 
 
 def get_femininity_score(g_preds):
-    """vbx_segmenter.py:55-61: an Annotation keyed by Segment(start, stop) keeps ONE entry per distinct segment
+    """vbx_segmenter.py:55-61: an Annotation keyed by Segment(start, stop) keeps ONE entry per distinct non-empty segment
     (a later prediction on the same segment replaces the earlier one); score = #(p >= 0.5) / #segments."""
     seen = {}
     for start, stop, p in g_preds:
-        seen[(float(start), float(stop))] = bool(p >= 0.5)
+        if _nonempty(start, stop):
+            seen[(float(start), float(stop))] = bool(p >= 0.5)
     return sum(seen.values()) / len(seen)
 
 
@@ -145,14 +194,14 @@ class VoiceFemininityScoring:
         signal = media2sig16kmono(fpath, ffmpeg=self.ffmpeg, dtype='float64')
         duration = len(signal) / SR
         speech = speech_intervals(self.vad(fpath))
-        speech_duration = sum(e - s for s, e in speech)
-        if not speech_duration:
-            return None, speech_duration, 0
+        speech_dur = speech_duration(speech)
+        if not speech_dur:
+            return None, speech_dur, 0
         feats = self.features(signal)
         x_vectors = self.xvector_model(basename, feats, duration)
         x_vectors = apply_vad(x_vectors, speech, self.vad_thresh)
         if not x_vectors:                                 # (the reference fails inside the MLP predict on an empty batch)
-            return None, speech_duration, 0
+            return None, speech_dur, 0
         pred = self.gender_predict(np.asarray([x for _, _, x in x_vectors])).reshape(len(x_vectors), -1)[:, 0]
         g = [(seg[0], seg[1], p) for (_, seg, _), p in zip(x_vectors, pred)]
-        return get_femininity_score(g), speech_duration, len(g)
+        return get_femininity_score(g), speech_dur, len(g)
