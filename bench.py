@@ -462,7 +462,7 @@ def self_spawn(n, argv):
 
 
 def bench_files(args, torch, dev, local_rank, rank, world, kind, seg=None, comm=None, comm_kind=None, steps=None, warmup=None,
-                per_gpu=None):
+                per_gpu=None, dense=None):
     """`batch` (configs[2], one GPU) and `archive` (configs[3] shape, file-parallel + one all-gather) workloads.
     -> the JSON line as a dict on rank 0 (None elsewhere).  seg / comm: reuse the caller's (companion runs)."""
     from inaspeechsegmenter_amd import Segmenter, _native, sharding
@@ -474,6 +474,8 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind, seg=None, comm=
         seg = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models='synthetic', device=local_rank)
     x3 = args.precision == 'bf16x3'
     seg.ctx.set_precision(_native.PREC_BF16X3 if x3 else _native.PREC_F32)
+    dense = bool(args.dense_files if dense is None else dense)
+    seg.dense_batches = dense                        # both networks on every slot of every file (comparable with the resident-path figure)
     if comm is None and world > 1:
         comm, comm_kind = make_comm(seg.ctx, rank, world, dev, args.comm)
     minutes = args.file_minutes or (5.0 if kind == 'batch' else 3.0)
@@ -602,7 +604,9 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind, seg=None, comm=
                                     "through Segmenter.batch_process" if kind == 'batch' else
                                     f"BASELINE.json configs[3] shape: {nfiles} x {minutes:g} min synthetic WAV files ({per_gpu} per GPU, weak scaling), "
                                     "file-parallel through archive.segment_archive, one all-gather of the segment tables per step") +
-                                   "; reference semantics (VAD net on energy slots, gender net on speech slots); RIFF parse, H2D copy, device "
+                                   ("; DENSE: both nets on 100% of the slots of every file (same work per audio-hour as the segmenter workload's "
+                                    "dense figure)" if dense else "; reference semantics (VAD net on energy slots, gender net on speech slots)") +
+                                   "; RIFF parse, H2D copy, device "
                                    "features + CNNs, compiled Viterbi and CSV export are all inside the timed region",
                        "files": nfiles, "files_per_gpu": per_gpu, "minutes_per_file": minutes, "audio_hours_per_step": hours,
                        "ms_per_file_per_gpu": dt / steps / per_gpu * 1e3, "segments_per_step": nseg,
@@ -820,6 +824,7 @@ def main():
     ap.add_argument('--files-per-gpu', type=int, default=0, help='batch / archive: files per GPU and step (default 128)')
     ap.add_argument('--file-minutes', type=float, default=0.0, help='batch / archive: minutes per file (default 5 / 3)')
     ap.add_argument('--dir', default='/dev/shm/iss_bench', help='batch / archive: where the synthetic WAV files live')
+    ap.add_argument('--dense-files', action='store_true', help='batch / archive: both networks on every slot of every file (Segmenter.dense_batches)')
     ap.add_argument('--no-f32-companion', action='store_true', help='skip the exact-f32 (ISS_PREC_F32) companion step')
     ap.add_argument('--batch-files', type=int, default=0, help='batch / archive: files per device pass at most (0 = library default, 32)')
     ap.add_argument('--batch-seconds', type=float, default=0, help='batch / archive: audio per device pass at most (0 = library default, 2400 s)')
@@ -991,7 +996,11 @@ def main():
         if rank == 0:
             companions["archive"] = _companion_view(arch)
         if world == 1:
-            companions["batch"] = _companion_view(bench_files(args, torch, dev, local_rank, rank, world, 'batch', seg=seg, steps=2, warmup=1))
+            companions["batch"] = _companion_view(bench_files(args, torch, dev, local_rank, rank, world, 'batch', seg=seg, steps=2, warmup=1, dense=False))
+            # the same files with both nets on every slot: the file path's counterpart of the headline (dense, resident) figure
+            companions["batch_dense"] = _companion_view(bench_files(args, torch, dev, local_rank, rank, world, 'batch', seg=seg, steps=2, warmup=1,
+                                                                    dense=True))
+            seg.dense_batches = False
             vb = bench_vbx(args, torch, dev, local_rank, rank, world, steps=2, warmup=1, cpu_leg=False)
             companions["vbx"] = _companion_view(vb)
 

@@ -542,6 +542,94 @@ __global__ __launch_bounds__(256) void first_layer_raw_kernel(const float* __res
     }
 }
 
+// Zero-padded ('same') first layer, the rows every window shares (conv_x3_ws_kernel<..., FS>): output row t of the recording,
+// column x, from ALL kh filter rows (input rows t - pt .. t - pt + kh - 1; a window reads row wr + y only for pt <= y < H - pb,
+// where these are its own rows) and the filter columns that see data at x (0 <= x - pl + kx < W: the padding of the normalised
+// window is worth the window mean in raw units, which the consumer accounts for through S[x][c]).  Rows outside the recording
+// are clamped (never read).  One thread per (t, x, 4 channels), run-time filter shape.
+__global__ __launch_bounds__(256) void first_layer_same_kernel(const float* __restrict__ mspec, int nrows_mspec, int row0, long long total,
+                                                               int W, int Cout, int kh, int kw, int pt, int pl,
+                                                               const float* __restrict__ w, int Kpad, float* __restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];     // [K][Cout]
+    const int K = kh * kw;
+    for (int e = threadIdx.x; e < K * Cout; e += 256) {
+        const int co = e / K, k = e - co * K;
+        sW[k * Cout + co] = w[(size_t)co * Kpad + k];
+    }
+    __syncthreads();
+    const unsigned cg = (unsigned)Cout >> 2, utotal = (unsigned)total;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < utotal; idx += gridDim.x * 256u) {
+        const unsigned pix = idx / cg;
+        const int c4 = (int)(idx - pix * cg) * 4;
+        const unsigned t = pix / (unsigned)W;
+        const int x = (int)(pix - t * (unsigned)W);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int ky = 0; ky < kh; ++ky) {
+            int r = row0 + (int)t - pt + ky;
+            r = r < 0 ? 0 : (r > nrows_mspec - 1 ? nrows_mspec - 1 : r);
+            const float* src = mspec + (size_t)r * 24;
+            for (int kx = 0; kx < kw; ++kx) {
+                const int ix = x - pl + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const float v = src[ix];
+                const float4 wk = *reinterpret_cast<const float4*>(&sW[(ky * kw + kx) * Cout + c4]);
+                a0 = fmaf(v, wk.x, a0); a1 = fmaf(v, wk.y, a1); a2 = fmaf(v, wk.z, a2); a3 = fmaf(v, wk.w, a3);
+            }
+        }
+        float4 o;
+        o.x = isfinite(a0) ? a0 : 0.f; o.y = isfinite(a1) ? a1 : 0.f; o.z = isfinite(a2) ? a2 : 0.f; o.w = isfinite(a3) ? a3 : 0.f;
+        *reinterpret_cast<float4*>(R + (size_t)idx * 4) = o;
+    }
+}
+
+// ... and the rows that are NOT shared: the first pt / last pb output rows of each window see fewer filter rows.  Window b's edge
+// row e (e < pt: y = e; else y = H - pb + e - pt) is written per window, already shifted so that the consumer's ordinary map
+// rs * X + (bias - mean * rs * S[x][c]) gives the reference's value:  X = partial sum + mean_b * (S[x][c] - S_partial[x][c])
+// (partial = the filter rows / columns that lie inside the window).  One thread per (b, e, x, 4 channels).
+__global__ __launch_bounds__(256) void first_layer_edge_kernel(const float* __restrict__ mspec, const int32_t* __restrict__ win_row,
+                                                               const float* __restrict__ stats, long long total, int H, int W, int Cout,
+                                                               int kh, int kw, int pt, int pb, int pl, const float* __restrict__ w, int Kpad,
+                                                               const float* __restrict__ S, float* __restrict__ E) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];     // [K][Cout]
+    const int K = kh * kw;
+    for (int e = threadIdx.x; e < K * Cout; e += 256) {
+        const int co = e / K, k = e - co * K;
+        sW[k * Cout + co] = w[(size_t)co * Kpad + k];
+    }
+    __syncthreads();
+    const unsigned cg = (unsigned)Cout >> 2, utotal = (unsigned)total, ne = (unsigned)(pt + pb);
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < utotal; idx += gridDim.x * 256u) {
+        const unsigned pix = idx / cg;
+        const int c4 = (int)(idx - pix * cg) * 4;
+        const unsigned be = pix / (unsigned)W;
+        const int x = (int)(pix - be * (unsigned)W);
+        const unsigned b = be / ne;
+        const int e = (int)(be - b * ne);
+        const int y = e < pt ? e : H - pb + (e - pt);
+        const int wr = win_row[b];
+        const float mean = stats[2u * b];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int ky = 0; ky < kh; ++ky) {
+            const int iy = y - pt + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            const float* src = mspec + (size_t)(wr + iy) * 24;
+            for (int kx = 0; kx < kw; ++kx) {
+                const int ix = x - pl + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const float v = src[ix];
+                const float4 wk = *reinterpret_cast<const float4*>(&sW[(ky * kw + kx) * Cout + c4]);
+                a0 = fmaf(v, wk.x, a0); a1 = fmaf(v, wk.y, a1); a2 = fmaf(v, wk.z, a2); a3 = fmaf(v, wk.w, a3);
+                s0 += wk.x; s1 += wk.y; s2 += wk.z; s3 += wk.w;
+            }
+        }
+        const float4 sf = *reinterpret_cast<const float4*>(S + (size_t)x * Cout + c4);
+        a0 = fmaf(mean, sf.x - s0, a0); a1 = fmaf(mean, sf.y - s1, a1); a2 = fmaf(mean, sf.z - s2, a2); a3 = fmaf(mean, sf.w - s3, a3);
+        float4 o;
+        o.x = isfinite(a0) ? a0 : 0.f; o.y = isfinite(a1) ? a1 : 0.f; o.z = isfinite(a2) ? a2 : 0.f; o.w = isfinite(a3) ? a3 : 0.f;
+        *reinterpret_cast<float4*>(E + (size_t)idx * 4) = o;
+    }
+}
+
 // The same R for a compile-time filter shape, one thread per (log-mel row t, 4 channels): the thread keeps the 24 values
 // of each of its KH input rows in registers and produces ALL Wout positions of the row from them -- 6 float4
 // loads per input row instead of KH * KW scalar loads per OUTPUT (first_layer_raw_kernel issues 20 loads per 16 bytes
@@ -904,6 +992,7 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
     {   // per-channel weight sums of the patch-mode first layers (ConvArgs::f_wsum)
         std::vector<float> wsum;
         n.wsum_off.assign(nrows, -1);
+        n.wsumx_off.assign(nrows, -1);
         for (int r = 0; r < nrows; ++r) {
             const int32_t* R = &n.prog[(size_t)r * ISS_PROG_COLS];
             if (R[ISS_C_OP] != ISS_OP_CONV || R[ISS_C_INMODE] != 1) continue;
@@ -915,6 +1004,21 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
                 wsum.push_back((float)acc);
             }
             while (wsum.size() % 8) wsum.push_back(0.f);         // float4-aligned rows
+            // zero-padded first layer: S[x][co] = sum over all filter rows and the filter columns that see data at column x
+            // (conv_x3_ws_kernel<..., FS>, first_layer_edge_kernel)
+            if ((R[ISS_C_PT] != 0 || R[ISS_C_PL] != 0 || R[ISS_C_WO] == R[ISS_C_W]) && R[ISS_C_CIN] == 1 && R[ISS_C_SW] == 1) {
+                n.wsumx_off[r] = (int64_t)wsum.size();
+                const int W = R[ISS_C_W], kh = R[ISS_C_KH], kw = R[ISS_C_KW], pl = R[ISS_C_PL];
+                for (int x = 0; x < W; ++x)
+                    for (int co = 0; co < R[ISS_C_COUT]; ++co) {
+                        double acc = 0.0;
+                        for (int ky = 0; ky < kh; ++ky)
+                            for (int kx = 0; kx < kw; ++kx)
+                                if (x - pl + kx >= 0 && x - pl + kx < W) acc += (double)blob[R[ISS_C_WOFF] + (int64_t)co * n.kpad[r] + ky * kw + kx];
+                        wsum.push_back((float)acc);
+                    }
+                while (wsum.size() % 8) wsum.push_back(0.f);
+            }
         }
         if (!wsum.empty()) {
             ISS_HIP(c, hipMalloc((void**)&n.d_wsum, wsum.size() * sizeof(float)));
@@ -1021,13 +1125,21 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         int ph, pw;
         fused_pool_of(R1, ph, pw);
         if (R1[ISS_C_OP] != ISS_OP_CONV || R1[ISS_C_INMODE] != 1 || ph * pw != 1 || R1[ISS_C_RES] >= 0 || R1[ISS_C_ACT] > 1) return false;
-        if (R1[ISS_C_CIN] != 1 || R1[ISS_C_SH] != 1 || R1[ISS_C_SW] != 1 || R1[ISS_C_PT] != 0 || R1[ISS_C_PL] != 0) return false;
-        if (R1[ISS_C_HO] != R1[ISS_C_H] - R1[ISS_C_KH] + 1 || R1[ISS_C_WO] != R1[ISS_C_W] - R1[ISS_C_KW] + 1) return false;   // 'valid'
+        if (R1[ISS_C_CIN] != 1 || R1[ISS_C_SH] != 1 || R1[ISS_C_SW] != 1) return false;
+        const bool valid1 = R1[ISS_C_PT] == 0 && R1[ISS_C_PL] == 0 && R1[ISS_C_HO] == R1[ISS_C_H] - R1[ISS_C_KH] + 1 &&
+                            R1[ISS_C_WO] == R1[ISS_C_W] - R1[ISS_C_KW] + 1;                                                     // 'valid'
+        // 'same' (zero-padded, output = input size): shared through conv_x3_ws_kernel<..., FS> (S table + per-window edge rows)
+        const bool same1 = !valid1 && R1[ISS_C_HO] == R1[ISS_C_H] && R1[ISS_C_WO] == R1[ISS_C_W] && R1[ISS_C_PT] <= R1[ISS_C_KH] - 1 &&
+                           R1[ISS_C_PL] <= R1[ISS_C_KW] - 1 && R1[ISS_C_KH] <= R1[ISS_C_H] && n.wsumx_off[r] >= 0 &&
+                           R1[ISS_C_W] * R1[ISS_C_COUT] * 4 <= issk::WS_STAB && !(c->diag & (ISS_DIAG_NO_FSAME | ISS_DIAG_NO_WS)) &&
+                           R1[ISS_C_PSOFF] < 0 && issk::iss_ws_fs_compiled(R2[ISS_C_KH], R2[ISS_C_KW]);
+        if (!valid1 && !same1) return false;
         if (R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4 > 48 * 1024) return false;        // first_layer_raw_kernel's LDS weights
         if (R1[ISS_C_BOFF] < 0 || (R1[ISS_C_PSOFF] >= 0) != (R1[ISS_C_PTOFF] >= 0) || R1[ISS_C_COUT] % 4 != 0 || n.wsum_off[r] < 0) return false;
         if (R2[ISS_C_OP] != ISS_OP_CONV || R2[ISS_C_INMODE] != 0 || R2[ISS_C_IN] != R1[ISS_C_OUT] || R2[ISS_C_RES] >= 0) return false;
         if (R2[ISS_C_CIN] != R1[ISS_C_COUT] || R2[ISS_C_CIN] % XBK != 0 || R2[ISS_C_H] != R1[ISS_C_HO] || R2[ISS_C_W] != R1[ISS_C_WO]) return false;
-        if (R2[ISS_C_KH] * R2[ISS_C_KW] < 8 || !fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW])) return false;   // (>= 12 unless the weight-stationary kernel takes it, see conv_row)
+        const bool ring2 = valid1 && issk::iss_ws_ring_compiled(R2[ISS_C_KH], R2[ISS_C_KW]) && !(c->diag & (ISS_DIAG_NO_RING | ISS_DIAG_NO_WS));
+        if (R2[ISS_C_KH] * R2[ISS_C_KW] < 8 || (!fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW]) && !ring2)) return false;   // (>= 12 unless the weight-stationary kernel takes it, see conv_row)
         // (a zero-padded second conv is fused by the weight-stationary kernel only; conv_row decides)
         // the footprint may touch two windows at most, and the x / W trick of the kernel needs a small W
         if (R2[ISS_C_H] * R2[ISS_C_W] < FPIX + 32 || R2[ISS_C_W] > 128) return false;
@@ -1164,6 +1276,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         // weight-stationary kernel (conv_ws.h): the shared-first-layer convolution, 8..16 taps, one N tile of 64 channels
         bool ws = false;
         const bool no_ws = (c->diag & ISS_DIAG_NO_WS) != 0;
+        // the deferred first layer in front is zero-padded ('same'): only the FS form of the weight-stationary kernel can fuse it
+        const bool fs1 = pend >= 0 && (n.prog[(size_t)pend * ISS_PROG_COLS + ISS_C_HO] == n.prog[(size_t)pend * ISS_PROG_COLS + ISS_C_H]);
         if (!no_ws && fp && pend >= 0 && a.H_k * a.kw >= 8 && a.H_k * a.kw <= WS_MAXNT && ws_shape_compiled(a.H_k, a.kw) &&
             a.Cin % F2_CH == 0 && a.H * a.W >= WS_PIX + 64 + (a.pt_ + 1) * a.W && ws_recip_exact(a.W, a.H * a.W + WS_PIX + a.W)) {
             const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 62);
@@ -1171,13 +1285,39 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             if (it == n.fp_pix.end()) it = n.fp_pix.emplace(key, footprint_pixels(a, WS_TM)).first;
             ws = it->second <= WS_PIX && n.prog[(size_t)pend * ISS_PROG_COLS + ISS_C_PSOFF] < 0;     // (a post-activation affine of the
         }                                                                                            //  first layer stays on conv_x3_fp_kernel)
+        // ring form (conv_ws.h RING): more than WS_MAXNT taps (7x7), first-layer-fused, one 512-row tile per group on a
+        // 1024-pixel footprint; row-major epilogue
+        bool ws_ring = false;
+        if (!no_ws && !(c->diag & ISS_DIAG_NO_RING) && pend >= 0 && !fs1 && x3 && a.mode == 0 && issk::iss_ws_ring_compiled(a.H_k, a.kw) &&
+            a.sh == 1 && a.sw == 1 && a.Cin % F2_CH == 0 && a.Cin >= 2 * F2_CH && a.M < (1ll << 31) &&
+            a.H * a.W >= WS_PIX2 + 64 + (a.pt_ + 1) * a.W && ws_recip_exact(a.W, a.H * a.W + WS_PIX2 + a.W) &&
+            n.prog[(size_t)pend * ISS_PROG_COLS + ISS_C_PSOFF] < 0) {
+            // rows per tile: the largest multiple of 4 (<= 512, >= 384) whose footprint fits the 1024 pixels -- a 512-row tile of a
+            // pooled 59 x 14 output under a 7-row filter spans 1036 pixels, 496 rows 1002 (ConvArgs::tmr; the rest of the tile idles)
+            const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 57);
+            auto it = n.fp_pix.find(key);
+            if (it == n.fp_pix.end()) {
+                int tmr = 0;
+                for (int cand = WS_TM; cand >= 384 && !tmr; cand -= 4)
+                    if (footprint_pixels(a, cand) <= WS_PIX2) tmr = cand;
+                it = n.fp_pix.emplace(key, tmr).first;
+            }
+            a.tmr = it->second;
+            ws_ring = a.tmr > 0 && a.M % 4 == 0;
+            if (ws_ring) { ws = true; fp = true; } else a.tmr = 0;
+        }
         const bool padded = a.pt_ != 0 || a.pl_ != 0 ||
                             (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
+        // FS form: row-major epilogue only (a second conv without a fused pool would take the transposed one), stride 1
+        const bool ws_fs = fs1 && ws && issk::iss_ws_fs_compiled(a.H_k, a.kw) && !(a.pp == 1 && a.Cout % 4 == 0) && a.sh == 1 && a.sw == 1 &&
+                           a.Cin >= 2 * F2_CH && !(c->diag & ISS_DIAG_NO_FSAME);
+        if (fs1 && !ws_fs) ws = false;
         // weight-stationary kernel with two column halves per workgroup (conv_ws.h, NH = 2): unpadded 3x3 stride-1 layers with
         // a multiple of 128 output channels whose 512-row tiles fit a 1024-pixel footprint -- the 3x3 layers of the segmenter nets
         bool ws_nh2 = false;
         const bool no_ws3 = (c->diag & ISS_DIAG_NO_WS3) != 0;
-        const bool nh2_pad_ok = a.pp == 1 && a.Cout % 4 == 0 && issk::epi_is_simple_tr(a);       // the padded form is compiled transposed + simple only
+        const bool nh2_pad_pool = a.pp > 1 && issk::epi_is_pool_relu(a);                         // ... and row-major with the pooled relu epilogue
+        const bool nh2_pad_ok = (a.pp == 1 && a.Cout % 4 == 0 && issk::epi_is_simple_tr(a)) || nh2_pad_pool;   // the padded form is compiled transposed + simple
         if (!no_ws && !no_ws3 && pend < 0 && x3 && a.mode == 0 && (!padded || nh2_pad_ok) && a.sh == 1 && a.sw == 1 && !a.res && a.Cout % (2 * BN) == 0 &&
             issk::iss_ws_nh2_compiled(a.H_k, a.kw) && a.Cin % F2_CH == 0 && a.M < (1ll << 31) &&
             (long long)bc * a.img_stride * 4 < (1ll << 32)) {
@@ -1199,8 +1339,10 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         bool fused = false;
         if (pend >= 0) {
             const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
-            fused = fp && (ws || (!padded && a.H_k * a.kw >= 12)) && d_winrow != nullptr &&
-                    ((long long)(rmax - rmin) + Rp[ISS_C_HO]) * Rp[ISS_C_WO] * Rp[ISS_C_COUT] < (1ll << 32);   // 32-bit offsets into R
+            const long long edge_rows = fs1 ? (long long)bc * (Rp[ISS_C_KH] - 1) : 0;                          // per-window edge rows behind R
+            fused = fp && (ws || (!fs1 && !padded && a.H_k * a.kw >= 12)) && d_winrow != nullptr &&
+                    ((long long)(rmax - rmin) + Rp[ISS_C_HO] + edge_rows) * Rp[ISS_C_WO] * Rp[ISS_C_COUT] * 4 < (1ll << 32);   // 32-bit BYTE offsets into R
+            if (ws_ring && !fused) { ws = false; fp = false; ws_ring = false; a.tmr = 0; }                                // (no footprint kernel of that shape)
         }
         if (!fused && (long long)bc * a.img_stride >= (1ll << 32)) fp = false;        // 32-bit offsets into the input batch
         if (pend >= 0) {
@@ -1211,9 +1353,26 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 const int32_t* R1 = &n.prog[(size_t)pend * ISS_PROG_COLS];
                 const long long rrows = (long long)(rmax - rmin) + R1[ISS_C_HO];     // R: rows rmin .. rmax + H1 - 1
                 const long long rtot = rrows * R1[ISS_C_WO] * (R1[ISS_C_COUT] / 4);
-                { const int rc = iss_reserve(c, c->raw1, (size_t)rtot * 16); if (rc) return rc; }
+                const int f_ne = fs1 ? R1[ISS_C_KH] - 1 : 0;                         // zero-padded first layer: edge rows per window
+                const long long etot = (long long)bc * f_ne * R1[ISS_C_WO] * (R1[ISS_C_COUT] / 4);
+                { const int rc = iss_reserve(c, c->raw1, (size_t)(rtot + etot) * 16); if (rc) return rc; }
                 float* Rraw = (float*)c->raw1.p;
                 iss_prof_begin(c, 2, 0);
+                if (fs1) {
+                    // shared rows (all filter rows, the filter columns that see data) + the per-window edge rows behind them
+                    const int pt1 = R1[ISS_C_PT], pl1 = R1[ISS_C_PL], pb1 = R1[ISS_C_KH] - 1 - pt1;
+                    const float* S = n.d_wsum + n.wsumx_off[pend];
+                    const size_t lds1 = (size_t)R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4;
+                    if (rtot >= (1ll << 31) || etot >= (1ll << 31)) return iss_fail(c, ISS_EINVAL, "internal: shared first layer over %lld + %lld items", rtot, etot);
+                    hipLaunchKernelGGL(first_layer_same_kernel, dim3((unsigned)std::min<long long>((rtot + 255) / 256, 4096)), dim3(256), lds1, c->stream,
+                                       (const float*)c->mspec.p, (int)c->T, rmin, rtot, R1[ISS_C_WO], R1[ISS_C_COUT], R1[ISS_C_KH], R1[ISS_C_KW],
+                                       pt1, pl1, (const float*)(n.d_blob + R1[ISS_C_WOFF]), n.kpad[pend], Rraw);
+                    if (etot > 0)
+                        hipLaunchKernelGGL(first_layer_edge_kernel, dim3((unsigned)std::min<long long>((etot + 255) / 256, 8192)), dim3(256), lds1, c->stream,
+                                           (const float*)c->mspec.p, d_winrow, d_stats, etot, R1[ISS_C_H], R1[ISS_C_WO], R1[ISS_C_COUT], R1[ISS_C_KH],
+                                           R1[ISS_C_KW], pt1, pb1, pl1, (const float*)(n.d_blob + R1[ISS_C_WOFF]), n.kpad[pend], S, Rraw + (size_t)rtot * 4);
+                    a.f_padt = pt1; a.f_padb = pb1; a.f_erow0 = (int)rrows;
+                } else {
                 const dim3 rgrid((unsigned)std::min<long long>((rtot + 255) / 256, 4096));
                 const size_t rlds = (size_t)R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4;
                 const bool no_rows = (c->diag & ISS_DIAG_NO_FLROWS) != 0;             // diagnostic: the per-output kernel
@@ -1234,10 +1393,11 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                     hipLaunchKernelGGL((first_layer_raw_kernel<0, 0>), rgrid, dim3(256), rlds, c->stream, (const float*)c->mspec.p, rmin, rtot,
                                        R1[ISS_C_WO], R1[ISS_C_COUT], R1[ISS_C_KH], R1[ISS_C_KW],
                                        (const float*)(n.d_blob + R1[ISS_C_WOFF]), n.kpad[pend], Rraw);
+                }
                 iss_prof_end(c);
                 a.in = Rraw; a.win_row = d_winrow; a.stats = d_stats; a.finite = d_fin;
                 a.f_bias = n.d_blob + R1[ISS_C_BOFF];
-                a.f_wsum = n.d_wsum + n.wsum_off[pend];
+                a.f_wsum = fs1 ? n.d_wsum + n.wsumx_off[pend] : n.d_wsum + n.wsum_off[pend];
                 a.f_ps = R1[ISS_C_PSOFF] >= 0 ? n.d_blob + R1[ISS_C_PSOFF] : nullptr;
                 a.f_pt = R1[ISS_C_PTOFF] >= 0 ? n.d_blob + R1[ISS_C_PTOFF] : nullptr;
                 a.f_act = R1[ISS_C_ACT]; a.f_rmin = rmin;
@@ -1268,7 +1428,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const unsigned ny = (unsigned)(a.Cout / (2 * BN));
             const dim3 g2(std::min<unsigned>(ngroups, std::max(1u, 256u / ny)), ny);
             {   // template arguments as iss_ws_launch_nh2_3x3* pick them: <KH,KW,PADDED,TR,FUSED,NH,EPI>
-                const bool trn = padded || (a.pp == 1 && a.Cout % 4 == 0);
+                const bool trn = (padded && !nh2_pad_pool) || (a.pp == 1 && a.Cout % 4 == 0);
                 const int epi = padded ? 1 : (trn ? issk::epi_is_simple_tr(a) : issk::epi_is_pool_relu(a));
                 iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,%s,false,2,%d>", a.H_k, a.kw, padded ? "true" : "false", trn ? "true" : "false", epi);
             }
@@ -1297,13 +1457,25 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 iss_prof_inst(c, "conv_x3_wq3_kernel<%d>", wq3_kind);
                 issk::iss_wq3_launch(a, qgrid, c->stream, wq3_kind);
             } else
-            if (padded) issk::iss_ws_launch_nh2_3x3_padded(a, g2, c->stream);
+            if (padded && nh2_pad_pool) issk::iss_ws_launch_nh2_3x3_padded_pool(a, g2, c->stream);
+            else if (padded) issk::iss_ws_launch_nh2_3x3_padded(a, g2, c->stream);
             else issk::iss_ws_launch_nh2_3x3(a, g2, c->stream, a.pp == 1 && a.Cout % 4 == 0);
         } else if (ws_plain) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const unsigned per_n = std::max(1u, 256u / grid.y);                   // one 512-thread workgroup per CU in total
             iss_prof_inst(c, "conv_x3_ws_kernel<3,3,true,true,false,1,%d>", (int)issk::epi_is_simple_tr(a));
             issk::iss_ws_launch_plain_3x3(a, dim3(std::min<unsigned>(ngroups, per_n), grid.y), c->stream);
+        } else if (ws && ws_ring) {
+            const unsigned ngroups = (unsigned)((a.M + a.tmr - 1) / a.tmr);      // one tile of tmr rows per group
+            const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);
+            iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,false,true,1,%d,ring>", a.H_k, a.kw, padded ? "true" : "false", (int)issk::epi_is_pool_relu(a));
+            issk::iss_ws_launch_ring_7x7(a, wgrid, c->stream, padded);
+        } else if (ws && ws_fs) {
+            const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
+            const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);
+            iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,false,true,1,%d,fs>", a.H_k, a.kw, padded ? "true" : "false", (int)issk::epi_is_pool_relu(a));
+            if (a.H_k == 5) issk::iss_ws_launch_fs_5x3(a, wgrid, c->stream, padded);
+            else issk::iss_ws_launch_fs_3x3(a, wgrid, c->stream, padded);
         } else if (ws) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);         // persistent: one 512-thread workgroup per CU

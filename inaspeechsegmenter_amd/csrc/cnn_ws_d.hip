@@ -6,6 +6,10 @@ namespace issk {
 void iss_ws_launch_nh2_3x3_padded(const ConvArgs& a, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, true, true, false, 2, 1>), grid, dim3(512), 0, st, a);
 }
+// zero-padded + relu + fused non-overlapping max-pool (a 'same' 3x3 layer in front of a pool: VGG-style stacks), row-major epilogue
+void iss_ws_launch_nh2_3x3_padded_pool(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, true, false, false, 2, 1>), grid, dim3(512), 0, st, a);
+}
 void iss_ws_launch_nh2_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool tr) {
     if (tr && epi_is_simple_tr(a)) hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, false, true, false, 2, 1>), grid, dim3(512), 0, st, a);
     else if (tr) hipLaunchKernelGGL((conv_x3_ws_kernel<3, 3, false, true, false, 2>), grid, dim3(512), 0, st, a);

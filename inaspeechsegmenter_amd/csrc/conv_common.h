@@ -61,6 +61,10 @@ struct ConvArgs {
     const float* f_pt;
     int f_act;               // first layer activation: 0 none, 1 relu
     int f_rmin;              // log-mel row of `in`'s first row
+    // zero-padded ('same') first layer (conv_x3_ws_kernel<..., FS>): f_wsum is then the table S[W][Cin] of weight sums over the
+    // filter columns that see data at column x; the first f_padt / last f_padb rows of window b are rows f_erow0 + b * (f_padt + f_padb) + e
+    // of `in` (first_layer_edge_kernel), every other row y of a window whose first log-mel row is wr is row wr + y - f_rmin
+    int f_padt, f_padb, f_erow0;
     // exact division of 0 <= n < 2^31 by pp, pw, Hq*Wq, Wq as mulhi + shift (Granlund-Montgomery, N = 31): the footprint
     // kernel decomposes three GEMM rows per tile, and hipcc expands a 32-bit division by a run-time value into ~28 VALU ops
     unsigned dv_mul[4];

@@ -44,6 +44,8 @@ constexpr int F2_CH = 16;                         // channels per chunk (one k16
 typedef const bf16x8 __attribute__((address_space(3)))* LdsR16;
 typedef bf16x4 __attribute__((address_space(3)))* LdsW8;
 typedef unsigned __attribute__((address_space(3)))* LdsW4;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 __attribute__((address_space(3)))* LdsF4;
 
 // geometry parameters (row decomposition of a tile): loaded from the kernel-argument segment once per tile
 struct GeoArgs {
@@ -65,8 +67,25 @@ constexpr int WS_G = 2;                            // tiles per group (NH = 1)
 constexpr int WS_PIX = 896;                        // footprint capacity in pixels, NH = 1 (host-validated per launch)
 constexpr int WS_PIX2 = 1024;                      // footprint capacity, NH = 2 (9-tap layers: 18 x 4 KB of weights beside it)
 constexpr int WS_MAXNT = 16;                       // taps: NT x 4 KB of weights + the footprint must fit 160 KB of LDS
-constexpr int ws_pix(int nh) { return nh == 2 ? WS_PIX2 : WS_PIX; }
-constexpr int ws_lds_bytes(int nt, int nh) { return (ws_pix(nh) + 1) * F2_ROW + nt * nh * F2_BST; }
+// RING (filters with more than WS_MAXNT taps, e.g. 7x7 = 49; NH = 1 only): the weights of a 16-channel chunk do not fit LDS at
+// once (49 x 4 KB), so the taps are taken in groups of TG and the resident weights become a ring of two halves of TG tiles:
+// group k lives in half k % 2, and while a wave runs the steps of group k the tiles of group k + 1 land in the other half
+// (LDS-DMA, issued right behind the barrier that retires group k - 1 -- one barrier per TG steps = 12 TG MFMAs per wave,
+// where conv_x3_fp_kernel's per-tap ring pays one per 12).  TG is the largest value <= 9 that gives an EVEN number of groups,
+// so that every block starts with group 0 in half 0 and all ring slots stay compile-time constants.  One 512-row tile per
+// group and the 1024-pixel footprint of NH = 2 (a 512-row tile under a 7-row filter spans 920-1020 pixels).
+constexpr bool ws_ring(int nt) { return nt > WS_MAXNT; }
+constexpr int ws_tg(int nt) {
+    for (int tg = 9; tg >= 5; --tg)
+        if (((nt + tg - 1) / tg) % 2 == 0) return tg;
+    return 0;
+}
+constexpr int ws_pix(int nh, int nt = 0) { return (nh == 2 || ws_ring(nt)) ? WS_PIX2 : WS_PIX; }
+constexpr int ws_resident(int nt, int nh) { return ws_ring(nt) ? 2 * ws_tg(nt) : nt * nh; }      // 4 KB weight tiles kept in LDS
+constexpr int WS_STAB = 8192;                     // FS: bytes of the first layer's per-column weight-sum table S[W][Cin] (f32)
+constexpr int ws_lds_bytes(int nt, int nh, bool fs = false) {
+    return (ws_pix(nh, nt) + 1) * F2_ROW + ws_resident(nt, nh) * F2_BST + (fs ? WS_STAB : 0);
+}
 
 // NH = 2 (layers with >= 128 output channels, not first-layer-fused): the workgroup computes TWO 64-column halves of ONE
 // 512-row tile per group instead of one half of two tiles -- the same eight accumulators, indexed (half, row block, column
@@ -77,21 +96,35 @@ constexpr int ws_lds_bytes(int nt, int nh) { return (ws_pix(nh) + 1) * F2_ROW + 
 // off conv_x3_fp_kernel (8 KB weight ring, a barrier per 12 MFMAs, 12 reads per 12 MFMAs: 42 / 55 % matrix-pipe occupancy).
 // EPI = 1: the pooled relu epilogue only (epilogue_pool_relu; TR: bias + optional relu only, epilogue_tr<.., SIMPLE>); host-checked.
 // EPI = 0: the generic ones.
-template <int KH, int KW, bool PADDED, bool TR, bool FUSED, int NH = 1, int EPI = 0>
+// FS (FUSED only): the first layer in front of this convolution is zero-PADDED ('same').  Its padding is applied to the
+// z-normalised window, i.e. a padded position is worth the window's mean in raw log-mel units, so two things depend on where a
+// first-layer output sits in its window: (i) its COLUMN x decides which filter columns saw data -- the weight sum of the
+// per-window affine map becomes a table S[x][c] (ConvArgs::f_wsum, [W][Cin] f32, <= 8 KB, kept in LDS; two FMAs per value
+// instead of one); (ii) the first f_padt / last f_padb ROWS of a window saw fewer filter rows: those few rows are not shared between
+// windows -- first_layer_edge_kernel writes them per window, already corrected so that the SAME affine map applies
+// (E = partial sum + mean_b * (S - S_partial)), behind the shared rows in `in`, and only their address differs in the fetch.
+template <int KH, int KW, bool PADDED, bool TR, bool FUSED, int NH = 1, int EPI = 0, bool FS = false>
 __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     constexpr int NT = KH * KW;
-    constexpr int NV = NT * NH;                      // virtual steps per block = resident 4 KB weight tiles
-    constexpr int G = NH == 2 ? 1 : WS_G;            // tiles per group
-    constexpr int PIX = ws_pix(NH);
+    constexpr int NV = NT * NH;                      // virtual steps per block
+    constexpr bool RING = ws_ring(NT);               // more taps than resident weight tiles: ring of two tap groups (see ws_tg)
+    constexpr int TG = RING ? ws_tg(NT) : NV;        // steps per tap group
+    constexpr int NG = RING ? (NV + TG - 1) / TG : 1;
+    constexpr int NRES = ws_resident(NT, NH);        // resident 4 KB weight tiles
+    constexpr int G = (NH == 2 || RING) ? 1 : WS_G;  // tiles per group
+    constexpr int PIX = ws_pix(NH, NT);
     constexpr int WS_ZERO = PIX * F2_ROW;            // byte offset of the all-zero pixel behind the footprint
     constexpr int WS_NFV = PIX / 128;                // 128-pixel slices per footprint: 512 threads x 4 channels each
-    static_assert(NT >= 8 && NT <= WS_MAXNT && (NH == 1 || (NH == 2 && !FUSED)), "");
-    static_assert(ws_lds_bytes(NT, NH) <= 160 * 1024, "");
-    // [NV weight tiles][footprint]: the weights first, so that (lane base + step * 4096 + plane / half offset) stays an
-    // immediate offset of ds_read for the first 16 tiles and the steps share ONE address register
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[ws_lds_bytes(NT, NH)];
+    static_assert(NT >= 8 && (NH == 1 || (NH == 2 && !FUSED && !RING)) && (!FS || FUSED), "");
+    static_assert(!RING || (TG >= 5 && NG % 2 == 0 && NG >= 2), "");
+    static_assert(ws_lds_bytes(NT, NH, FS) <= 160 * 1024, "");
+    // [resident weight tiles][footprint][FS: S table]: the weights first, so that (lane base + slot * 4096 + plane / half offset)
+    // stays an immediate offset of ds_read for the first 16 tiles and the steps share ONE address register
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[ws_lds_bytes(NT, NH, FS)];
     const unsigned sB_base = (unsigned)(size_t)smem;
-    const unsigned sF_base = sB_base + NV * F2_BST;
+    const unsigned sF_base = sB_base + NRES * F2_BST;
+    const unsigned sS_base = sF_base + (unsigned)((PIX + 1) * F2_ROW);
+    auto slot_of = [](int v) { return RING ? ((v / TG) & 1) * TG + v % TG : v; };      // LDS slot of weight tile v
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
@@ -100,7 +133,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     const int M = (int)p.M;
     int totpix;                                      // samples * H * W
     { const int spp = p.Hq * p.Wq * p.pp; totpix = (int)(p.img_stride / p.Cin) * (M / spp); }
-    const int ntiles = (M + WS_TM - 1) / WS_TM;
+    // RING: the host picks the rows per tile (ConvArgs::tmr <= 512, a multiple of 4) so that a tile's footprint fits PIX pixels under a
+    // tall filter; the rows of a tile beyond tmr are computed on clamped addresses and not stored
+    const int TMR = RING ? p.tmr : WS_TM;
+    const int ntiles = (M + TMR - 1) / TMR;
     const int ngroups = (ntiles + G - 1) / G;
     int grp = (int)blockIdx.x;
     if (grp >= ngroups) return;
@@ -120,34 +156,35 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     auto clamp_tile = [&](int t) { return t < ntiles ? t : ntiles - 1; };
     auto geo_uniform = [&](const GeoArgs& ga, int tile) {
         TGeo u;
-        const int m0 = clamp_tile(tile) * WS_TM;
+        const int m0 = clamp_tile(tile) * TMR;
         int b, oy, ox;
         map_row32(ga, m0, b, oy, ox);
         u.p_lo = (b * ga.H + (oy * ga.sh - ga.pt_)) * ga.W + (ox * ga.sw - ga.pl_);
         u.fy = oy * ga.sh - ga.pt_; u.fx = ox * ga.sw - ga.pl_; u.wb = b;     // (negative for the padding rows / pixels)
-        const int ml = m0 + WS_TM - 1 < M - 1 ? m0 + WS_TM - 1 : M - 1;
+        const int ml = m0 + TMR - 1 < M - 1 ? m0 + TMR - 1 : M - 1;
         int b2, oy2, ox2;
         map_row32(ga, ml, b2, oy2, ox2);
         u.need = (b2 * ga.H + (oy2 * ga.sh - ga.pt_ + KH - 1)) * ga.W + (ox2 * ga.sw - ga.pl_ + KW - 1) - u.p_lo + 1;
         return u;
     };
-    auto geo_lane = [&](const GeoArgs& ga, int tile, int rb, const TGeo& u, int& lanepix, unsigned& vmask) {   // lanepix: see read_a
-        const int m0 = clamp_tile(tile) * WS_TM;
+    using VMask = typename std::conditional<(NT > 32), unsigned long long, unsigned>::type;      // one validity bit per tap
+    auto geo_lane = [&](const GeoArgs& ga, int tile, int rb, const TGeo& u, int& lanepix, VMask& vmask) {   // lanepix: see read_a
+        const int m0 = clamp_tile(tile) * TMR;
         const int m = m0 + (wv * 2 + rb) * 32 + li;
         int b, oy, ox;
-        map_row32(ga, m < M ? m : m0, b, oy, ox);
+        map_row32(ga, (m < M && (!RING || m < m0 + TMR)) ? m : m0, b, oy, ox);
         const int iy0 = oy * ga.sh - ga.pt_, ix0 = ox * ga.sw - ga.pl_;
         const int lp = (b * ga.H + iy0) * ga.W + ix0 - u.p_lo;
         const int hi = PIX - 1 - ((KH - 1) * ga.W + (KW - 1));       // keeps every tap of a row >= M inside the buffer
         lanepix = (int)sF_base + (lp < 0 ? 0 : (lp > hi ? hi : lp)) * F2_ROW + lh * 16;      // LDS byte address of the lane's first tap
-        vmask = 0xffffffffu;
+        vmask = ~(VMask)0;
         if (PADDED) {
-            unsigned vm = 0;
+            VMask vm = 0;
 #pragma unroll
             for (int ky = 0; ky < KH; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx)
-                    vm |= ((unsigned)(iy0 + ky) < (unsigned)ga.H && (unsigned)(ix0 + kx) < (unsigned)ga.W) ? 1u << (ky * KW + kx) : 0u;
+                    vm |= ((unsigned)(iy0 + ky) < (unsigned)ga.H && (unsigned)(ix0 + kx) < (unsigned)ga.W) ? (VMask)1 << (ky * KW + kx) : (VMask)0;
             vmask = vm;
         }
     };
@@ -196,8 +233,14 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
             if (i < 4 * NV && (i >> 2) >= v_lo && (i >> 2) < v_hi) {
                 const int v = i >> 2;                // weight tile: tap v / NH (column half v % NH == w_ch)
                 const uint16_t* src = (w_plane ? p.wl : p.wh) + ((v / NH) * p.Cin + c0);
+                if (RING) {                          // (the 49-step form ran out of SGPRs and kept this uniform address in VGPRs: back into an SGPR pair)
+                    const unsigned long long a64 = (unsigned long long)src;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a64);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a64 >> 32));
+                    src = (const uint16_t*)(((unsigned long long)hi << 32) | lo);
+                }
                 glds16(src, boff_w,
-                       (unsigned)__builtin_amdgcn_readfirstlane((int)(sB_base + v * F2_BST + w_plane * 2048 + w_half * 1024)));
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)(sB_base + slot_of(v) * F2_BST + w_plane * 2048 + w_half * 1024)));
             }
         }
     };
@@ -212,13 +255,22 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     Win wx = {}, wpend = {};                         // windows of the footprint being built (settled) / of the one after it (pending)
     const int magicW = (65536 + p.W - 1) / p.W;      // x / W == (x * magicW) >> 16 for x < 65536 / W (host-checked for FUSED)
     const unsigned cin4 = (unsigned)p.Cin * 4u, cg16 = (unsigned)cg * 16u;         // byte strides (32-bit offsets from a uniform base)
+    int fs_x0 = 0;                                   // FS: flattened (y * W + x) position of this thread's slice-0 pixel in its window
+    unsigned fs_sc = 0;                              // FS: LDS address of S[0][c0 + 4 cg] for the chunk being built
     auto fetch_block = [&](const TGeo& u, int c0) {  // all loads of one footprint chunk (FUSED: with wx = its windows' scalars)
         if (FUSED) {
             const unsigned o = (unsigned)(c0 + cg * 4);
-            fsw = *reinterpret_cast<const float4*>(p.f_wsum + o);
+            if (!FS) fsw = *reinterpret_cast<const float4*>(p.f_wsum + o);
             fbw = *reinterpret_cast<const float4*>(p.f_bias + o);
+            if (FS) { fs_x0 = u.fy * p.W + u.fx + prow; fs_sc = sS_base + o * 4u; }
         }
         dbmask = 0;
+        int f_padt = 0, f_ne = 0, f_ybot = 0, f_erow0 = 0;      // FS: through the kernel-argument pointer (not resident in SGPRs)
+        if (FS) {
+            KArg qa = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(qa));
+            f_padt = qa->f_padt; f_ne = f_padt + qa->f_padb; f_ybot = qa->H - qa->f_padb; f_erow0 = qa->f_erow0;
+        }
 #pragma unroll
         for (int q = 0; q < WS_NFV; ++q) {
             const int qq = 128 * q < u.need ? q : 0; // unneeded slices re-load slice 0
@@ -234,7 +286,14 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                 const bool second = y >= p.H;
                 y -= second ? p.H : 0;
                 dbmask |= second ? 1u << q : 0u;
-                const int row = y + (second ? wx.wr1 : wx.wr0) - p.f_rmin;
+                int row = y + (second ? wx.wr1 : wx.wr0) - p.f_rmin;
+                if (FS) {                            // the first f_padt / last f_padb rows of a window: its own edge rows behind the shared ones
+                    const int yb = y - f_ybot;
+                    const int e = y < f_padt ? y : (yb >= 0 ? f_padt + yb : -1);
+                    int bw = u.wb + (second ? 1 : 0);
+                    bw = bw < nwin ? bw : nwin - 1;
+                    row = e >= 0 ? f_erow0 + bw * f_ne + e : row;
+                }
                 fv[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.in + c0) + ((unsigned)(row * p.W + x) * cin4 + cg16));
             } else {
                 int gp = u.p_lo + prow + 128 * qq;
@@ -245,12 +304,15 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     };
     const float f_lob = p.f_act == 1 ? 0.f : -INFINITY;
     float t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f}, rs0 = 0.f, rs1 = 0.f;
+    float fs_mr0 = 0.f, fs_mr1 = 0.f;               // FS: -mean / std of the two windows (the shift is fma(S[x][c], mr, bias) per value)
     auto conv_consts = [&]() {
         if (!FUSED) return;
-        asm volatile("" : "+v"(fsw.x), "+v"(fsw.y), "+v"(fsw.z), "+v"(fsw.w), "+v"(fbw.x), "+v"(fbw.y), "+v"(fbw.z), "+v"(fbw.w));
+        if (FS) asm volatile("" : "+v"(fbw.x), "+v"(fbw.y), "+v"(fbw.z), "+v"(fbw.w));
+        else asm volatile("" : "+v"(fsw.x), "+v"(fsw.y), "+v"(fsw.z), "+v"(fsw.w), "+v"(fbw.x), "+v"(fbw.y), "+v"(fbw.z), "+v"(fbw.w));
         rs0 = wx.live0 ? 1.0f / wx.sd0 : 0.f;
         rs1 = wx.live1 ? 1.0f / wx.sd1 : 0.f;
         const float mr0 = wx.live0 ? -wx.mean0 * rs0 : 0.f, mr1 = wx.live1 ? -wx.mean1 * rs1 : 0.f;
+        if (FS) { fs_mr0 = mr0; fs_mr1 = mr1; return; }
         const float sw[4] = {fsw.x, fsw.y, fsw.z, fsw.w}, bw[4] = {fbw.x, fbw.y, fbw.z, fbw.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { t0[i] = fmaf(sw[i], mr0, bw[i]); t1[i] = fmaf(sw[i], mr1, bw[i]); }
@@ -263,7 +325,21 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     auto convert_slice = [&](int q) {                // q: compile-time
         float4 v = fv[q];
         asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(dbmask));    // not before this point (see fetch_block)
-        if (FUSED) {
+        if (FUSED && FS) {
+            // column of this slice's pixel -> its row of the S table (the position inside the window wraps at W; a pixel of the
+            // second window has the same column arithmetic because windows are whole rows)
+            int xf = fs_x0;
+            asm volatile("" : "+v"(xf));             // computed HERE, per slice: hoisted to the fetch it costs a live register per slice
+            xf += 128 * q;
+            xf = PADDED && xf < 0 ? 0 : xf;
+            const int xx = xf - ((xf * magicW) >> 16) * p.W;
+            const f32x4 sv = *(LdsF4)(fs_sc + (unsigned)xx * cin4);
+            const bool second = (dbmask >> q) & 1u;
+            const float sc = second ? rs1 : rs0, mr = second ? fs_mr1 : fs_mr0;
+            v = make_float4(fmaf(v.x, sc, fmaf(sv.x, mr, fbw.x)), fmaf(v.y, sc, fmaf(sv.y, mr, fbw.y)),
+                            fmaf(v.z, sc, fmaf(sv.z, mr, fbw.z)), fmaf(v.w, sc, fmaf(sv.w, mr, fbw.w)));
+            v.x = fmaxf(v.x, f_lob); v.y = fmaxf(v.y, f_lob); v.z = fmaxf(v.z, f_lob); v.w = fmaxf(v.w, f_lob);
+        } else if (FUSED) {
             const bool second = (dbmask >> q) & 1u;
             const float sc = second ? rs1 : rs0;
             v = make_float4(fmaf(v.x, sc, second ? t1[0] : t0[0]), fmaf(v.y, sc, second ? t1[1] : t0[1]),
@@ -304,9 +380,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     const unsigned row_step = (unsigned)((p.W - (KW - 1)) * F2_ROW);    // from the last tap of a filter row to the first of the next
     // `cur` walks the taps: + 80 bytes within a filter row, + row_step at the end of one (a loop-carried value, so hipcc
     // cannot materialise all KH * KW addresses of a tile at once)
-    auto read_a = [&](AFr& f, unsigned cur, unsigned vmask, int tap) {                   // tap: compile-time
+    auto read_a = [&](AFr& f, unsigned cur, VMask vmask, int tap) {                   // tap: compile-time
         unsigned a = cur;
-        if (PADDED) a = (vmask >> tap) & 1u ? a : zbase;
+        if (PADDED) a = ((vmask >> tap) & (VMask)1) ? a : zbase;
         f.h = *(LdsR16)(a);
         f.l = *(LdsR16)(a + 32);
     };
@@ -315,12 +391,12 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
         return cur + ((tap + 1) % KW == 0 ? row_step : (unsigned)F2_ROW);
     };
     auto read_bh = [&](BH& f, int tap) {             // hi plane of the tap's weight tile
-        const unsigned a = bread + (unsigned)(tap * F2_BST);
+        const unsigned a = bread + (unsigned)(slot_of(tap) * F2_BST);
         f.b0 = *(LdsR16)(a);
         f.b1 = *(LdsR16)(a + 1024);
     };
     auto read_bl = [&](BH& f, int tap) {             // lo plane
-        const unsigned a = bread + (unsigned)(tap * F2_BST);
+        const unsigned a = bread + (unsigned)(slot_of(tap) * F2_BST);
         f.b0 = *(LdsR16)(a + 2048);
         f.b1 = *(LdsR16)(a + 3072);
     };
@@ -360,13 +436,21 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     // barrier there, and the next chunk's tiles [0, VB) are in flight for the rest of the block instead of being waited for
     // at the boundary.  Only when that buys at least two steps.
     constexpr int VB = CS + (WS_NFV - 1) * CSTRIDE + 1;
-    constexpr bool EARLY_W = ISS_EARLY && VB + 2 <= NV;
+    constexpr bool EARLY_W = ISS_EARLY && !RING && VB + 2 <= NV;
 
     // ---- prologue: zero pixels; geometry of the first group; its first footprint converted serially
     if (tid < F2_ROW / 4) *(LdsW4)(sF_base + (unsigned)(WS_ZERO + tid * 4)) = 0u;
+    if (FS) {                                        // S[x][c] (host-checked: W * Cin * 4 <= WS_STAB)
+        for (int i = tid; i < p.W * p.Cin / 4; i += 512) {
+            const float4 sw4 = reinterpret_cast<const float4*>(p.f_wsum)[i];
+            f32x4 sv; sv.x = sw4.x; sv.y = sw4.y; sv.z = sw4.z; sv.w = sw4.w;
+            *(LdsF4)(sS_base + (unsigned)i * 16u) = sv;
+        }
+        __syncthreads();                             // the serial conversion of the first footprint below reads it
+    }
     TGeo ug[G + 2];                                  // the group's tiles + the next group's first two tiles
     int lanepix[G][2];
-    unsigned vmask[G][2];
+    VMask vmask[G][2];
     auto group_geometry = [&](int g0) {
         const GeoArgs ga = geo_args();
 #pragma unroll
@@ -395,6 +479,11 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     bool first_chunk = true;
     for (; grp < ngroups; grp += gstep) {
         const bool last_group = grp + gstep >= ngroups;
+        if (G == 1 && FUSED) {                       // the windows of the next group's tile are requested two blocks ahead (un2)
+            if (!last_group) ug[G] = geo_uniform(geo_args(), (grp + gstep) * G);
+            else ug[G] = ug[0];
+            ug[G + 1] = ug[G];
+        }
         for (int ch = 0; ch < nchunk; ++ch) {
             const int c0 = ch * F2_CH;
             const bool last_chunk = ch + 1 == nchunk;
@@ -402,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
             // block (behind its first barrier, in flight while the footprint is written); only the very first chunk of the
             // workgroup loads them here.  The geometry of the next group's first tiles is computed here.
             const bool fc = first_chunk;
-            if (fc) { load_weights(c0, 0, NV); first_chunk = false; }
+            if (fc) { load_weights(c0, 0, RING ? 2 * TG : NV); first_chunk = false; }
             if (last_chunk) {
                 if (!last_group) {
                     const GeoArgs ga = geo_args();
@@ -417,7 +506,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                                  floatx16& d00, floatx16& d01, floatx16& d10, floatx16& d11) __attribute__((always_inline)) {
                 // the footprint this block builds (for the block after it) and the one after that (whose windows it loads)
                 const TGeo un = t + 1 < G ? ug[t + 1] : (last_chunk ? ug[G] : ug[0]);
-                const TGeo un2 = t + 2 < G ? ug[t + 2] : (last_chunk ? ug[t + 2] : ug[t + 2 - G]);
+                // (G == 1: the block after the next one is this tile's chunk ch + 2, or -- from the second-to-last chunk on -- the
+                //  next group's tile, whose geometry ug[G] holds from the start of the group)
+                const TGeo un2 = G == 1 ? (ch + 2 < nchunk ? ug[0] : ug[G])
+                                        : (t + 2 < G ? ug[t + 2] : (last_chunk ? ug[t + 2] : ug[t + 2 - G]));
                 const int nc0 = t + 1 < G ? c0 : (last_chunk ? 0 : c0 + F2_CH);
                 // Per virtual step (tap, column half): 12 MFMAs on two row blocks x two column blocks, in three groups ordered
                 // a.l * b.h, a.h * b.h, a.h * b.l.  Fragment reads: the A fragments of the next TAP (double-buffered) behind the
@@ -458,6 +550,17 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                     if (half == 0) { mfma2(a0.h, bh, c00, c01); mfma2(a1.h, bh, c10, c11); }
                     else { mfma2(a0.h, bh, d00, d01); mfma2(a1.h, bh, d10, d11); }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (RING && (v + 1) % TG == 0 && v + 1 < NV) {
+                        // last step of tap group k - 1: the fragments of this step are in registers on every wave once all have
+                        // passed the barrier, so the half that held group k - 1 is dead -- group k + 1 (or the next block's
+                        // group 0) goes there; group k, whose first fragments are read right below, was issued TG steps ago
+                        const int k = (v + 1) / TG;
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // group k landed; this step's lo fragments arrived
+                        __builtin_amdgcn_s_barrier();
+                        if (k + 1 < NG) load_weights(c0, (k + 1) * TG, (k + 2) * TG < NV ? (k + 2) * TG : NV);
+                        else load_weights(nc0, 0, TG);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (v + 1 < NV) read_bh(bh, v + 1);
 #pragma unroll
                     for (int q = 0; q < WS_NFV; ++q)
@@ -470,12 +573,17 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                     // every wave has read its last fragments of this footprint (and of the weights)
-                if (t + 1 == G) load_weights(nc0, EARLY_W ? VB : 0, NV);   // the (rest of the) next chunk's weights fly while the footprint is written
+                if (RING) load_weights(nc0, TG, 2 * TG);                // next block's group 1 into half 1 (group NG - 1 is done with it)
+                else if (t + 1 == G) load_weights(nc0, EARLY_W ? VB : 0, NV);   // the (rest of the) next chunk's weights fly while the footprint is written
                 write_footprint();
-                if (t + 1 == G) wait_vmcnt<0>();
+                // RING: the next block's group 0 (issued at the last refresh point) must have landed; its group 1 -- at least
+                // 4 TG / 8 LDS-DMA pieces per wave, just issued, completing in order behind it -- is waited for at step TG - 1
+                if (RING) wait_vmcnt<(4 * TG) / 8>();
+                else if (t + 1 == G) wait_vmcnt<0>();
                 __syncthreads();
             };
             if (NH == 2) run_block(0, acc000, acc001, acc010, acc011, acc100, acc101, acc110, acc111);
+            else if (G == 1) run_block(0, acc000, acc001, acc010, acc011, acc000, acc001, acc010, acc011);      // RING: one tile per group
             else {
                 run_block(0, acc000, acc001, acc010, acc011, acc000, acc001, acc010, acc011);
                 run_block(1, acc100, acc101, acc110, acc111, acc100, acc101, acc110, acc111);
@@ -492,7 +600,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
             auto finish = [&](const int t, const int rb, floatx16& c0acc, floatx16& c1acc) __attribute__((always_inline)) {
                 const int tile = NH == 2 ? grp : grp * G + t;
                 const int nc = NH == 2 ? n0 + BN * t : n0;
-                const long long row0 = (long long)tile * WS_TM + (wv * 2 + rb) * 32;
+                const long long row0 = (long long)tile * TMR + (wv * 2 + rb) * 32;
+                if (RING) { const long long mend = (long long)tile * TMR + TMR; e.M = mend < (long long)M ? mend : (long long)M; }
                 if (tile < ntiles) {
                     if (TR && EPI == 1) epilogue_tr<false, EpiArgs, true>(e, c0acc, c1acc, row0 + li, nc, lh);
                     else if (TR) epilogue_tr(e, c0acc, c1acc, row0 + li, nc, lh);
@@ -508,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                 for (int i = 0; i < 16; ++i) { c0acc[i] = 0.f; c1acc[i] = 0.f; }
             };
             finish(0, 0, acc000, acc001); finish(0, 1, acc010, acc011);
-            finish(1, 0, acc100, acc101); finish(1, 1, acc110, acc111);
+            if (NH == 2 || G == 2) { finish(1, 0, acc100, acc101); finish(1, 1, acc110, acc111); }
         }
         if (!last_group) {
             group_geometry(grp + gstep);
@@ -536,6 +645,22 @@ void launch_ws_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, 
     }
 }
 
+// Ring form (more than WS_MAXNT taps): first-layer-fused, row-major epilogue only (cnn_ws_e.hip)
+inline bool iss_ws_ring_compiled(int kh, int kw) { return kh == 7 && kw == 7; }
+void iss_ws_launch_ring_7x7(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded);
+// FS form (zero-padded first layer in front): first-layer-fused, row-major epilogue only (cnn_ws_f.hip, cnn_ws_g.hip)
+inline bool iss_ws_fs_compiled(int kh, int kw) { return (kh == 5 && kw == 3) || (kh == 3 && kw == 3); }
+void iss_ws_launch_fs_5x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded);
+void iss_ws_launch_fs_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded);
+template <int KH, int KW, bool FS_>
+void launch_ws_fused_rowmajor(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded) {
+    const bool fast = epi_is_pool_relu(a);
+#define ISS_WS_LAUNCH2(P_, E_) hipLaunchKernelGGL((conv_x3_ws_kernel<KH, KW, P_, false, true, 1, E_, FS_>), grid, dim3(512), 0, st, a)
+    if (padded) { if (fast) ISS_WS_LAUNCH2(true, 1); else ISS_WS_LAUNCH2(true, 0); }
+    else { if (fast) ISS_WS_LAUNCH2(false, 1); else ISS_WS_LAUNCH2(false, 0); }
+#undef ISS_WS_LAUNCH2
+}
+
 // Plain (not first-layer-fused) use of the kernel: zero-padded 3x3 stride-1 layers whose 128-row tile does not fit
 // conv_x3_fp_kernel's 360-pixel footprint because the image is WIDE (ResNet-101's 32 -> 32 convolutions at 64 x 144: 580
 // pixels per 128 rows, 802 per 512 rows <= WS_PIX) -- they ran on the gather kernel at 6 x their bandwidth bound.
@@ -545,6 +670,7 @@ void iss_ws_launch_plain_3x3(const ConvArgs& a, dim3 grid, hipStream_t st);     
 inline bool iss_ws_nh2_compiled(int kh, int kw) { return kh == 3 && kw == 3; }
 void iss_ws_launch_nh2_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool tr);
 void iss_ws_launch_nh2_3x3_padded(const ConvArgs& a, dim3 grid, hipStream_t st);    // transposed + simple epilogue (epi_is_simple_tr)
+void iss_ws_launch_nh2_3x3_padded_pool(const ConvArgs& a, dim3 grid, hipStream_t st);   // row-major, relu + fused max-pool (epi_is_pool_relu)
 
 }  // namespace issk
 

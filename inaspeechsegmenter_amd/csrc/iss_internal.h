@@ -25,6 +25,7 @@ struct IssNet {
     uint16_t* d_wl = nullptr;             // bf16 lo part
     float* d_wsum = nullptr;              // patch-mode first layers: sum_k w[c][k] per output channel (shared first layer)
     std::vector<int64_t> wsum_off;        // per row: offset into d_wsum, -1 = none
+    std::vector<int64_t> wsumx_off;       // per row: offset of S[W][Cout] (zero-padded first layers: per-column weight sums), -1 = none
     int64_t blob_floats = 0;
     std::vector<int64_t> w_dev_off;       // per row: offset of the padded weight matrix in d_blob
     std::vector<int32_t> kpad;            // per row: K padded to the GEMM k-tile

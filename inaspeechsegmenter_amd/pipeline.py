@@ -171,24 +171,37 @@ class _Worker:
             lsegs.append(lseg)
         st['energy_host'] += time.perf_counter() - t_
         wrs = [S._window_rows(nfr[f]) + np.int32(g0[f]) for f in range(len(lsegs))]
+        # Segmenter.dense_batches (an extension, default False): every network on EVERY slot of every file -- the most work
+        # the reference semantics can require, independent of what the networks decide (bench.py's "dense" figures); the rows
+        # of the `inlabel` segments are then picked from the full result, so the segments are the same
+        dense = bool(getattr(seg, 'dense_batches', False))
+        if dense:
+            wbase = np.concatenate(([0], np.cumsum([len(w) for w in wrs])))
+            allw = np.concatenate(wrs)
         for net in ([seg.vad, seg.gender] if seg.detect_gender else [seg.vad]):
             t_ = time.perf_counter()
             # slots of every `inlabel` segment of every file, in order (segmenter.py:156-159), in ONE device call; the
             # per-segment smoothing (:168-178) in ONE host call on np.log of the whole probability array (elementwise: the
             # same values as per-segment np.log calls); run-length encoding vectorised over the pass
-            rows, seglen = [], []
+            rows, seglen, sel = [], [], []
             for f, lseg in enumerate(lsegs):
                 wr = wrs[f]
                 for lab, start, stop in lseg:
                     if lab == net.inlabel:
                         rows.append(wr[start:stop])
                         seglen.append(stop - start)
+                        if dense:
+                            sel.append(np.arange(wbase[f] + start, wbase[f] + stop))
             if not rows:
                 st['smooth_host'] += time.perf_counter() - t_
                 continue
             allrows = np.concatenate(rows)
             st['smooth_host'] += time.perf_counter() - t_; t_ = time.perf_counter()
-            probs, _fin = ctx.cnn_probs(net.net_id, allrows)
+            if dense:
+                probs, _fin = ctx.cnn_probs(net.net_id, allw)
+                probs = probs[np.concatenate(sel)]
+            else:
+                probs, _fin = ctx.cnn_probs(net.net_id, allrows)
             st['cnn_device'] += time.perf_counter() - t_; t_ = time.perf_counter()
             with np.errstate(divide='ignore'):
                 logp = np.log(probs)

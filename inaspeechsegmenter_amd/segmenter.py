@@ -283,6 +283,7 @@ class Segmenter:
                 raise (Exception("""ffmpeg program not found"""))
         self.ffmpeg = ffmpeg
         self.energy_ratio = energy_ratio
+        self.dense_batches = False                     # extension: batch_process evaluates both networks on every slot (pipeline.py)
 
         self.ctx = _native.Context(device)
         self.ctx.sidekit_tables(tables.sidekit_window(), tables.sidekit_melbank())

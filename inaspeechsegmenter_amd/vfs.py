@@ -180,6 +180,7 @@ class VoiceFemininityScoring:
         self.features = FeatureExtractor(self.ctx)
         self.xvector_model = VBxExtractor(self.ctx, resnet)
         layers, in_shape = mlp
+        self.mlp_layers = layers                          # (kept for inspection / tests; the engine holds the compiled program)
         if len(in_shape) == 1:
             in_shape = (1, 1, in_shape[0])
         self.ctx.cnn_load(_MLP_NET, keras_model.compile_layers(layers, in_shape, patch_input=False))

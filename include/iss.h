@@ -191,7 +191,9 @@ int iss_set_precision(iss_ctx* ctx, int mode);
 #define ISS_DIAG_NO_WQ           0x400u  /* conv_x3_ws_kernel (two waves per SIMD) instead of conv_x3_wq_kernel for the fused 5x3 layer */
 #define ISS_DIAG_NO_DUAL         0x800u  /* projection shortcut + expansion as two launches (ISS_C_DUALW ignored)            */
 #define ISS_DIAG_NO_CHAIN        0x1000u /* identity-residual expansion and the next block's reduction as two launches       */
-#define ISS_DIAG_ALL             0x1fffu
+#define ISS_DIAG_NO_RING         0x2000u /* no ring form of the weight-stationary kernel (second convs with > 16 taps: gather kernel) */
+#define ISS_DIAG_NO_FSAME        0x4000u /* a zero-padded ('same') first layer is run per window, not shared between windows  */
+#define ISS_DIAG_ALL             0x7fffu
 int iss_set_diag(iss_ctx* ctx, uint32_t flags);
 
 /* FLOPs (2*MAC of the conv/dense outputs actually computed) per sample of a loaded network. */

@@ -53,6 +53,27 @@ def test_topology_parity(ctx, name):
         finally:
             ctx.set_diag(0)
         assert np.array_equal(p_old, probs) and np.array_equal(f_old, fin), (name, net, np.abs(p_old - probs).max())
+        # round-5 forms of the weight-stationary kernel: the ring form for second convs with more than 16 taps (7x7) and the
+        # shared ZERO-PADDED first layer ('same' first conv: S table + per-window edge rows).  Where a topology takes one, it
+        # must be the kernel that ran, and switching it off (gather kernel / per-window first layer) must give the same
+        # probabilities up to the summation order
+        want_new = {'conv2_7x7': 'ring>', 'conv1_same': 'fs>', 'vgg_same_3x3': 'fs>'}.get(name)
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        ctx.cnn_probs(5, rows)
+        insts = [i['kernel'] for i in ctx.prof_instances()]
+        ctx.prof_enable(False)
+        took = [k for k in insts if k.endswith('ring>') or k.endswith('fs>')]
+        assert (want_new is None and not took) or (want_new and any(k.endswith(want_new) for k in took)), (name, net, insts)
+        if took:
+            ctx.set_diag('no_ring,no_fsame')
+            try:
+                p_off, f_off = ctx.cnn_probs(5, rows)
+            finally:
+                ctx.set_diag(0)
+            d_off = np.abs(p_off - probs).max()
+            print(f'{name}/{net}: {took[0]} vs the path it replaces: max |dp| {d_off:.2e}')
+            assert np.array_equal(f_off, fin) and d_off < 5e-5, (name, net, d_off)
         scat = np.sort(rng.integers(0, T - 68, 64)).astype(np.int32)     # scattered: per-window first layer
         p2, f2 = ctx.cnn_probs(5, scat)
         r2, rf2 = _oracle_probs(layers, mspec, nmel, scat)

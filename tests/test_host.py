@@ -480,6 +480,21 @@ def test_super_batch_pipeline_equals_per_file_calls_with_fake_device(tmp_path):
             assert got[i][1] is None
             assert got[i][0] == want, (i, got[i][0][:4], want[:4])
     assert len({lab for lseg, _ in got.values() if lseg for lab, _, _ in lseg}) >= 3      # the inputs exercise several labels
+    # Segmenter.dense_batches: both networks on every slot of every file, the rows of the segments picked afterwards -- the
+    # same segments (bench.py's dense file-path figure is the same work the reference semantics could at most require)
+    first = dict(got)
+    got.clear()
+    calls = []
+    orig = fake.cnn_probs
+    fake.cnn_probs = lambda net, rows: (calls.append(len(rows)), orig(net, rows))[1]
+    seg.dense_batches = True
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pipeline.process_files(seg, paths, on_result, batch_files=3, workers=1, decode_threads=2)
+    seg.dense_batches = False
+    assert {i: v[0] for i, v in got.items() if i != 2} == {i: v[0] for i, v in first.items() if i != 2}
+    nslots = [((n - 400) // 160 + 2) // 2 for n in lengths if n != 9000]                     # P = ceil(T / 2) slots per file
+    assert sum(calls) >= 2 * sum(nslots)                                                      # every slot, both nets (+ the single-file medium)
 
 
 def test_batch_process_contract_with_fake_device(tmp_path):

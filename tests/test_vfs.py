@@ -182,5 +182,20 @@ def test_pipeline_with_stand_in_weights():
     emb = np.stack([ovbx.resnet101_forward(v.xvector_model.params, fea[a:b].T[None])[0] * 10 for _, _, (a, b) in kept[:6]])
     dev = np.stack([v.xvector_model.get_embedding(fea[a:b]) * 10 for _, _, (a, b) in kept[:6]])
     assert np.abs(dev - emb).max() <= 1e-3 * np.abs(emb).max()
+    # the gender MLP (vbx_segmenter.py:189): the device's forward of the Dense stack == the oracle's Keras-semantics forward,
+    # on the device's own x-vectors of every kept window; and the score is what the reference's statements give on them
+    from oracle import keras_cnn as ocnn, pyannote_core as pc
+    feats = v.features(sig)
+    allx = v.xvector_model('lamartine', feats, len(sig) / 16000)
+    a_vad = pc.get_annot_VAD(v.vad(wav))
+    kept_ref = pc.apply_vad(list(allx), a_vad, v.vad_thresh)               # pyannote-semantics restatement of :129-145
+    kept_dev = vfs.apply_vad(list(allx), speech, v.vad_thresh)
+    assert [(k, se) for k, se, _ in kept_dev] == [(k, se) for k, se, _ in kept_ref] and len(kept_ref) == nvec
+    X = np.asarray([x for _, _, x in kept_ref], np.float32)
+    p_dev = v.gender_predict(X).reshape(len(X), -1)[:, 0]
+    p_ora = ocnn.forward(v.mlp_layers, X.reshape(len(X), 1, 1, -1)).reshape(len(X), -1)[:, 0]
+    assert np.abs(p_dev - p_ora).max() <= 1e-4                               # probabilities; north star: logits within 1e-3
+    g = np.asarray([(se[0], se[1], p) for (_, se, _), p in zip(kept_ref, p_ora)])
+    assert score == pc.get_femininity_score(g) or np.abs(p_ora - 0.5).min() < 2e-4
     v.vad = lambda path: [('music', 0.0, 14.0)]
     assert v(wav) == (None, 0, 0)

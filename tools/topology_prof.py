@@ -17,11 +17,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('names', nargs='+')
     ap.add_argument('--minutes', type=float, default=20.0)
+    ap.add_argument('--diag', default='', help="kernel-selection switches for the run, e.g. 'no_fsame,no_ring'")
     args = ap.parse_args()
     from inaspeechsegmenter_amd import _native as N, keras_model as KM, segmenter as S
     import topologies as TP
     from test_gpu_topologies import _mspec
     ctx = N.Context(0)
+    if args.diag:
+        ctx.set_diag(args.diag)
+        print(f'# diag = {args.diag}')
     T = int(args.minutes * 6000) - 2
     ctx.set_mspec(_mspec(np.random.default_rng(7), T))
     rows = S._window_rows(T)
@@ -35,7 +39,9 @@ def main():
             ctx.cnn_probs(5, rows)
             inst = ctx.prof_instances()
             tot = sum(k['ms'] for k in inst)
-            print(f"## {name} / {net}: {tot:.2f} ms in GEMM kernels, {comp.flops_per_sample * len(rows) / 1e9:.0f} GFLOP algorithmic")
+            oth_ms, oth_n, _ = ctx.prof_get(2)
+            print(f"## {name} / {net}: {tot:.2f} ms in GEMM kernels, {comp.flops_per_sample * len(rows) / 1e9:.0f} GFLOP algorithmic; "
+                  f"{oth_ms:.2f} ms in {oth_n} other launches (shared first layer, window statistics, pools, softmax)")
             prog = np.asarray(comp.prog).reshape(-1, N.PROG_COLS)
             for i, r in enumerate(prog):
                 ms, nl = ctx.prof_get_row(i)
