@@ -201,6 +201,106 @@ def synth_recording_numpy(file_index, n_samples):
     return np.clip(np.round(out * 32768.0), -32768, 32767).astype(np.int16)
 
 
+def _cpu_full_worker(job):
+    """One process of the full-path all-cores CPU leg (1c): the WHOLE hot path on the CPU for one file -- oracle feature path,
+    energy detector, torch-CPU forward of both stand-in networks (reference semantics: VAD net on energy slots, gender net on
+    speech slots, batch 32 as segmenter.py:208), reference-order Viterbi -- with `threads` torch threads.
+    Runs as `bench.py --cpu-full-worker index nsec threads`; prints the seconds the pipeline took (imports excluded)."""
+    file_index, nsec, threads = job
+    import time as _t
+    import torch
+    torch.set_num_threads(threads)
+    from oracle import sidekit as osk, segment as oseg, keras_cnn as ocnn
+    from inaspeechsegmenter_amd import keras_model as KM
+    vad_layers, _ = KM.synthetic_ina_like(21, 3, seed=1)          # what Segmenter(models='synthetic') loads (net ids 0 / 1 -> seeds 1 / 2)
+    gen_layers, _ = KM.synthetic_ina_like(24, 2, seed=2)
+    pcm = synth_recording_numpy(file_index, nsec * FS)
+    sig = (pcm / 32768.0).astype(np.float32)
+    ocnn.forward(vad_layers, np.zeros((32, 68, 21, 1), np.float32), batch_size=32)         # thread pool / allocator warm-up
+    t0 = _t.perf_counter()
+    mspec, loge, difflen = osk.media2feats(sig)
+    lseg0 = oseg.energy_seglist(loge, 0.03)
+    lseg1 = oseg.dnn_segment('smn', lambda b: ocnn.forward(vad_layers, b, batch_size=32), mspec, lseg0, difflen)
+    oseg.dnn_segment('gender', lambda b: ocnn.forward(gen_layers, b, batch_size=32), mspec, lseg1, difflen)
+    return _t.perf_counter() - t0
+
+
+def host_cpu_info():
+    """What the host really gives this process: os.cpu_count() (hardware threads the kernel shows), the affinity mask, and the
+    cgroup CPU quota of the container -- a 256-thread node behind a 32-core quota is a 32-core host for every CPU leg."""
+    info = {"cpu_count": os.cpu_count() or 1}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info["affinity"] = info["cpu_count"]
+    quota = None
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt and txt[0] != 'max':
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    info["cgroup_quota_cores"] = quota
+    eff = min(info["cpu_count"], info["affinity"])
+    if quota:
+        eff = max(1, min(eff, int(quota + 0.5)))
+    # ... and what it measurably gives: k copies of a fixed interpreter loop at once against one copy alone (a quota, SMT siblings
+    # or neighbours on the node show up here whether or not the cgroup files are readable)
+    try:
+        import subprocess
+        k = min(info["cpu_count"], 256)
+        cmd = [sys.executable, '-S', '-c', 'import time\nt=time.perf_counter()\nx=0\nfor i in range(6000000): x+=i\nprint(time.perf_counter()-t)']
+        t1 = float(subprocess.run(cmd, capture_output=True, text=True, timeout=60).stdout.strip())
+        t0 = time.perf_counter()
+        ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(k)]
+        tk = [float(p_.communicate(timeout=120)[0].decode().strip()) for p_ in ps]
+        wall = time.perf_counter() - t0
+        info["measured_parallelism"] = {"copies": k, "one_copy_s": t1, "mean_copy_s": sum(tk) / k, "wall_s": wall,
+                                        "effective_cores": k * t1 / (sum(tk) / k)}
+        eff = max(1, min(eff, int(info["measured_parallelism"]["effective_cores"] + 0.5)))
+    except Exception as exc:                                # noqa: BLE001
+        info["measured_parallelism"] = {"error": repr(exc)}
+    info["effective_cores"] = eff
+    return info
+
+
+def cpu_full_path_all_cores_leg(cores_host, threads=8, nsec=90, budget_s=120.0):
+    """Leg 1c: cores_host / threads processes x `threads` torch threads, every process the whole CPU pipeline incl. both CNNs on
+    its own `nsec`-second synthetic file: what the host ALONE could do on this path with all of its cores."""
+    import subprocess
+    nproc = max(1, cores_host // threads)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS='1', HIP_VISIBLE_DEVICES='',
+               ROCR_VISIBLE_DEVICES='')
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-full-worker', str(2000 + i), str(nsec), str(threads)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for i in range(nproc)]
+    per, failed = [], 0
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=max(1.0, budget_s - (time.perf_counter() - t0)))
+            per.append(float(out.decode().strip().splitlines()[-1]))
+        except Exception:                                   # noqa: BLE001
+            failed += 1
+            pr.kill()
+    wall = time.perf_counter() - t0
+    if not per:
+        return {"processes": nproc, "threads_per_process": threads, "error": "no worker finished"}
+    return {"processes": nproc, "threads_per_process": threads, "cores": nproc * threads, "finished": len(per), "failed": failed,
+            "seconds_per_file": nsec, "wall_s": wall, "x_realtime_aggregate_incl_startup": len(per) * nsec / wall,
+            "x_realtime_aggregate_steady": len(per) * nsec / max(per), "x_realtime_one_process_mean": nsec / (sum(per) / len(per)),
+            "what": "the whole CPU path per process (oracle numpy features, energy detector, torch-CPU forward of both stand-in nets "
+                    "at batch 32 on reference-semantics slots, reference-order Python Viterbi), one synthetic file each, all processes "
+                    "at once on all host cores; `steady` = files x seconds / the slowest process's own pipeline time (imports and "
+                    "interpreter start-up excluded), `incl_startup` = / the wall time of the whole leg"}
+
+
 def cpu_file_parallel_leg(nproc, nsec=120, budget_s=90.0):
     """Leg 1b: `nproc` processes (`python bench.py --cpu-worker i nsec`, numpy / BLAS pinned to one thread each, no GPU), each
     running the oracle feature path + Viterbi on its own `nsec`-second synthetic file.  -> dict (x real time aggregate)."""
@@ -284,6 +384,11 @@ def cpu_baseline(seg, pcm_host, target_s=25.0):
                            "cnn_threads": threads, "cnn_batch_size": bs_best}
     # ---- leg 1b: file-parallel feature path + Viterbi on every host core
     legs["file_parallel_features_viterbi"] = cpu_file_parallel_leg(min(cores_host, 256))
+    # ---- leg 1c: the FULL path (both CNNs included) on every host core: cores / 8 processes x 8 threads
+    hinfo = host_cpu_info()
+    legs["host_cpu"] = hinfo
+    eff = min(hinfo["effective_cores"], 256)
+    legs["full_path_all_cores"] = cpu_full_path_all_cores_leg(eff, threads=8 if eff >= 8 else max(1, eff))
     if os.path.isdir('/root/reference/inaSpeechSegmenter'):      # build container only: the unmodified reference front end
         import importlib.util
         spec = importlib.util.spec_from_file_location('ref_sidekit_mfcc', '/root/reference/inaSpeechSegmenter/sidekit_mfcc.py')
@@ -808,6 +913,9 @@ def main_fake_device(args, rank, world):
 def main():
     if len(sys.argv) == 4 and sys.argv[1] == '--cpu-worker':          # one process of cpu_file_parallel_leg: numpy only, no torch
         print(_cpu_feature_worker((int(sys.argv[2]), int(sys.argv[3]))))
+        return
+    if len(sys.argv) == 5 and sys.argv[1] == '--cpu-full-worker':     # one process of cpu_full_path_all_cores_leg: torch-CPU, no GPU
+        print(_cpu_full_worker((int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))))
         return
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)

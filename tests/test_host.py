@@ -693,7 +693,7 @@ def test_oracle_is_only_used_as_the_checker():
             for f in files:
                 if f.endswith('.py'):
                     assert oracle_imports(os.path.join(dirpath, f)) == [], (dirpath, f)
-    assert {fn for fn, _ in oracle_imports(os.path.join(ROOT, 'bench.py'))} <= {'cpu_baseline', '_cpu_feature_worker', 'bench_vbx', 'parity_check'}
+    assert {fn for fn, _ in oracle_imports(os.path.join(ROOT, 'bench.py'))} <= {'cpu_baseline', '_cpu_feature_worker', '_cpu_full_worker', 'bench_vbx', 'parity_check'}
     assert {fn for fn, _ in oracle_imports(os.path.join(ROOT, '__graft_entry__.py'))} <= {'smoke'}
 
 
@@ -732,6 +732,8 @@ def test_bench_cpu_file_parallel_leg_runs_without_a_gpu():
     leg = bench.cpu_file_parallel_leg(2, nsec=4, budget_s=120.0)
     assert leg['processes'] == 2 and leg['finished'] == 2 and leg['failed'] == 0, leg
     assert leg['x_realtime_aggregate'] > 0 and leg['x_realtime_one_process_mean'] > 1.0, leg
+    full = bench.cpu_full_path_all_cores_leg(4, threads=2, nsec=4, budget_s=240.0)               # leg 1c: 2 processes x 2 threads, CNNs included
+    assert full['processes'] == 2 and full['finished'] == 2 and full['cores'] == 4 and full['x_realtime_aggregate_steady'] > 0, full
     pcm = bench.synth_recording_numpy(3, 5 * bench.FS)
     assert pcm.dtype == np.int16 and pcm.shape == (5 * bench.FS,) and np.abs(pcm).max() > 0
     assert np.array_equal(pcm, bench.synth_recording_numpy(3, 5 * bench.FS))          # seeded: the same file every time

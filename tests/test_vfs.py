@@ -193,7 +193,7 @@ def test_pipeline_with_stand_in_weights():
     assert [(k, se) for k, se, _ in kept_dev] == [(k, se) for k, se, _ in kept_ref] and len(kept_ref) == nvec
     X = np.asarray([x for _, _, x in kept_ref], np.float32)
     p_dev = v.gender_predict(X).reshape(len(X), -1)[:, 0]
-    p_ora = ocnn.forward(v.mlp_layers, X.reshape(len(X), 1, 1, -1)).reshape(len(X), -1)[:, 0]
+    p_ora = ocnn.forward([dict(type='flatten')] + list(v.mlp_layers), X.reshape(len(X), 1, 1, -1)).reshape(len(X), -1)[:, 0]
     assert np.abs(p_dev - p_ora).max() <= 1e-4                               # probabilities; north star: logits within 1e-3
     g = np.asarray([(se[0], se[1], p) for (_, se, _), p in zip(kept_ref, p_ora)])
     assert score == pc.get_femininity_score(g) or np.abs(p_ora - 0.5).min() < 2e-4
