@@ -144,7 +144,15 @@ def gemm_kernel_table(ctxs, peak_tf, pj=None):
                "flops_per_launch": fl / nl, "achieved": tf, "frac": tf / peak_tf}
         pk = _pmc_kernel(pj or {}, name)
         if pk and 'FETCH_SIZE_bytes' in pk and 'WRITE_SIZE_bytes' in pk:
-            row["traffic_per_launch_static"] = 2 * pk['FETCH_SIZE_bytes'] + pk['WRITE_SIZE_bytes']
+            raw = 2 * pk['FETCH_SIZE_bytes'] + pk['WRITE_SIZE_bytes']            # mean launch of the PMC run
+            # the PMC run is a shorter recording (rocprofv3 --pmc crashes on the hour, profiles/r05_pmc_1h_attempt.txt): its mean launch
+            # mixes full passes and a remainder in other proportions than this run's.  A launch's bytes scale with its rows like its
+            # flops do, so the PMC run's bytes per algorithmic flop x THIS run's flops per launch is this run's mean launch
+            fpl_pmc = ((pj or {}).get('pmc_run_flops_per_launch') or {}).get(name.replace(' ', ''))
+            scale = (fl / nl) / fpl_pmc if fpl_pmc else None
+            row["traffic_per_launch_pmc_run"] = raw
+            row["traffic_scale_to_this_run"] = scale
+            row["traffic_per_launch_static"] = raw * scale if scale else raw
             row["mfma_busy_frac_static"] = pk.get('mfma_busy_frac')
         rows.append(row)
     rows.sort(key=lambda r: -r["ms_per_step"])
@@ -251,6 +259,7 @@ def host_cpu_info():
     eff = min(info["cpu_count"], info["affinity"])
     if quota:
         eff = max(1, min(eff, int(quota + 0.5)))
+    quota_known = bool(quota)
     # ... and what it measurably gives: k copies of a fixed interpreter loop at once against one copy alone (a quota, SMT siblings
     # or neighbours on the node show up here whether or not the cgroup files are readable)
     try:
@@ -264,7 +273,8 @@ def host_cpu_info():
         wall = time.perf_counter() - t0
         info["measured_parallelism"] = {"copies": k, "one_copy_s": t1, "mean_copy_s": sum(tk) / k, "wall_s": wall,
                                         "effective_cores": k * t1 / (sum(tk) / k)}
-        eff = max(1, min(eff, int(info["measured_parallelism"]["effective_cores"] + 0.5)))
+        if not quota_known:                                  # (a stated quota wins: the interpreter loop under-reports SMT pairs)
+            eff = max(1, min(eff, int(info["measured_parallelism"]["effective_cores"] + 0.5)))
     except Exception as exc:                                # noqa: BLE001
         info["measured_parallelism"] = {"error": repr(exc)}
     info["effective_cores"] = eff
@@ -1044,11 +1054,15 @@ def main():
     traffic_src = ("static_from_profiles: profiles/pmc_latest.json = rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of "
                    + str(pj.get('source', 'bench.py --minutes 20 --steps 1 --warmup 0 of the round-3 build'))
                    + "; per launch of THIS instantiation, 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for 16-byte-per-lane "
-                     "reads); PMC counters cannot be collected inside a bench run")
+                     "reads); PMC counters cannot be collected inside a bench run, and rocprofv3 --pmc crashes on the 1 h recording "
+                     "(profiles/r05_pmc_1h_attempt.txt): the PMC run's bytes per launch are scaled by this run's / the PMC run's algorithmic "
+                     "flops per launch of the same instantiation (traffic_scale_to_this_run; same pass geometry, other mix of full and "
+                     "remainder passes)")
     roofline = {"bound": "mfma",
                 "kernel": kd["kernel"],
                 "achieved": kd["achieved"], "peak": peak_tf, "unit": "TFLOP/s", "frac": kd["frac"],
                 "traffic": kd.get("traffic_per_launch_static"), "traffic_source": traffic_src,
+                "traffic_pmc_run_mean_launch": kd.get("traffic_per_launch_pmc_run"), "traffic_scale_to_this_run": kd.get("traffic_scale_to_this_run"),
                 "flops_per_launch": kd["flops_per_launch"], "avg_launch_ms": kd["avg_launch_ms"],
                 "launches_per_step": kd["launches"], "kernel_ms_per_step": kd["ms_per_step"],
                 "mfma_executed_tflops": kd["achieved"] * (3 if x3 else 1),

@@ -1119,7 +1119,10 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
     // conv_fp.h FUSED).  Static part of the test; the footprint-capacity part is decided when the second row is reached
     // (the first layer is then launched per window after all).
     auto can_defer = [&](int r) {
-        if (!x3mode || r + 1 >= n.nrows || !share_first || rmax < rmin) return false;
+        if (r + 1 >= n.nrows || !share_first || rmax < rmin) return false;
+        // exact-f32 mode: only the shape the F32 form of the weight-stationary kernel is instantiated for (conv_ws.h F32, cnn_ws_h.hip)
+        const bool f32defer = !x3mode;
+        if (f32defer && (c->diag & (ISS_DIAG_NO_WS | ISS_DIAG_NO_F32WS))) return false;
         const int32_t* R1 = &n.prog[(size_t)r * ISS_PROG_COLS];
         const int32_t* R2 = &n.prog[(size_t)(r + 1) * ISS_PROG_COLS];
         int ph, pw;
@@ -1134,6 +1137,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                            R1[ISS_C_W] * R1[ISS_C_COUT] * 4 <= issk::WS_STAB && !(c->diag & (ISS_DIAG_NO_FSAME | ISS_DIAG_NO_WS)) &&
                            R1[ISS_C_PSOFF] < 0 && issk::iss_ws_fs_compiled(R2[ISS_C_KH], R2[ISS_C_KW]);
         if (!valid1 && !same1) return false;
+        if (f32defer && (!valid1 || !issk::iss_ws_f32_fused_compiled(R2[ISS_C_KH], R2[ISS_C_KW]) || R2[ISS_C_SH] != 1 || R2[ISS_C_SW] != 1 ||
+                         R2[ISS_C_PT] != 0 || R2[ISS_C_PL] != 0 || R1[ISS_C_PSOFF] >= 0)) return false;
         if (R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4 > 48 * 1024) return false;        // first_layer_raw_kernel's LDS weights
         if (R1[ISS_C_BOFF] < 0 || (R1[ISS_C_PSOFF] >= 0) != (R1[ISS_C_PTOFF] >= 0) || R1[ISS_C_COUT] % 4 != 0 || n.wsum_off[r] < 0) return false;
         if (R2[ISS_C_OP] != ISS_OP_CONV || R2[ISS_C_INMODE] != 0 || R2[ISS_C_IN] != R1[ISS_C_OUT] || R2[ISS_C_RES] >= 0) return false;
@@ -1308,6 +1313,19 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         const bool padded = a.pt_ != 0 || a.pl_ != 0 ||
                             (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
+        // exact-f32 mode (ISS_PREC_F32): the F32 form of the weight-stationary kernel for the first-layer-fused 5x3 layer
+        const bool no_f32ws = (c->diag & ISS_DIAG_NO_F32WS) != 0;
+        bool ws_f32 = false;
+        if (!x3 && !no_ws && !no_f32ws && pend >= 0 && !fs1 && a.mode == 0 && issk::iss_ws_f32_fused_compiled(a.H_k, a.kw) && !padded &&
+            a.sh == 1 && a.sw == 1 && issk::epi_is_pool_relu(a) && a.Cin % F2_CH == 0 && a.Cin >= 2 * F2_CH && a.M < (1ll << 31) &&
+            a.H * a.W >= WS_PIX + 64 + a.W && ws_recip_exact(a.W, a.H * a.W + WS_PIX + a.W) &&
+            n.prog[(size_t)pend * ISS_PROG_COLS + ISS_C_PSOFF] < 0) {
+            const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 62);
+            auto it = n.fp_pix.find(key);
+            if (it == n.fp_pix.end()) it = n.fp_pix.emplace(key, footprint_pixels(a, WS_TM)).first;
+            ws_f32 = it->second <= WS_PIX;
+            if (ws_f32) { ws = true; fp = true; }
+        }
         // FS form: row-major epilogue only (a second conv without a fused pool would take the transposed one), stride 1
         const bool ws_fs = fs1 && ws && issk::iss_ws_fs_compiled(a.H_k, a.kw) && !(a.pp == 1 && a.Cout % 4 == 0) && a.sh == 1 && a.sw == 1 &&
                            a.Cin >= 2 * F2_CH && !(c->diag & ISS_DIAG_NO_FSAME);
@@ -1318,7 +1336,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         const bool no_ws3 = (c->diag & ISS_DIAG_NO_WS3) != 0;
         const bool nh2_pad_pool = a.pp > 1 && issk::epi_is_pool_relu(a);                         // ... and row-major with the pooled relu epilogue
         const bool nh2_pad_ok = (a.pp == 1 && a.Cout % 4 == 0 && issk::epi_is_simple_tr(a)) || nh2_pad_pool;   // the padded form is compiled transposed + simple
-        if (!no_ws && !no_ws3 && pend < 0 && x3 && a.mode == 0 && (!padded || nh2_pad_ok) && a.sh == 1 && a.sw == 1 && !a.res && a.Cout % (2 * BN) == 0 &&
+        // (exact-f32 mode: the unpadded form with the simple transposed or the pooled relu epilogue only -- cnn_ws_h.hip)
+        const bool nh2_f32 = !x3 && !no_f32ws && !padded && ((a.pp == 1 && a.Cout % 4 == 0 && issk::epi_is_simple_tr(a)) || (a.pp > 1 && issk::epi_is_pool_relu(a)));
+        if (!no_ws && !no_ws3 && pend < 0 && (x3 || nh2_f32) && a.mode == 0 && (!padded || nh2_pad_ok) && a.sh == 1 && a.sw == 1 && !a.res && a.Cout % (2 * BN) == 0 &&
             issk::iss_ws_nh2_compiled(a.H_k, a.kw) && a.Cin % F2_CH == 0 && a.M < (1ll << 31) &&
             (long long)bc * a.img_stride * 4 < (1ll << 32)) {
             const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 60);
@@ -1343,6 +1363,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             fused = fp && (ws || (!fs1 && !padded && a.H_k * a.kw >= 12)) && d_winrow != nullptr &&
                     ((long long)(rmax - rmin) + Rp[ISS_C_HO] + edge_rows) * Rp[ISS_C_WO] * Rp[ISS_C_COUT] * 4 < (1ll << 32);   // 32-bit BYTE offsets into R
             if (ws_ring && !fused) { ws = false; fp = false; ws_ring = false; a.tmr = 0; }                                // (no footprint kernel of that shape)
+            if (ws_f32 && !fused) { ws = false; fp = false; ws_f32 = false; }                                              // (exact-f32 mode has no other one)
         }
         if (!fused && (long long)bc * a.img_stride >= (1ll << 32)) fp = false;        // 32-bit offsets into the input batch
         if (pend >= 0) {
@@ -1423,6 +1444,14 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             if (window) hipLaunchKernelGGL(conv1_direct3x3_kernel<true>, dgrid, dim3(256), dlds, c->stream, a);
             else hipLaunchKernelGGL(conv1_direct3x3_kernel<false>, dgrid, dim3(256), dlds, c->stream, a);
         } else
+        if (ws_nh2 && !x3) {
+            const unsigned ngroups = (unsigned)((a.M + WS_TM - 1) / WS_TM);
+            const unsigned ny = (unsigned)(a.Cout / (2 * BN));
+            const dim3 g2(std::min<unsigned>(ngroups, std::max(1u, 256u / ny)), ny);
+            const bool trn = a.pp == 1;
+            iss_prof_inst(c, "conv_x3_ws_kernel<3,3,false,%s,false,2,1,f32>", trn ? "true" : "false");
+            issk::iss_ws_launch_f32_nh2_3x3(a, g2, c->stream, trn);
+        } else
         if (ws_nh2) {
             const unsigned ngroups = (unsigned)((a.M + WS_TM - 1) / WS_TM);         // one 512-row tile per group
             const unsigned ny = (unsigned)(a.Cout / (2 * BN));
@@ -1465,6 +1494,11 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const unsigned per_n = std::max(1u, 256u / grid.y);                   // one 512-thread workgroup per CU in total
             iss_prof_inst(c, "conv_x3_ws_kernel<3,3,true,true,false,1,%d>", (int)issk::epi_is_simple_tr(a));
             issk::iss_ws_launch_plain_3x3(a, dim3(std::min<unsigned>(ngroups, per_n), grid.y), c->stream);
+        } else if (ws && ws_f32) {
+            const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
+            const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);
+            iss_prof_inst(c, "conv_x3_ws_kernel<5,3,false,false,true,1,1,f32>");
+            issk::iss_ws_launch_f32_fused_5x3(a, wgrid, c->stream);
         } else if (ws && ws_ring) {
             const unsigned ngroups = (unsigned)((a.M + a.tmr - 1) / a.tmr);      // one tile of tmr rows per group
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);

@@ -103,7 +103,14 @@ constexpr int ws_lds_bytes(int nt, int nh, bool fs = false) {
 // instead of one); (ii) the first f_padt / last f_padb ROWS of a window saw fewer filter rows: those few rows are not shared between
 // windows -- first_layer_edge_kernel writes them per window, already corrected so that the SAME affine map applies
 // (E = partial sum + mean_b * (S - S_partial)), behind the shared rows in `in`, and only their address differs in the fetch.
-template <int KH, int KW, bool PADDED, bool TR, bool FUSED, int NH = 1, int EPI = 0, bool FS = false>
+// F32 (ISS_PREC_F32, the exact-f32 mode): the same kernel on v_mfma_f32_32x32x2_f32.  LDS holds f32 instead of bf16 hi | lo -- the
+// SAME bytes per element, so footprint, weight tiles, addresses and the whole pipeline are unchanged: a pixel's 64 data bytes are
+// 16 floats (k quads 0..3), a weight tile is 64 rows x 16 floats with quads {0, 1} where the hi plane was and {2, 3} where the lo
+// plane was.  A lane's two 16-byte fragment reads give it quads lh and 2 + lh; MFMA j of a quad multiplies element j of the A quad
+// with element j of the B quad, i.e. lanes 0-31 contribute k = 4 q + j and lanes 32-63 k = 4 (q + 1) + j -- a permutation of the k
+// order that both operands share.  8 MFMAs (16 passes each) per 32 x 32 block and k-step of 16 instead of three bf16 ones; no
+// operand split in the conversion.  Bit-wise an fmaf chain per output, like conv_igemm_kernel, in a different k order.
+template <int KH, int KW, bool PADDED, bool TR, bool FUSED, int NH = 1, int EPI = 0, bool FS = false, bool F32 = false>
 __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     constexpr int NT = KH * KW;
     constexpr int NV = NT * NH;                      // virtual steps per block
@@ -223,7 +230,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     {
         const int n = 32 * w_half + (lane >> 1), h = (lane & 1) ^ ((n >> 3) & 1);
         const int row = n0 + 64 * w_ch + n;
-        boff_w = 2u * ((unsigned)(row < p.Cout ? row : 0) * (unsigned)p.Kpad + (unsigned)(h * 8));      // bytes
+        if (F32) boff_w = 4u * ((unsigned)(row < p.Cout ? row : 0) * (unsigned)p.Kpad + (unsigned)(h * 4));     // bytes: quad 2 plane + h
+        else boff_w = 2u * ((unsigned)(row < p.Cout ? row : 0) * (unsigned)p.Kpad + (unsigned)(h * 8));      // bytes
     }
     // tiles [v_lo, v_hi) of chunk c0
     auto load_weights = [&](int c0, int v_lo, int v_hi) {
@@ -232,7 +240,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
             const int i = wv + 8 * k;                // uniform
             if (i < 4 * NV && (i >> 2) >= v_lo && (i >> 2) < v_hi) {
                 const int v = i >> 2;                // weight tile: tap v / NH (column half v % NH == w_ch)
-                const uint16_t* src = (w_plane ? p.wl : p.wh) + ((v / NH) * p.Cin + c0);
+                const uint16_t* src = F32 ? reinterpret_cast<const uint16_t*>(p.w + ((v / NH) * p.Cin + c0 + w_plane * 8))
+                                          : (w_plane ? p.wl : p.wh) + ((v / NH) * p.Cin + c0);
                 if (RING) {                          // (the 49-step form ran out of SGPRs and kept this uniform address in VGPRs: back into an SGPR pair)
                     const unsigned long long a64 = (unsigned long long)src;
                     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a64);
@@ -346,9 +355,15 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                             fmaf(v.z, sc, second ? t1[2] : t0[2]), fmaf(v.w, sc, second ? t1[3] : t0[3]));
             v.x = fmaxf(v.x, f_lob); v.y = fmaxf(v.y, f_lob); v.z = fmaxf(v.z, f_lob); v.w = fmaxf(v.w, f_lob);
         }
-        split4(v, cvh[q], cvl[q]);
+        if (F32) {                                   // the 4 floats as they are: (v.x, v.y) and (v.z, v.w) in the two 8-byte registers
+            struct F2 { float a, b; };
+            cvh[q] = __builtin_bit_cast(bf16x4, F2{v.x, v.y});
+            cvl[q] = __builtin_bit_cast(bf16x4, F2{v.z, v.w});
+        } else split4(v, cvh[q], cvl[q]);
     };
-    const unsigned fwrite = sF_base + (unsigned)(prow * F2_ROW + cg * 8);
+    // bf16: 4 channels hi at +8 cg, lo 32 bytes behind; F32: the 4 floats are one 16-byte quad at +16 cg
+    constexpr int FW_SECOND = F32 ? 1 : 4;           // 8-byte units between the two stores of a slice
+    const unsigned fwrite = sF_base + (unsigned)(prow * F2_ROW + cg * (F32 ? 16 : 8));
     auto write_footprint = [&]() {
         unsigned b = fwrite;
         asm volatile("" : "+v"(b));                  // opaque base: one address register, the slices are immediates (< 64 KB;
@@ -362,10 +377,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
         for (int q = 0; q < WS_NFV; ++q) {
             if (q < QB) {
                 pb[q * (128 * F2_ROW / 8)] = cvh[q];
-                pb[q * (128 * F2_ROW / 8) + 4] = cvl[q];
+                pb[q * (128 * F2_ROW / 8) + FW_SECOND] = cvl[q];
             } else {
                 pb2[(q - QB) * (128 * F2_ROW / 8)] = cvh[q];
-                pb2[(q - QB) * (128 * F2_ROW / 8) + 4] = cvl[q];
+                pb2[(q - QB) * (128 * F2_ROW / 8) + FW_SECOND] = cvl[q];
             }
         }
     };
@@ -402,6 +417,19 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     };
     // one MFMA pair: A vector x the two column blocks of a weight plane, into the two accumulators of a row block
     auto mfma2 = [&](const bf16x8& av, const BH& b, floatx16& c0, floatx16& c1) {
+        if constexpr (F32) {                             // the 16 bytes are one k quad of f32: four K = 2 MFMAs per column block
+            const f32x4 a4 = __builtin_bit_cast(f32x4, av), b0 = __builtin_bit_cast(f32x4, b.b0), b1 = __builtin_bit_cast(f32x4, b.b1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (TR) {
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[j], a4[j], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[j], a4[j], c1, 0, 0, 0);
+                } else {
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b0[j], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b1[j], c1, 0, 0, 0);
+                }
+            }
+        } else
         if (TR) {                                        // C^T: rows = channels, columns = pixels (epilogue_tr)
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.b0, av, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.b1, av, c1, 0, 0, 0);
@@ -534,7 +562,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                         load_weights(nc0, 0, VB);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (half == 0) { mfma2(a0.l, bh, c00, c01); mfma2(a1.l, bh, c10, c11); }
+                    // (F32: the first fragment read, .h, holds k quads {0, 1} and pairs with the first weight plane, .l with the second:
+                    //  groups (a0.h x bh), (a1.h x bh), (a.l x bl))
+                    if (F32) { if (half == 0) mfma2(a0.h, bh, c00, c01); else mfma2(a0.h, bh, d00, d01); }
+                    else if (half == 0) { mfma2(a0.l, bh, c00, c01); mfma2(a1.l, bh, c10, c11); }
                     else { mfma2(a0.l, bh, d00, d01); mfma2(a1.l, bh, d10, d11); }
                     __builtin_amdgcn_sched_barrier(0);
                     if (half == NH - 1 && tap + 1 < NT) {
@@ -547,7 +578,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                     }
                     if (v == CS - 1) conv_consts();
                     __builtin_amdgcn_sched_barrier(0);
-                    if (half == 0) { mfma2(a0.h, bh, c00, c01); mfma2(a1.h, bh, c10, c11); }
+                    if (F32) { if (half == 0) mfma2(a1.h, bh, c10, c11); else mfma2(a1.h, bh, d10, d11); }
+                    else if (half == 0) { mfma2(a0.h, bh, c00, c01); mfma2(a1.h, bh, c10, c11); }
                     else { mfma2(a0.h, bh, d00, d01); mfma2(a1.h, bh, d10, d11); }
                     __builtin_amdgcn_sched_barrier(0);
                     if (RING && (v + 1) % TG == 0 && v + 1 < NV) {
@@ -566,7 +598,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                     for (int q = 0; q < WS_NFV; ++q)
                         if (v == CS + q * CSTRIDE) convert_slice(q);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (half == 0) { mfma2(a0.h, bl, c00, c01); mfma2(a1.h, bl, c10, c11); }
+                    if (F32) {
+                        if (half == 0) { mfma2(a0.l, bl, c00, c01); mfma2(a1.l, bl, c10, c11); }
+                        else { mfma2(a0.l, bl, d00, d01); mfma2(a1.l, bl, d10, d11); }
+                    } else if (half == 0) { mfma2(a0.h, bl, c00, c01); mfma2(a1.h, bl, c10, c11); }
                     else { mfma2(a0.h, bl, d00, d01); mfma2(a1.h, bl, d10, d11); }
                     __builtin_amdgcn_sched_barrier(0);
                     if (v + 1 < NV) read_bl(bl, v + 1);
@@ -660,6 +695,11 @@ void launch_ws_fused_rowmajor(const ConvArgs& a, dim3 grid, hipStream_t st, bool
     else { if (fast) ISS_WS_LAUNCH2(false, 1); else ISS_WS_LAUNCH2(false, 0); }
 #undef ISS_WS_LAUNCH2
 }
+
+// exact-f32 form (cnn_ws_h.hip): the fused 5x3 layer (pooled relu epilogue) and the unpadded 3x3 NH = 2 layers (simple epilogues)
+inline bool iss_ws_f32_fused_compiled(int kh, int kw) { return kh == 5 && kw == 3; }
+void iss_ws_launch_f32_fused_5x3(const ConvArgs& a, dim3 grid, hipStream_t st);
+void iss_ws_launch_f32_nh2_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool tr);
 
 // Plain (not first-layer-fused) use of the kernel: zero-padded 3x3 stride-1 layers whose 128-row tile does not fit
 // conv_x3_fp_kernel's 360-pixel footprint because the image is WIDE (ResNet-101's 32 -> 32 convolutions at 64 x 144: 580

@@ -376,3 +376,38 @@ def test_one_wave_per_simd_kernels_edge_sizes(ctx, nmel, nout):
         assert np.array_equal(f_new, rfin) and np.array_equal(f_new, f_old)
         assert np.abs(p_new - ref).max() < 1e-4, (n, np.abs(p_new - ref).max())
         assert np.array_equal(p_new, p_old), (n, np.abs(p_new - p_old).max())
+
+
+@pytest.mark.parametrize('net,nmel,ncls', [('smn', 21, 3), ('gender', 24, 2)])
+def test_exact_f32_mode_takes_the_weight_stationary_kernels(ctx, net, nmel, ncls):
+    """ISS_PREC_F32 on the stand-in nets over the segmenter's own overlapping window list: the three layers that carry the
+    arithmetic run on the F32 form of the weight-stationary kernel (v_mfma_f32_32x32x2_f32 on the LDS footprint, shared first
+    layer), the result matches the oracle to 1e-4 and the conv_igemm_kernel path it replaces (ISS_DIAG_NO_F32WS) to float32
+    rounding of a different summation order, and the split-bf16 default to its own operand error."""
+    rng = np.random.default_rng(31 + nmel)
+    T = 1500
+    mspec = _mspec(rng, T)
+    mspec[400:403, 7] = -np.inf
+    ctx.set_mspec(mspec)
+    layers, shp = KM.synthetic_ina_like(nmel, ncls, seed=5)
+    ctx.cnn_load(3, KM.compile_layers(layers, shp))
+    rows = S._window_rows(T)
+    ref, rfin = _oracle_probs(layers, mspec, nmel, rows)
+    p_x3, f_x3 = ctx.cnn_probs(3, rows)
+    ctx.set_precision(_native.PREC_F32)
+    try:
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        p_f32, f_f32 = ctx.cnn_probs(3, rows)
+        insts = [i['kernel'] for i in ctx.prof_instances()]
+        ctx.prof_enable(False)
+        ctx.set_diag('no_f32ws')
+        p_old, f_old = ctx.cnn_probs(3, rows)
+    finally:
+        ctx.set_diag(0)
+        ctx.set_precision(_native.PREC_BF16X3)
+    assert sum(k.endswith('f32>') for k in insts) == 3, insts               # fused 5x3, 3x3 transposed, 3x3 pooled
+    assert np.array_equal(f_f32, rfin) and np.array_equal(f_old, rfin) and np.array_equal(f_x3, rfin)
+    e_or, e_old, e_x3 = np.abs(p_f32 - ref).max(), np.abs(p_f32 - p_old).max(), np.abs(p_f32 - p_x3).max()
+    print(f'{net}: f32 ws vs oracle {e_or:.2e}, vs conv_igemm_kernel {e_old:.2e}, vs bf16x3 {e_x3:.2e}')
+    assert e_or < 1e-4 and e_old < 2e-5 and e_x3 < 1e-4

@@ -11,6 +11,7 @@ import sys
 
 def main():
     fe, wr, sq = (json.load(open(p)) for p in sys.argv[1:4])
+    geometry = sys.argv[5] if len(sys.argv) > 5 else 'bench.py --minutes 20 --steps 1 --warmup 0'
     per = {}
     for k in sorted(set(fe) | set(wr) | set(sq)):
         d = {}
@@ -41,9 +42,19 @@ def main():
     # tallied at 64 B) -- the conv kernels read 16 bytes per lane -- so the corrected figure doubles the fetch part
     corrected = sum(v['launches'] * (2 * v['FETCH_SIZE_bytes'] + v['WRITE_SIZE_bytes']) for v in conv) / max(n, 1)
     out = {'conv_hbm_bytes_per_launch_bf16x3': traffic, 'conv_hbm_bytes_per_launch_corrected_bf16x3': corrected,
-           'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --minutes 20 --steps 1 --warmup 0: '
+           'source': geometry,
+           'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on ' + geometry + ': '
                    'launch-weighted mean of FETCH_SIZE+WRITE_SIZE over the conv GEMM launches, RAW counter bytes (KB x 1024)',
            'per_kernel': per}
+    # the bench line the PMC run itself printed (argv[6]): algorithmic flops per launch of every kernel instantiation in THAT run, so that
+    # bench.py can scale the per-launch bytes to the mean launch of another recording length
+    if len(sys.argv) > 6:
+        try:
+            line = [json.loads(l) for l in open(sys.argv[6]) if l.startswith('{')][-1]
+            out['pmc_run_flops_per_launch'] = {k['kernel'].replace(' ', ''): k['flops_per_launch'] for k in line['roofline']['kernels']}
+            out['pmc_run_minutes'] = line['config']['audio_hours_per_step_per_gpu'] * 60.0
+        except Exception as exc:                               # noqa: BLE001
+            out['pmc_run_flops_per_launch_error'] = repr(exc)
     json.dump(out, open(sys.argv[4], 'w'), indent=1)
     print('| kernel | launches | avg us | FETCH MB | WRITE MB | (F+W)/t TB/s | MFMA busy % | clock GHz | LDS conflict % |')
     print('|---|---|---|---|---|---|---|---|---|')
