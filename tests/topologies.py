@@ -111,6 +111,15 @@ SPECS = {
                   ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 1)] + HEAD,
     'gap_head': [('conv', 4, 5, 64), ('bn_relu',), ('conv', 5, 3, 64), ('bn_relu',), ('maxpool', 2, 2),
                  ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('gap',), ('dense', 128)],
+    # ---- round 5: every instantiation of the ring form (> 16 taps) and of the shared zero-padded first layer (FS) at least once
+    'conv1_same_conv2_same': [('conv', 4, 5, 64, 'same'), ('bn_relu',), ('conv', 5, 3, 64, 'same'), ('bn_relu',), ('maxpool', 2, 2),
+                              ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 1)] + HEAD,
+    'conv1_same3x3_avg': [('conv', 3, 3, 64, 'same'), ('bn_relu',), ('conv', 3, 3, 64), ('bn_relu',), ('avgpool', 2, 2),
+                          ('conv', 3, 3, 128, 'same'), ('bn_relu',), ('maxpool', 2, 2)] + HEAD,
+    'conv1_same_nopool': [('conv', 4, 5, 64, 'same'), ('bn_relu',), ('conv', 5, 3, 64), ('bn_relu',),
+                          ('conv', 3, 3, 128, 'valid', 2), ('bn_relu',), ('maxpool', 2, 2)] + HEAD,
+    'conv2_7x7_same_avg': [('conv', 4, 5, 64), ('bn_relu',), ('conv', 7, 7, 64, 'same'), ('bn_relu',), ('avgpool', 2, 2),
+                           ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 1)] + HEAD,
     'overlap_pool_avg': [('conv', 4, 5, 64), ('bn_relu',), ('conv', 5, 3, 64), ('bn_relu',), ('maxpool', 3, 3, 2, 2),
                          ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('avgpool', 2, 2)] + HEAD,
 }
