@@ -1295,16 +1295,17 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         bool ws_ring = false;
         if (!no_ws && !(c->diag & ISS_DIAG_NO_RING) && pend >= 0 && !fs1 && x3 && a.mode == 0 && issk::iss_ws_ring_compiled(a.H_k, a.kw) &&
             a.sh == 1 && a.sw == 1 && a.Cin % F2_CH == 0 && a.Cin >= 2 * F2_CH && a.M < (1ll << 31) &&
-            a.H * a.W >= WS_PIX2 + 64 + (a.pt_ + 1) * a.W && ws_recip_exact(a.W, a.H * a.W + WS_PIX2 + a.W) &&
-            n.prog[(size_t)pend * ISS_PROG_COLS + ISS_C_PSOFF] < 0) {
-            // rows per tile: the largest multiple of 4 (<= 512, >= 384) whose footprint fits the 1024 pixels -- a 512-row tile of a
+            ws_recip_exact(a.W, a.H * a.W + WS_PIX2 + a.W) && n.prog[(size_t)pend * ISS_PROG_COLS + ISS_C_PSOFF] < 0) {
+            // rows per tile: the largest multiple of 4 (<= 512, >= 320) whose footprint fits the 1024 pixels -- a 512-row tile of a
             // pooled 59 x 14 output under a 7-row filter spans 1036 pixels, 496 rows 1002 (ConvArgs::tmr; the rest of the tile idles)
             const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 57);
             auto it = n.fp_pix.find(key);
             if (it == n.fp_pix.end()) {
+                // ... and reaches into at most ONE following window (the fetch decomposes a footprint position into two windows)
+                const int cap = std::min<long long>(WS_PIX2, (long long)a.H * a.W - 64 - (long long)(a.pt_ + 1) * a.W);
                 int tmr = 0;
-                for (int cand = WS_TM; cand >= 384 && !tmr; cand -= 4)
-                    if (footprint_pixels(a, cand) <= WS_PIX2) tmr = cand;
+                for (int cand = WS_TM; cand >= 320 && !tmr; cand -= 4)
+                    if (footprint_pixels(a, cand) <= cap) tmr = cand;
                 it = n.fp_pix.emplace(key, tmr).first;
             }
             a.tmr = it->second;
@@ -1326,7 +1327,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             ws_f32 = it->second <= WS_PIX;
             if (ws_f32) { ws = true; fp = true; }
         }
-        // FS form: row-major epilogue only (a second conv without a fused pool would take the transposed one), stride 1
+        // FS form: row-major epilogue only.  A second conv WITHOUT a fused pool is not taken: its unpooled output through the row-major
+        // epilogue (4-byte stores) measured 3.1 -> 2.3 h/s on conv1_same_nopool against the per-window first layer + transposed kernel
         const bool ws_fs = fs1 && ws && issk::iss_ws_fs_compiled(a.H_k, a.kw) && !(a.pp == 1 && a.Cout % 4 == 0) && a.sh == 1 && a.sw == 1 &&
                            a.Cin >= 2 * F2_CH && !(c->diag & ISS_DIAG_NO_FSAME);
         if (fs1 && !ws_fs) ws = false;
