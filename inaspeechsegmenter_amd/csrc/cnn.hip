@@ -1505,7 +1505,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const unsigned ngroups = (unsigned)((a.M + a.tmr - 1) / a.tmr);      // one tile of tmr rows per group
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);
             iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,false,true,1,%d,ring>", a.H_k, a.kw, padded ? "true" : "false", (int)issk::epi_is_pool_relu(a));
-            issk::iss_ws_launch_ring_7x7(a, wgrid, c->stream, padded);
+            issk::iss_ws_launch_ring(a, wgrid, c->stream, padded);
         } else if (ws && ws_fs) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);

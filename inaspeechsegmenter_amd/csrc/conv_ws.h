@@ -681,8 +681,15 @@ void launch_ws_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, 
 }
 
 // Ring form (more than WS_MAXNT taps): first-layer-fused, row-major epilogue only (cnn_ws_e.hip)
-inline bool iss_ws_ring_compiled(int kh, int kw) { return kh == 7 && kw == 7; }
+inline bool iss_ws_ring_compiled(int kh, int kw) { return (kh == 7 && kw == 7) || (kh == 5 && kw == 5) || (kh == 4 && kw == 5); }
 void iss_ws_launch_ring_7x7(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded);
+void iss_ws_launch_ring_5x5(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded);      // cnn_ws_i.hip
+void iss_ws_launch_ring_4x5(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded);      // cnn_ws_j.hip
+inline void iss_ws_launch_ring(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded) {
+    if (a.H_k == 7) iss_ws_launch_ring_7x7(a, grid, st, padded);
+    else if (a.H_k == 5) iss_ws_launch_ring_5x5(a, grid, st, padded);
+    else iss_ws_launch_ring_4x5(a, grid, st, padded);
+}
 // FS form (zero-padded first layer in front): first-layer-fused, row-major epilogue only (cnn_ws_f.hip, cnn_ws_g.hip)
 inline bool iss_ws_fs_compiled(int kh, int kw) { return (kh == 5 && kw == 3) || (kh == 3 && kw == 3); }
 void iss_ws_launch_fs_5x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded);

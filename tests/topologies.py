@@ -120,6 +120,10 @@ SPECS = {
                           ('conv', 3, 3, 128, 'valid', 2), ('bn_relu',), ('maxpool', 2, 2)] + HEAD,
     'conv2_7x7_same_avg': [('conv', 4, 5, 64), ('bn_relu',), ('conv', 7, 7, 64, 'same'), ('bn_relu',), ('avgpool', 2, 2),
                            ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 1)] + HEAD,
+    'conv2_5x5': [('conv', 4, 5, 64), ('bn_relu',), ('conv', 5, 5, 64), ('bn_relu',), ('maxpool', 2, 2),
+                  ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 1)] + HEAD,
+    'conv2_4x5_same': [('conv', 4, 5, 64), ('bn_relu',), ('conv', 4, 5, 64, 'same'), ('bn_relu',), ('maxpool', 2, 2),
+                       ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 1)] + HEAD,
     'overlap_pool_avg': [('conv', 4, 5, 64), ('bn_relu',), ('conv', 5, 3, 64), ('bn_relu',), ('maxpool', 3, 3, 2, 2),
                          ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('avgpool', 2, 2)] + HEAD,
 }
