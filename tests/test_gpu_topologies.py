@@ -75,6 +75,15 @@ def test_topology_parity(ctx, name):
             d_off = np.abs(p_off - probs).max()
             print(f'{name}/{net}: {took[0]} vs the path it replaces: max |dp| {d_off:.2e}')
             assert np.array_equal(f_off, fin) and d_off < 5e-5, (name, net, d_off)
+            # ... and in ~10 passes instead of one (per-pass first-layer rows, per-window edge rows and window scalars are
+            # indexed relative to the pass): the same probabilities up to where the tile boundaries fall
+            prev_limit = getattr(ctx, 'workspace_limit', 12 << 30)
+            ctx.set_workspace_limit(64 << 20)
+            try:
+                p_ch, f_ch = ctx.cnn_probs(5, rows)
+            finally:
+                ctx.set_workspace_limit(prev_limit)
+            assert np.array_equal(f_ch, fin) and np.abs(p_ch - probs).max() < 5e-6, (name, net, np.abs(p_ch - probs).max())
         scat = np.sort(rng.integers(0, T - 68, 64)).astype(np.int32)     # scattered: per-window first layer
         p2, f2 = ctx.cnn_probs(5, scat)
         r2, rf2 = _oracle_probs(layers, mspec, nmel, scat)
