@@ -299,11 +299,39 @@ def _bn_affine(L):
 CH_ALIGN = 32      # channel counts of intermediate activations are padded to this (the k-tile of the MFMA kernels)
 
 
-def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_channels=True):
+def _can_fold_forward(layers, j, sc):
+    """A BatchNorm BEHIND an activation (y = sc * r + sft per channel) can be moved into the NEXT linear layer -- W' = W diag(sc),
+    b' = b + W sft -- when everything in between commutes with a per-channel affine map: dropout, flatten, average pools, max pools
+    if every sc > 0 (max(sc r + sft) = sc max(r) + sft), and the consumer is a Dense layer or a Conv2D that does not zero-pad (the
+    padding zeros of a 'same' convolution are zeros of y, not of r)."""
+    for L in layers[j:]:
+        ty = L['type']
+        if ty in ('dropout', 'flatten', 'avgpool', 'globalavgpool'):
+            if ty == 'avgpool' and L.get('padding', 'valid') == 'same':
+                return False
+            continue
+        if ty in ('maxpool', 'globalmaxpool'):
+            if not np.all(sc > 0):
+                return False
+            continue
+        if ty == 'dense':
+            return True
+        if ty == 'conv2d':
+            return L.get('padding', 'valid') == 'valid'
+        return False
+    return False
+
+
+def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_channels=True, fold_post_bn=True):
     """Lower a sequential layer list onto the op program.  Fusions: conv/dense + bias,
     + BatchNorm directly after (folded into W, b), + relu/sigmoid/tanh, + BatchNorm after the
     activation (epilogue scale/shift), + a non-overlapping 'valid' max/avg pool over 2 or 4 outputs.
     Anything left over becomes an identity 1x1 conv.
+
+    fold_post_bn: `Conv2D(activation='relu')` + `BatchNormalization()` -- the BatchNorm BEHIND the activation -- is folded into the
+    next Dense / unpadded Conv2D where that is exact (`_can_fold_forward`) instead of becoming an epilogue affine of its producer: the
+    program then has the same shape as a conv - BN - relu net and takes the same kernels (a post-activation affine keeps a layer off
+    the shared-first-layer / one-wave-per-SIMD forms).  Float64 on the host; results move by float32 rounding of a re-associated sum.
 
     pad_channels: an intermediate activation whose channel count is not a multiple of 32 (48, 96, 20 ...) is stored with
     zero channels appended (zero weight rows / bias / scale in the producer, zero weight columns in every consumer), so
@@ -316,6 +344,7 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
     cur = N.BUF_INPUT
     first = True
     i, n = 0, len(layers)
+    carry = None                                    # (sc, sft) float64 per LOGICAL input feature of the next linear layer (fold_post_bn)
 
     def nxt_buf():
         return 0 if cur in (N.BUF_INPUT, 1) else 1
@@ -336,6 +365,8 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
             pmap = (np.where(pmap >= 0, pmap, -(1 << 40))[None, :] + (np.arange(hw) * c)[:, None]).ravel()
             pmap = np.where(pmap >= 0, pmap, -1)
             shape = (1, 1, hw * c)
+            if carry is not None:                   # feature index = position * channels + channel
+                carry = (np.tile(carry[0], hw), np.tile(carry[1], hw))
             i += 1
             continue
         if ty in ('conv2d', 'dense', 'batchnorm', 'activation') and not (ty == 'activation' and L['fn'] == 'softmax'):
@@ -374,6 +405,12 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
                 bias = None
                 act_name = 'linear'
                 j = i
+            if carry is not None:                   # the producer's post-activation BatchNorm, moved here (see _can_fold_forward)
+                assert ty in ('conv2d', 'dense') and pt == 0 and pl == 0 and len(carry[0]) == cin, (ty, pt, pl, len(carry[0]), cin)
+                W3 = Wm.reshape(cout, kh * kw, cin)
+                bias = (bias if bias is not None else np.zeros(cout)) + (W3 * carry[1][None, None, :]).sum(axis=(1, 2))
+                Wm = (W3 * carry[0][None, None, :]).reshape(cout, kh * kw * cin)
+                carry = None
             softmax_after = False
             if act_name == 'softmax':
                 act_name, softmax_after = 'linear', True
@@ -395,7 +432,10 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
             ps = pt_ = None
             if not softmax_after and j < n and layers[j]['type'] == 'batchnorm':
                 sc, sft = _bn_affine(layers[j])
-                ps, pt_ = sc.astype(np.float32), sft.astype(np.float32)
+                if fold_post_bn and _can_fold_forward(layers, j + 1, sc):
+                    carry = (sc, sft)               # into the next linear layer's weights and bias
+                else:
+                    ps, pt_ = sc.astype(np.float32), sft.astype(np.float32)
                 j = peek(j + 1)
             # non-overlapping 'valid' pool of 2 or 4 outputs right after -> epilogue
             fpool = None
@@ -485,6 +525,7 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
         i += 1
     if cur == N.BUF_INPUT:
         raise ValueError("empty network")
+    assert carry is None, "a deferred BatchNorm was never consumed"
     if len(pmap) != shape[2]:
         raise NotImplementedError("network output is channel-padded")
     out_dim = shape[0] * shape[1] * shape[2]

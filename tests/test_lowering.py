@@ -50,3 +50,34 @@ def test_resnet101_lowering_equals_oracle():
     assert got.shape == ref.shape == (2, 256)
     assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
 
+
+
+def _post_affine_rows(comp):
+    return int(sum(1 for R in comp.prog if R[N.C_OP] == N.OP_CONV and R[N.C_PSOFF] >= 0))
+
+
+def test_post_activation_batchnorm_is_folded_forward_where_that_is_exact():
+    """`Conv2D(activation='relu')` + `BatchNormalization()` (BatchNorm BEHIND the activation, a common Keras idiom): the affine map
+    moves into the next Dense / unpadded Conv2D (through dropout, flatten, average pools, and max pools when every scale is
+    positive), so the program has no post-activation affine left and looks like a conv - BN - relu net to the kernels; it stays an
+    epilogue affine in front of a zero-padded convolution and, with a negative scale, in front of a max pool."""
+    rng = np.random.default_rng(11)
+    for net, (layers, shp) in TP.nets('relu_then_bn').items():
+        a = KM.compile_layers(layers, shp)
+        b = KM.compile_layers(layers, shp, fold_post_bn=False)
+        assert _post_affine_rows(a) == 0 and _post_affine_rows(b) == 4, (net, _post_affine_rows(a), _post_affine_rows(b))
+        x = rng.normal(0, 1, (4,) + shp).astype(np.float32)
+        want = ocnn.forward(layers, x)
+        assert np.abs(prog_interp.run(a, x) - want).max() < 2e-5 and np.abs(prog_interp.run(b, x) - want).max() < 2e-5
+        assert a.flops_per_sample == b.flops_per_sample
+    # guards: 'same' consumer, negative scale in front of a max pool, average pool (any sign), global max pool, tanh activation
+    spec = [('conv', 4, 5, 32), ('relu_bn',), ('conv', 3, 3, 32, 'same'), ('relu_bn',), ('maxpool', 2, 2), ('conv', 3, 3, 64), ('relu_bn',),
+            ('avgpool', 2, 2), ('conv', 3, 3, 64), ('relu_bn',), ('gap',), ('dense', 32, 'tanh')]
+    layers, shp = TP.build(spec, 21, 3, 5)
+    bns = [L for L in layers if L['type'] == 'batchnorm']
+    bns[1]['gamma'][3] = -0.7                                     # in front of the max pool: not foldable
+    bns[2]['gamma'][5] = -0.4                                     # in front of the average pool: foldable all the same
+    comp = KM.compile_layers(layers, shp)
+    assert _post_affine_rows(comp) == 2                           # conv1 (its consumer zero-pads) and conv2 (negative scale, max pool)
+    x = rng.normal(0, 1, (4,) + shp).astype(np.float32)
+    assert np.abs(prog_interp.run(comp, x) - ocnn.forward(layers, x)).max() < 2e-5
