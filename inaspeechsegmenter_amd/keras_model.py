@@ -71,6 +71,18 @@ def layers_from_keras_config(model_config, weights):
         w = weights.get(name, {})
         if cn == 'InputLayer':
             continue
+        if cn == 'ZeroPadding2D':                   # merged into the convolution behind it (explicit padding)
+            pd = c.get('padding', 1)
+            if np.isscalar(pd):
+                zp = (int(pd),) * 4
+            elif np.isscalar(pd[0]):
+                zp = (int(pd[0]), int(pd[0]), int(pd[1]), int(pd[1]))
+            else:
+                zp = (int(pd[0][0]), int(pd[0][1]), int(pd[1][0]), int(pd[1][1]))
+            if c.get('data_format', 'channels_last') != 'channels_last':
+                raise NotImplementedError('channels_first ZeroPadding2D')
+            layers.append(dict(type='zeropad', name=name, pad=zp))
+            continue
         if cn in ('Conv2D', 'Convolution2D'):
             if c.get('data_format', 'channels_last') != 'channels_last':
                 raise NotImplementedError('channels_first Conv2D')
@@ -116,6 +128,18 @@ def layers_from_keras_config(model_config, weights):
             layers.append(dict(type='dropout', name=name))
         else:
             raise NotImplementedError(f"Keras layer {cn!r} ({name}) is not supported by the op program")
+    # ZeroPadding2D -> explicit padding of the Conv2D right behind it (the only place the op program can express it)
+    merged = []
+    for L in layers:
+        if merged and merged[-1]['type'] == 'zeropad':
+            z = merged.pop()
+            if L['type'] != 'conv2d' or L.get('padding', 'valid') != 'valid':
+                raise NotImplementedError(f"ZeroPadding2D ({z['name']}) must be followed by a Conv2D(padding='valid')")
+            L = dict(L, pad=z['pad'])
+        merged.append(L)
+    if merged and merged[-1]['type'] == 'zeropad':
+        raise NotImplementedError('ZeroPadding2D at the end of the model')
+    layers = merged
     if in_shape is None:
         raise ValueError("model_config carries no batch_input_shape")
     if len(in_shape) == 1:                          # plain MLP on feature vectors (e.g. the x-vector gender model)
@@ -317,7 +341,7 @@ def _can_fold_forward(layers, j, sc):
         if ty == 'dense':
             return True
         if ty == 'conv2d':
-            return L.get('padding', 'valid') == 'valid'
+            return L.get('padding', 'valid') == 'valid' and not L.get('pad')
         return False
     return False
 
@@ -377,8 +401,12 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
                 assert wc == cin, (L.get('name'), wc, cin)
                 sh, sw = L.get('strides', (1, 1))
                 if L.get('padding', 'valid') == 'same':
+                    assert not L.get('pad'), "explicit padding goes with padding='valid'"
                     ho, pt = _same_pads(h, kh, sh)
                     wo, pl = _same_pads(w, kw, sw)
+                elif L.get('pad'):                  # ZeroPadding2D merged into this convolution: (top, bottom, left, right)
+                    zt, zb, zl, zr = L['pad']
+                    ho, wo, pt, pl = (h + zt + zb - kh) // sh + 1, (w + zl + zr - kw) // sw + 1, zt, zl
                 else:
                     ho, wo, pt, pl = (h - kh) // sh + 1, (w - kw) // sw + 1, 0, 0
                 Wm = W.transpose(3, 0, 1, 2).reshape(cout, -1).astype(np.float64)

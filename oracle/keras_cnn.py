@@ -76,6 +76,9 @@ def forward(layers, x, batch_size=1024, threads=None):
                     b = None if L.get('b') is None else torch.from_numpy(L['b'])
                     kh, kw = L['W'].shape[:2]
                     sh, sw = L.get('strides', (1, 1))
+                    if L.get('pad'):                       # a ZeroPadding2D in front of the convolution: (top, bottom, left, right)
+                        zt, zb, zl, zr = L['pad']
+                        t = F.pad(t, (zl, zr, zt, zb))
                     if L.get('padding', 'valid') == 'same':
                         pt, pb = same_pads(t.shape[2], kh, sh)
                         pl, pr = same_pads(t.shape[3], kw, sw)
@@ -136,6 +139,9 @@ def forward_naive(layers, x):
         if ty == 'conv2d':
             W = L['W']; kh, kw, cin, cout = W.shape
             sh, sw = L.get('strides', (1, 1))
+            if L.get('pad'):
+                zt, zb, zl, zr = L['pad']
+                t = np.pad(t, ((0, 0), (zt, zb), (zl, zr), (0, 0)))
             if L.get('padding', 'valid') == 'same':
                 pt, pb = same_pads(t.shape[1], kh, sh); pl, pr = same_pads(t.shape[2], kw, sw)
                 t = np.pad(t, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
@@ -195,6 +201,8 @@ def flops_per_sample(layers, in_shape):
         if ty == 'conv2d':
             kh, kw, cin, cout = L['W'].shape
             sh, sw = L.get('strides', (1, 1))
+            if L.get('pad'):
+                h, w = h + L['pad'][0] + L['pad'][1], w + L['pad'][2] + L['pad'][3]
             if L.get('padding', 'valid') == 'same':
                 h, w = -(-h // sh), -(-w // sw)
             else:

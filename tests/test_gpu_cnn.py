@@ -78,6 +78,11 @@ TOPOLOGIES = {
     'cin_not_multiple_of_4': lambda r, h: [_rand_conv(r, 2, 2, 1, 6, act='relu'), _rand_conv(r, 3, 2, 6, 10, act='relu'),
                                            dict(type='maxpool', pool=(3, 3), strides=(3, 3), padding='same'),
                                            dict(type='globalmaxpool'), _rand_dense(r, 10, 2, 'softmax')],
+    # ZeroPadding2D merged into the convolutions behind it: asymmetric explicit padding on the first (PATCH) layer and on a 32-channel one
+    'zeropadding2d_explicit': lambda r, h: [dict(_rand_conv(r, 4, 5, 1, 32, act='relu'), pad=(1, 2, 2, 1)),
+                                            dict(type='maxpool', pool=(2, 2), strides=(2, 2), padding='valid'),
+                                            dict(_rand_conv(r, 3, 3, 32, 32, act='relu'), pad=(2, 0, 0, 3)), _rand_bn(r, 32),
+                                            dict(type='globalavgpool'), _rand_dense(r, 32, 3, 'softmax')],
     'standalone_bn_first': lambda r, h: [_rand_bn(r, 1), _rand_conv(r, 3, 3, 1, 4, act='relu'), dict(type='dropout'),
                                          dict(type='flatten'), _rand_dense(r, 66 * (h - 2) * 4, 64, 'relu'), _rand_bn(r, 64),
                                          _rand_dense(r, 64, 2, 'softmax')],

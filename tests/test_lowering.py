@@ -81,3 +81,35 @@ def test_post_activation_batchnorm_is_folded_forward_where_that_is_exact():
     assert _post_affine_rows(comp) == 2                           # conv1 (its consumer zero-pads) and conv2 (negative scale, max pool)
     x = rng.normal(0, 1, (4,) + shp).astype(np.float32)
     assert np.abs(prog_interp.run(comp, x) - ocnn.forward(layers, x)).max() < 2e-5
+
+
+def test_zeropadding2d_is_merged_into_the_convolution_behind_it():
+    """Keras `ZeroPadding2D(((1, 2), (2, 1)))` + `Conv2D(padding='valid')`: parsed into one conv row with explicit (asymmetric)
+    padding; anything else behind a ZeroPadding2D is refused."""
+    rng = np.random.default_rng(4)
+    k1 = rng.normal(0, 0.3, (4, 5, 1, 8)).astype(np.float32)
+    k2 = rng.normal(0, 0.2, (3, 3, 8, 16)).astype(np.float32)
+    d = rng.normal(0, 0.1, (16, 3)).astype(np.float32)
+    cfg = {'class_name': 'Sequential', 'config': {'layers': [
+        {'class_name': 'ZeroPadding2D', 'config': {'name': 'zp1', 'padding': [[1, 2], [2, 1]], 'batch_input_shape': [None, 68, 21, 1]}},
+        {'class_name': 'Conv2D', 'config': {'name': 'c1', 'padding': 'valid', 'activation': 'relu', 'strides': [1, 1]}},
+        {'class_name': 'MaxPooling2D', 'config': {'name': 'p1', 'pool_size': [2, 2]}},
+        {'class_name': 'ZeroPadding2D', 'config': {'name': 'zp2', 'padding': 1}},
+        {'class_name': 'Conv2D', 'config': {'name': 'c2', 'padding': 'valid', 'activation': 'tanh'}},
+        {'class_name': 'GlobalAveragePooling2D', 'config': {'name': 'g'}},
+        {'class_name': 'Dense', 'config': {'name': 'd', 'activation': 'softmax'}}]}}
+    weights = {'c1': {'kernel': k1, 'bias': np.zeros(8, np.float32)}, 'c2': {'kernel': k2, 'bias': rng.normal(0, 0.1, 16).astype(np.float32)},
+               'd': {'kernel': d, 'bias': np.zeros(3, np.float32)}}
+    layers, shp = KM.layers_from_keras_config(cfg, weights)
+    assert shp == (68, 21, 1) and [L['type'] for L in layers] == ['conv2d', 'maxpool', 'conv2d', 'globalavgpool', 'dense']
+    assert layers[0]['pad'] == (1, 2, 2, 1) and layers[2]['pad'] == (1, 1, 1, 1)
+    comp = KM.compile_layers(layers, shp)
+    rows = [R for R in comp.prog if R[N.C_OP] == N.OP_CONV]
+    assert (int(rows[0][N.C_HO]), int(rows[0][N.C_WO]), int(rows[0][N.C_PT]), int(rows[0][N.C_PL])) == (68 + 3 - 4 + 1, 21 + 3 - 5 + 1, 1, 2)
+    x = rng.normal(0, 1, (3,) + shp).astype(np.float32)
+    want = ocnn.forward(layers, x)
+    assert np.abs(prog_interp.run(comp, x) - want).max() < 2e-5 and np.abs(ocnn.forward_naive(layers, x[:1]) - want[:1]).max() < 1e-5
+    assert comp.flops_per_sample <= ocnn.flops_per_sample(layers, shp)
+    bad = {'class_name': 'Sequential', 'config': {'layers': [cfg['config']['layers'][0], cfg['config']['layers'][2]]}}
+    with pytest.raises(NotImplementedError):
+        KM.layers_from_keras_config(bad, weights)
