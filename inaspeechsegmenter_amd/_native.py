@@ -12,9 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ISS_LIB') or os.path.join(_HERE, 'libiss_hip.so')      # ISS_LIB: another build of the library (A/B runs)
 
 PROG_COLS = 32
-OP_CONV, OP_POOL, OP_SOFTMAX, OP_STATPOOL = 1, 2, 3, 4
+OP_CONV, OP_POOL, OP_SOFTMAX, OP_STATPOOL, OP_ACT = 1, 2, 3, 4, 5
 (C_OP, C_IN, C_OUT, C_RES, C_H, C_W, C_CIN, C_HO, C_WO, C_COUT, C_KH, C_KW, C_SH, C_SW, C_PT, C_PL,
- C_ACT, C_WOFF, C_BOFF, C_PSOFF, C_PTOFF, C_INMODE, C_POOLKIND, C_ORDER, C_FPOOLH, C_FPOOLW, C_DUALW, C_DUALB) = range(28)
+ C_ACT, C_WOFF, C_BOFF, C_PSOFF, C_PTOFF, C_INMODE, C_POOLKIND, C_ORDER, C_FPOOLH, C_FPOOLW, C_DUALW, C_DUALB, C_ACTPARAM) = range(29)
 PREC_BF16X3, PREC_F32 = 0, 1
 K_ALIGN = 32          # conv weight rows are padded to a multiple of this many k
 BUF_INPUT = -2

@@ -821,6 +821,25 @@ __global__ void pool_kernel(const float* __restrict__ in, float* __restrict__ ou
     (void)cnt;
 }
 
+
+// Elementwise activations that are not fused into a producer's epilogue (ISS_OP_ACT): elu, leaky relu, selu, softplus.  One thread per
+// 4 elements (the tail scalar), grid-stride; in place when in == out.
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ in, float* __restrict__ out, long long total, int act, float alpha) {
+    auto f = [&](float v) {
+        if (act == 4) return v > 0.f ? v : alpha * (expf(v) - 1.f);                       // keras.activations.elu
+        if (act == 5) return v > 0.f ? v : alpha * v;                                    // keras.layers.LeakyReLU
+        if (act == 6) return 1.05070098f * (v > 0.f ? v : 1.67326324f * (expf(v) - 1.f)); // selu
+        return v > 20.f ? v : log1pf(expf(v));                                           // softplus
+    };
+    const long long n4 = total >> 2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4*>(in)[i];
+        v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+    for (long long i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) out[i] = f(in[i]);
+}
+
 __global__ void softmax_kernel(const float* __restrict__ in, float* __restrict__ out, long long rows, int C) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
@@ -971,6 +990,8 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
                     return bad("ISS_C_DUALW / ISS_C_DUALB: rows r - 1, r are not a linear 1x1 projection and the in-place 1x1 expansion it is added to, "
                                "or the concatenated parameters lie outside the blob (include/iss.h)");
             }
+        } else if (R[ISS_C_OP] == ISS_OP_ACT) {
+            if (R[ISS_C_ACT] < 4 || R[ISS_C_ACT] > 7) return bad("ISS_OP_ACT: activation code must be 4 (elu), 5 (leaky relu), 6 (selu) or 7 (softplus)");
         } else if (R[ISS_C_OP] != ISS_OP_POOL && R[ISS_C_OP] != ISS_OP_SOFTMAX && R[ISS_C_OP] != ISS_OP_STATPOOL) {
             return bad("unknown op");
         }
@@ -1669,6 +1690,14 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             iss_prof_begin(c, 2, 0);
             hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, in, out,
                                rows, R[ISS_C_CIN]);
+            iss_prof_end(c);
+        } else if (op == ISS_OP_ACT) {
+            const long long total = (long long)bc * R[ISS_C_H] * R[ISS_C_W] * R[ISS_C_CIN];
+            float alpha;
+            { const int32_t bits = R[ISS_C_ACTPARAM]; memcpy(&alpha, &bits, sizeof(float)); }
+            iss_prof_begin(c, 2, 0);
+            hipLaunchKernelGGL(act_kernel, dim3((unsigned)std::min<long long>((total + 1023) / 1024, 1 << 20)), dim3(256), 0, c->stream, in, out, total,
+                               R[ISS_C_ACT], alpha);
             iss_prof_end(c);
         } else if (op == ISS_OP_STATPOOL) {
             const long long total = (long long)bc * R[ISS_C_H] * R[ISS_C_CIN];

@@ -24,7 +24,9 @@ import numpy as np
 
 from . import _native as N
 
-_ACT_CODE = {None: 0, 'linear': 0, 'relu': 1, 'sigmoid': 2, 'tanh': 3}
+_ACT_CODE = {None: 0, 'linear': 0, 'relu': 1, 'sigmoid': 2, 'tanh': 3}                 # fused into a conv / dense epilogue
+_ACT_OP_CODE = {'elu': 4, 'leaky_relu': 5, 'selu': 6, 'softplus': 7}                   # their own elementwise op (ISS_OP_ACT)
+_ACT_DEFAULT_ALPHA = {'elu': 1.0, 'leaky_relu': 0.3}      # keras.activations.elu / keras.layers.LeakyReLU defaults
 
 
 class CompiledNet:
@@ -110,7 +112,16 @@ def layers_from_keras_config(model_config, weights):
         elif cn == 'Activation':
             layers.append(dict(type='activation', name=name, fn=c['activation']))
         elif cn == 'ReLU':
-            layers.append(dict(type='activation', name=name, fn='relu'))
+            if c.get('max_value') is not None or float(c.get('threshold', 0.0) or 0.0) != 0.0:
+                raise NotImplementedError('ReLU with max_value / threshold')
+            slope = float(c.get('negative_slope', 0.0) or 0.0)
+            layers.append(dict(type='activation', name=name, fn='relu') if slope == 0.0 else
+                          dict(type='activation', name=name, fn='leaky_relu', alpha=slope))
+        elif cn == 'LeakyReLU':
+            layers.append(dict(type='activation', name=name, fn='leaky_relu',
+                               alpha=float(c.get('alpha', c.get('negative_slope', 0.3)))))
+        elif cn == 'ELU':
+            layers.append(dict(type='activation', name=name, fn='elu', alpha=float(c.get('alpha', 1.0))))
         elif cn == 'Softmax':
             layers.append(dict(type='activation', name=name, fn='softmax'))
         elif cn in ('MaxPooling2D', 'AveragePooling2D'):
@@ -279,6 +290,21 @@ class _Builder:
         self.rows.append(r)
         self.use_buf(dst, ho * wo * c)
         return (ho, wo, c)
+
+    def act(self, buf, shape_in, code, alpha):
+        """Elementwise activation in place on `buf` (ISS_OP_ACT: elu / leaky relu / selu / softplus)."""
+        h, w, c = shape_in
+        r = [0] * N.PROG_COLS
+        r[N.C_OP] = N.OP_ACT
+        r[N.C_IN], r[N.C_OUT], r[N.C_RES] = buf, buf, -1
+        r[N.C_H], r[N.C_W], r[N.C_CIN] = h, w, c
+        r[N.C_HO], r[N.C_WO], r[N.C_COUT] = h, w, c
+        r[N.C_ACT] = code
+        r[N.C_ACTPARAM] = int(np.array([alpha], np.float32).view(np.int32)[0])
+        for col in (N.C_WOFF, N.C_BOFF, N.C_PSOFF, N.C_PTOFF):
+            r[col] = -1
+        self.rows.append(r)
+        return shape_in
 
     def softmax(self, src, dst, shape_in):
         h, w, c = shape_in
@@ -450,15 +476,25 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
                 bias = (bias if bias is not None else 0.0) * sc + sft
                 j = peek(j + 1)
             # activation
+            act_alpha = L.get('alpha') if ty in ('conv2d', 'dense') else None
             if act_name in (None, 'linear') and not softmax_after and j < n and layers[j]['type'] == 'activation' \
-                    and layers[j]['fn'] in ('relu', 'sigmoid', 'tanh'):
+                    and layers[j]['fn'] in ('relu', 'sigmoid', 'tanh', 'elu', 'leaky_relu', 'selu', 'softplus'):
                 act_name = layers[j]['fn']
+                act_alpha = layers[j].get('alpha')
                 j = peek(j + 1)
+            # elu / leaky relu / selu / softplus are not fused into the producer's epilogue: the conv runs linear (with a fused MAX pool
+            # in front of the activation when there is one: these functions are non-decreasing for alpha >= 0, so they commute with it)
+            # and an elementwise ISS_OP_ACT row follows; a BatchNorm behind such an activation is lowered on its own afterwards
+            act_op = None
+            if act_name in _ACT_OP_CODE:
+                alpha = float(act_alpha if act_alpha is not None else _ACT_DEFAULT_ALPHA.get(act_name, 0.0))
+                act_op = (_ACT_OP_CODE[act_name], alpha)
+                act_name = 'linear'
             if act_name not in _ACT_CODE:
                 raise NotImplementedError(f"activation {act_name!r}")
             # BN after the activation -> epilogue affine
             ps = pt_ = None
-            if not softmax_after and j < n and layers[j]['type'] == 'batchnorm':
+            if act_op is None and not softmax_after and j < n and layers[j]['type'] == 'batchnorm':
                 sc, sft = _bn_affine(layers[j])
                 if fold_post_bn and _can_fold_forward(layers, j + 1, sc):
                     carry = (sc, sft)               # into the next linear layer's weights and bias
@@ -467,7 +503,8 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
                 j = peek(j + 1)
             # non-overlapping 'valid' pool of 2 or 4 outputs right after -> epilogue
             fpool = None
-            if fuse_pool and not softmax_after and j < n and layers[j]['type'] in ('maxpool', 'avgpool'):
+            if fuse_pool and not softmax_after and j < n and layers[j]['type'] in ('maxpool', 'avgpool') and \
+                    (act_op is None or (layers[j]['type'] == 'maxpool' and act_op[1] >= 0.0)):
                 PL = layers[j]
                 pph, ppw = PL['pool']
                 pst = tuple(PL.get('strides') or PL['pool'])
@@ -506,6 +543,8 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
             pshape = B.conv(cur, dst, (h, w, cin_p), Wm.astype(np.float32), kh, kw, sh, sw, pt, pl, ho, wo,
                             bias=None if bias is None else np.asarray(bias, np.float32),
                             act=_ACT_CODE[act_name], ps=ps, pt_=pt_, inmode=inmode, fpool=fpool, alg_kc=alg_kc)
+            if act_op is not None:
+                B.act(dst, (pshape[0], pshape[1], cout_p), act_op[0], act_op[1])
             shape = (pshape[0], pshape[1], cout)
             pmap = np.concatenate((np.arange(cout), np.full(cout_p - cout, -1)))
             cur, first = dst, False

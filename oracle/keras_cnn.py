@@ -28,11 +28,23 @@ def same_pads(size, k, s):
     return total // 2, total - total // 2
 
 
-def _act_np(x, fn):
+_ALPHA = {'elu': 1.0, 'leaky_relu': 0.3}          # keras.activations.elu / keras.layers.LeakyReLU defaults
+
+
+def _act_np(x, fn, alpha=None):
+    alpha = _ALPHA.get(fn, 0.0) if alpha is None else alpha
     if fn in (None, 'linear'):
         return x
     if fn == 'relu':
         return np.maximum(x, 0)
+    if fn == 'elu':                                # keras.activations.elu: x if x > 0 else alpha * (exp(x) - 1)
+        return np.where(x > 0, x, np.float32(alpha) * (np.exp(np.minimum(x, 0)) - 1))
+    if fn == 'leaky_relu':                         # keras.layers.LeakyReLU: x if x > 0 else alpha * x
+        return np.where(x > 0, x, np.float32(alpha) * x)
+    if fn == 'selu':                               # scale * elu(x, alpha) with the fixed SELU constants
+        return np.float32(1.05070098) * np.where(x > 0, x, np.float32(1.67326324) * (np.exp(np.minimum(x, 0)) - 1))
+    if fn == 'softplus':
+        return np.logaddexp(x, 0)
     if fn == 'sigmoid':
         return 1.0 / (1.0 + np.exp(-x))
     if fn == 'tanh':
@@ -50,11 +62,20 @@ def forward(layers, x, batch_size=1024, threads=None):
     if threads:
         torch.set_num_threads(threads)
 
-    def act(t, fn):
+    def act(t, fn, alpha=None):
+        alpha = _ALPHA.get(fn, 0.0) if alpha is None else alpha
         if fn in (None, 'linear'):
             return t
         if fn == 'relu':
             return torch.relu(t)
+        if fn == 'elu':
+            return F.elu(t, alpha=float(alpha))
+        if fn == 'leaky_relu':
+            return F.leaky_relu(t, negative_slope=float(alpha))
+        if fn == 'selu':
+            return F.selu(t)
+        if fn == 'softplus':
+            return F.softplus(t)
         if fn == 'sigmoid':
             return torch.sigmoid(t)
         if fn == 'tanh':
@@ -83,7 +104,7 @@ def forward(layers, x, batch_size=1024, threads=None):
                         pt, pb = same_pads(t.shape[2], kh, sh)
                         pl, pr = same_pads(t.shape[3], kw, sw)
                         t = F.pad(t, (pl, pr, pt, pb))
-                    t = act_nchw(F.conv2d(t, w, b, stride=(sh, sw)), L.get('activation'), act)
+                    t = act_nchw(F.conv2d(t, w, b, stride=(sh, sw)), L.get('activation'), act, L.get('alpha'))
                 elif ty == 'batchnorm':
                     sc = L['gamma'] / np.sqrt(L['var'] + np.float32(L['eps']))
                     sh_ = L['beta'] - L['mean'] * sc
@@ -94,7 +115,7 @@ def forward(layers, x, batch_size=1024, threads=None):
                     else:
                         t = t * sc_t[None, :, None, None] + sh_t[None, :, None, None]
                 elif ty == 'activation':
-                    t = act(t, L['fn']) if flat else act_nchw(t, L['fn'], act)
+                    t = act(t, L['fn'], L.get('alpha')) if flat else act_nchw(t, L['fn'], act, L.get('alpha'))
                 elif ty in ('maxpool', 'avgpool'):
                     ph, pw = L['pool']
                     sh, sw = L.get('strides') or L['pool']
@@ -116,7 +137,7 @@ def forward(layers, x, batch_size=1024, threads=None):
                     t = t @ torch.from_numpy(L['W'])
                     if L.get('b') is not None:
                         t = t + torch.from_numpy(L['b'])
-                    t = act(t, L.get('activation'))
+                    t = act(t, L.get('activation'), L.get('alpha'))
                 elif ty == 'dropout':
                     pass
                 else:
@@ -125,10 +146,10 @@ def forward(layers, x, batch_size=1024, threads=None):
     return np.concatenate(outs) if outs else np.zeros((0, 0), np.float32)
 
 
-def act_nchw(t, fn, act):
+def act_nchw(t, fn, act, alpha=None):
     if fn == 'softmax':
         return act(t.permute(0, 2, 3, 1), fn).permute(0, 3, 1, 2)
-    return act(t, fn)
+    return act(t, fn, alpha)
 
 
 def forward_naive(layers, x):
@@ -154,12 +175,12 @@ def forward_naive(layers, x):
                     o[:, y, xx, :] = patch @ W.reshape(-1, cout)
             if L.get('b') is not None:
                 o = o + L['b']
-            t = _act_np(o, L.get('activation')).astype(np.float32)
+            t = _act_np(o, L.get('activation'), L.get('alpha')).astype(np.float32)
         elif ty == 'batchnorm':
             sc = L['gamma'] / np.sqrt(L['var'] + np.float32(L['eps']))
             t = (t * sc + (L['beta'] - L['mean'] * sc)).astype(np.float32)
         elif ty == 'activation':
-            t = _act_np(t, L['fn']).astype(np.float32)
+            t = _act_np(t, L['fn'], L.get('alpha')).astype(np.float32)
         elif ty in ('maxpool', 'avgpool'):
             ph, pw = L['pool']; sh, sw = L.get('strides') or L['pool']
             if L.get('padding', 'valid') == 'same':
@@ -183,7 +204,7 @@ def forward_naive(layers, x):
             t = t @ L['W']
             if L.get('b') is not None:
                 t = t + L['b']
-            t = _act_np(t, L.get('activation')).astype(np.float32)
+            t = _act_np(t, L.get('activation'), L.get('alpha')).astype(np.float32)
         elif ty == 'dropout':
             pass
         else:

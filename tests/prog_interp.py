@@ -58,6 +58,10 @@ def run(comp, x):
             out = y[:, :, :ho, :wo].permute(0, 2, 3, 1)
         elif op == N.OP_SOFTMAX:
             out = torch.softmax(src, dim=-1)
+        elif op == N.OP_ACT:                         # elementwise elu / leaky relu / selu / softplus (in place in the program)
+            alpha = float(np.array([int(R[N.C_ACTPARAM])], np.int32).view(np.float32)[0])
+            out = {4: lambda: F.elu(src, alpha=alpha), 5: lambda: F.leaky_relu(src, negative_slope=alpha), 6: lambda: F.selu(src),
+                   7: lambda: F.softplus(src)}[int(R[N.C_ACT])]()
         elif op == N.OP_STATPOOL:                    # mean || std over W (time) per (h, c), torch's (c, h) flatten order
             mean = src.mean(dim=2)                   # (N, H, C)
             std = torch.sqrt((src * src).mean(dim=2) - mean * mean + 1e-10)

@@ -83,6 +83,12 @@ TOPOLOGIES = {
                                             dict(type='maxpool', pool=(2, 2), strides=(2, 2), padding='valid'),
                                             dict(_rand_conv(r, 3, 3, 32, 32, act='relu'), pad=(2, 0, 0, 3)), _rand_bn(r, 32),
                                             dict(type='globalavgpool'), _rand_dense(r, 32, 3, 'softmax')],
+    # activations beyond relu / sigmoid / tanh: ELU (layer, alpha 0.7), LeakyReLU (layer, alpha 0.2), selu and softplus (activation strings)
+    'elu_leaky_selu_softplus': lambda r, h: [_rand_conv(r, 4, 5, 1, 32), dict(type='activation', fn='elu', alpha=0.7),
+                                            dict(type='maxpool', pool=(2, 2), strides=(2, 2), padding='valid'),
+                                            _rand_conv(r, 3, 3, 32, 32), _rand_bn(r, 32), dict(type='activation', fn='leaky_relu', alpha=0.2),
+                                            _rand_conv(r, 3, 3, 32, 64, act='selu'), dict(type='globalavgpool'),
+                                            _rand_dense(r, 64, 32, 'softplus'), _rand_dense(r, 32, 3, 'softmax')],
     'standalone_bn_first': lambda r, h: [_rand_bn(r, 1), _rand_conv(r, 3, 3, 1, 4, act='relu'), dict(type='dropout'),
                                          dict(type='flatten'), _rand_dense(r, 66 * (h - 2) * 4, 64, 'relu'), _rand_bn(r, 64),
                                          _rand_dense(r, 64, 2, 'softmax')],
