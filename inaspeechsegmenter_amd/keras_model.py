@@ -13,7 +13,7 @@ channels-last activations, HWIO conv kernels, (in,out) dense kernels, TF 'same' 
 (H,W,C) order, Dropout = identity.
 
 File formats accepted by `load_model_file`:
-  *.hdf5 / *.h5   Keras HDF5 (needs h5py at run time)
+  *.hdf5 / *.h5   Keras HDF5: h5py where it is installed, else the package's own reader of the file format (hdf5_reader.py)
   *.npz           flat export written by tools/convert_keras_hdf5.py (numpy only):
                   key 'model_config' (JSON string) + one array per '<layer>/<weight>'.
 """
@@ -178,14 +178,13 @@ def load_model_file(path):
             lname, wname = k.rsplit('/', 1) if '/' in k else (k, k)
             weights.setdefault(lname.split('/')[0], {})[_short(wname)] = z[k]
         return layers_from_keras_config(cfg, weights)
-    try:
+    try:                                            # h5py where it exists; else the package's own reader of the file format
         import h5py
-    except ImportError as e:
-        raise ImportError(
-            f"{path}: reading Keras HDF5 needs h5py, which is not installed in this interpreter. "
-            "Convert once with tools/convert_keras_hdf5.py (any python with h5py) and place the "
-            ".npz next to the .hdf5.") from e
-    with h5py.File(path, 'r') as f:
+        opener = lambda p: h5py.File(p, 'r')        # noqa: E731
+    except ImportError:
+        from . import hdf5_reader
+        opener = hdf5_reader.File
+    with opener(path) as f:
         mc = f.attrs['model_config']
         if isinstance(mc, bytes):
             mc = mc.decode('utf-8')

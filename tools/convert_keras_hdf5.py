@@ -19,7 +19,11 @@ import numpy as np
 
 
 def convert(path, out=None):
-    import h5py
+    try:
+        import h5py
+    except ImportError:                              # the package's own reader has the same interface for what is used here
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+        from inaspeechsegmenter_amd import hdf5_reader as h5py
     out = out or os.path.splitext(path)[0] + '.npz'
     arrays = {}
     with h5py.File(path, 'r') as f:
