@@ -394,7 +394,9 @@ class Dataset:
 
 
 class File(Group):
-    def __init__(self, path):
+    def __init__(self, path, mode='r'):
+        if mode != 'r':
+            raise Hdf5Error('this reader opens files read-only')
         with open(path, 'rb') as fh:
             data = fh.read()
         base = data.find(_SIG)
