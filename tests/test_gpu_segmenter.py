@@ -292,3 +292,39 @@ def test_pipeline_mixed_batch_equals_single_calls(seg, tmp_path):
     with __import__('warnings').catch_warnings():
         __import__('warnings').simplefilter('ignore')
         assert table[2] == seg(lin[2]) and table[6] == seg(lin[6])
+
+
+@pytest.mark.parametrize('topology', ['conv1_same', 'conv2_7x7', 'relu_then_bn'])
+def test_other_topologies_through_the_file_pipeline(tmp_path, topology):
+    """A Segmenter whose two nets are NOT the stand-in topology -- a zero-padded first conv (FS form: per-window edge rows indexed by the
+    launch-local window), a 7x7 second conv (ring form, rows per tile < 512), BatchNorm behind the activation (folded forward by the
+    lowering) -- through batch_process (several files laid end to end in one super-batch, window lists offset per file) must give
+    what the per-file calls give, dense batches included, and what the oracle pipeline gives on the same layers."""
+    import topologies as TP
+    from oracle import sidekit as osk, segment as oseg, keras_cnn as ocnn
+    nets = TP.nets(topology, seed=3)
+    models = {'keras_speech_music_noise_cnn.hdf5': nets['vad'], 'keras_male_female_cnn.hdf5': nets['gender']}
+    s2 = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models=models)
+    lin = []
+    for i in range(5):
+        _wav(tmp_path / f't{i}.wav', synth_pcm(70 + i, 16000 * (12 + 5 * i) + 13 * i))
+        lin.append(str(tmp_path / f't{i}.wav'))
+    single = [s2(p) for p in lin]
+    for dense in (False, True):
+        s2.dense_batches = dense
+        lout = [str(tmp_path / f'o{int(dense)}_{i}.csv') for i in range(5)]
+        t, nb, avg, lmsg = s2.batch_process(lin, lout, batch_files=3, workers=2)
+        assert nb == 5, lmsg
+        for seg_i, dst in zip(single, lout):
+            ref = str(tmp_path / 'ref.csv')
+            seg2csv(seg_i, ref)
+            assert filecmp.cmp(dst, ref, shallow=False), (topology, dense, dst)
+    s2.dense_batches = False
+    # the oracle pipeline on file 2 (random weights: the labels mean nothing, the identity of the segmentation does)
+    from inaspeechsegmenter_amd.io import decode_pcm
+    pcm = decode_pcm(lin[2], None, None, None)
+    mspec, loge, difflen = osk.media2feats((pcm / 32768.0).astype(np.float32))
+    want = oseg.segment_feats(mspec, loge, difflen, 0, 'smn', lambda b: ocnn.forward(nets['vad'][0], b), lambda b: ocnn.forward(nets['gender'][0], b))
+    got = single[2]
+    assert [g[0] for g in got] == [w[0] for w in want] and [g[1:] for g in got] == [w[1:] for w in want], (got, want)
+    s2.close()
