@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--out', default=None)
     ap.add_argument('--minutes', type=float, default=60.0)
     ap.add_argument('--only', nargs='*', default=None)
+    ap.add_argument('--reps', type=int, default=3, help='timed runs per net; the fastest counts')
     args = ap.parse_args()
     from inaspeechsegmenter_amd import _native, keras_model as KM, segmenter as S, tables
     import topologies as TP
@@ -45,9 +46,12 @@ def main():
             ctx.cnn_load(5, comp)
             ctx.cnn_probs(5, rows)                                      # warm up at full size (code objects, workspace growth)
             ctx.synchronize()
-            t0 = time.perf_counter()
-            probs, fin = ctx.cnn_probs(5, rows)
-            dt = time.perf_counter() - t0
+            dt = None
+            for _ in range(args.reps):                                  # the fastest of `reps` runs: one run per net caught clock /
+                t0 = time.perf_counter()                                # host hiccups of up to 15 % on single rows
+                probs, fin = ctx.cnn_probs(5, rows)
+                d = time.perf_counter() - t0
+                dt = d if dt is None else min(dt, d)
             idx = np.sort(rng.integers(0, len(rows), 512))
             ref, rfin = _oracle_probs(layers, mspec, shp[1], rows[idx])
             err = float(np.abs(probs[idx] - ref).max())
@@ -68,7 +72,7 @@ def main():
     if args.out:
         with open(args.out, 'w') as f:
             json.dump({'workload': f'{args.minutes:g} min of log-mel rows, both nets dense on every 20 ms slot, CNN stage only '
-                                   '(wall time of iss_cnn_probs incl. result copy)', 'results': res}, f, indent=1)
+                                   '(wall time of iss_cnn_probs incl. result copy; the fastest of ' + str(args.reps) + ' runs per net)', 'results': res}, f, indent=1)
     bad = [e['topology'] for e in res if not e['ok']]
     print('all topologies ok' if not bad else f'FAILED: {bad}')
     return 1 if bad else 0
