@@ -1350,7 +1350,10 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         // FS form: row-major epilogue only.  A second conv WITHOUT a fused pool is not taken: its unpooled output through the row-major
         // epilogue (4-byte stores) measured 3.1 -> 2.3 h/s on conv1_same_nopool against the per-window first layer + transposed kernel
-        const bool ws_fs = fs1 && ws && issk::iss_ws_fs_compiled(a.H_k, a.kw) && !(a.pp == 1 && a.Cout % 4 == 0) && a.sh == 1 && a.sw == 1 &&
+        // ... except the one transposed instantiation: unpadded 5x3 with bias + relu (cnn_ws_f.hip)
+        const bool fs_tr = a.pp == 1 && a.Cout % 4 == 0;
+        const bool fs_tr_ok = fs_tr && a.H_k == 5 && a.kw == 3 && !padded && issk::epi_is_simple_tr(a);
+        const bool ws_fs = fs1 && ws && issk::iss_ws_fs_compiled(a.H_k, a.kw) && (!fs_tr || fs_tr_ok) && a.sh == 1 && a.sw == 1 &&
                            a.Cin >= 2 * F2_CH && !(c->diag & ISS_DIAG_NO_FSAME);
         if (fs1 && !ws_fs) ws = false;
         // weight-stationary kernel with two column halves per workgroup (conv_ws.h, NH = 2): unpadded 3x3 stride-1 layers with
@@ -1530,8 +1533,10 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         } else if (ws && ws_fs) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);
-            iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,false,true,1,%d,fs>", a.H_k, a.kw, padded ? "true" : "false", (int)issk::epi_is_pool_relu(a));
-            if (a.H_k == 5) issk::iss_ws_launch_fs_5x3(a, wgrid, c->stream, padded);
+            iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,%s,true,1,%d,fs>", a.H_k, a.kw, padded ? "true" : "false", fs_tr_ok ? "true" : "false",
+                          fs_tr_ok ? 1 : (int)issk::epi_is_pool_relu(a));
+            if (fs_tr_ok) issk::iss_ws_launch_fs_5x3_tr(a, wgrid, c->stream);
+            else if (a.H_k == 5) issk::iss_ws_launch_fs_5x3(a, wgrid, c->stream, padded);
             else issk::iss_ws_launch_fs_3x3(a, wgrid, c->stream, padded);
         } else if (ws) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));

@@ -694,6 +694,7 @@ inline void iss_ws_launch_ring(const ConvArgs& a, dim3 grid, hipStream_t st, boo
 inline bool iss_ws_fs_compiled(int kh, int kw) { return (kh == 5 && kw == 3) || (kh == 3 && kw == 3); }
 void iss_ws_launch_fs_5x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded);
 void iss_ws_launch_fs_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded);
+void iss_ws_launch_fs_5x3_tr(const ConvArgs& a, dim3 grid, hipStream_t st);   // unpadded, no fused pool: transposed simple epilogue (bias + relu)
 template <int KH, int KW, bool FS_>
 void launch_ws_fused_rowmajor(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded) {
     const bool fast = epi_is_pool_relu(a);
