@@ -1542,6 +1542,13 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);         // persistent: one 512-thread workgroup per CU
             const bool tr = a.pp == 1 && a.Cout % 4 == 0;
+            // <= 32 output channels: one 32-column block per workgroup (conv_ws.h NCB = 1) instead of half-empty 64-column ones
+            const bool ncb1 = !(c->diag & ISS_DIAG_NO_NCB1) && fused && !fs1 && !padded && !tr && a.Cout <= 32 && issk::epi_is_pool_relu(a) &&
+                              issk::iss_ws_ncb1_compiled(a.H_k, a.kw) && a.sh == 1 && a.sw == 1 && a.Cin >= 2 * F2_CH;
+            if (ncb1) {
+                iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,false,false,true,1,1,ncb1>", a.H_k, a.kw);
+                issk::iss_ws_launch_ncb1_5x3(a, wgrid, c->stream);
+            } else {
             // one-wave-per-SIMD, two-footprint variant (conv_wq.h): the dominant launch of the segmenter nets
             bool wq = false;
             if (!(c->diag & ISS_DIAG_NO_WQ) && fused && !padded && !tr && issk::epi_is_pool_relu(a) && a.pp == 4 && a.ph == 2 &&
@@ -1572,6 +1579,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
 #define ISS_WS_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_ws_launch_##KH_##x##KW_(a, wgrid, c->stream, padded, tr, fused); else
             ISS_WS_SHAPES(ISS_WS_CASE) { return iss_fail(c, ISS_EINVAL, "internal: no weight-stationary kernel for %dx%d", a.H_k, a.kw); }
 #undef ISS_WS_CASE
+            }
             }
         } else if (fp) {
 #define ISS_FP_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_fp_launch_##KH_##x##KW_(a, pgrid, c->stream, padded, tr, fused, nh); else

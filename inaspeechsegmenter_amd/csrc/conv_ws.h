@@ -110,8 +110,12 @@ constexpr int ws_lds_bytes(int nt, int nh, bool fs = false) {
 // with element j of the B quad, i.e. lanes 0-31 contribute k = 4 q + j and lanes 32-63 k = 4 (q + 1) + j -- a permutation of the k
 // order that both operands share.  8 MFMAs (16 passes each) per 32 x 32 block and k-step of 16 instead of three bf16 ones; no
 // operand split in the conversion.  Bit-wise an fmaf chain per output, like conv_igemm_kernel, in a different k order.
-template <int KH, int KW, bool PADDED, bool TR, bool FUSED, int NH = 1, int EPI = 0, bool FS = false, bool F32 = false>
+// NCB = 1 (layers with <= 32 output channels; row-major epilogue, NH = 1): one 32-column block per workgroup instead of two -- a
+// 32-channel layer on the 64-column form spends half of its MFMAs on columns that do not exist.  6 MFMAs per tap instead of 12, the
+// weight rows 32..63 of a tile are neither fetched nor read.
+template <int KH, int KW, bool PADDED, bool TR, bool FUSED, int NH = 1, int EPI = 0, bool FS = false, bool F32 = false, int NCB = 2>
 __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
+    static_assert(NCB == 2 || (NCB == 1 && !TR && NH == 1), "");
     constexpr int NT = KH * KW;
     constexpr int NV = NT * NH;                      // virtual steps per block
     constexpr bool RING = ws_ring(NT);               // more taps than resident weight tiles: ring of two tap groups (see ws_tg)
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7
-    const int n0 = blockIdx.y * BN * NH;
+    const int n0 = blockIdx.y * (NCB == 1 ? 32 : BN) * NH;
     const int li = lane & 31, lh = lane >> 5;
     const int M = (int)p.M;
     int totpix;                                      // samples * H * W
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
 #pragma unroll
         for (int k = 0; k < (4 * NV + 7) / 8; ++k) {
             const int i = wv + 8 * k;                // uniform
-            if (i < 4 * NV && (i >> 2) >= v_lo && (i >> 2) < v_hi) {
+            if (i < 4 * NV && (i >> 2) >= v_lo && (i >> 2) < v_hi && !(NCB == 1 && w_half)) {
                 const int v = i >> 2;                // weight tile: tap v / NH (column half v % NH == w_ch)
                 const uint16_t* src = F32 ? reinterpret_cast<const uint16_t*>(p.w + ((v / NH) * p.Cin + c0 + w_plane * 8))
                                           : (w_plane ? p.wl : p.wh) + ((v / NH) * p.Cin + c0);
@@ -408,12 +412,12 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     auto read_bh = [&](BH& f, int tap) {             // hi plane of the tap's weight tile
         const unsigned a = bread + (unsigned)(slot_of(tap) * F2_BST);
         f.b0 = *(LdsR16)(a);
-        f.b1 = *(LdsR16)(a + 1024);
+        if (NCB == 2) f.b1 = *(LdsR16)(a + 1024); else f.b1 = f.b0;
     };
     auto read_bl = [&](BH& f, int tap) {             // lo plane
         const unsigned a = bread + (unsigned)(slot_of(tap) * F2_BST);
         f.b0 = *(LdsR16)(a + 2048);
-        f.b1 = *(LdsR16)(a + 3072);
+        if (NCB == 2) f.b1 = *(LdsR16)(a + 3072); else f.b1 = f.b0;
     };
     // one MFMA pair: A vector x the two column blocks of a weight plane, into the two accumulators of a row block
     auto mfma2 = [&](const bf16x8& av, const BH& b, floatx16& c0, floatx16& c1) {
@@ -432,10 +436,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
         } else
         if (TR) {                                        // C^T: rows = channels, columns = pixels (epilogue_tr)
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.b0, av, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.b1, av, c1, 0, 0, 0);
+            if (NCB == 2) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.b1, av, c1, 0, 0, 0);
         } else {
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b.b0, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b.b1, c1, 0, 0, 0);
+            if (NCB == 2) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b.b1, c1, 0, 0, 0);
         }
     };
 
@@ -642,10 +646,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
                     else if (TR) epilogue_tr(e, c0acc, c1acc, row0 + li, nc, lh);
                     else if (EPI == 1) {
                         epilogue_pool_relu(e, c0acc, row0, nc + li, lh);
-                        epilogue_pool_relu(e, c1acc, row0, nc + 32 + li, lh);
+                        if (NCB == 2) epilogue_pool_relu(e, c1acc, row0, nc + 32 + li, lh);
                     } else {
                         epilogue_tile(e, c0acc, row0, nc + li, lh);
-                        epilogue_tile(e, c1acc, row0, nc + 32 + li, lh);
+                        if (NCB == 2) epilogue_tile(e, c1acc, row0, nc + 32 + li, lh);
                     }
                 }
 #pragma unroll
@@ -704,6 +708,9 @@ void launch_ws_fused_rowmajor(const ConvArgs& a, dim3 grid, hipStream_t st, bool
 #undef ISS_WS_LAUNCH2
 }
 
+// NCB = 1 form (cnn_ws_k.hip): first-layer-fused unpadded 5x3 with <= 32 output channels, pooled relu epilogue
+inline bool iss_ws_ncb1_compiled(int kh, int kw) { return kh == 5 && kw == 3; }
+void iss_ws_launch_ncb1_5x3(const ConvArgs& a, dim3 grid, hipStream_t st);
 // exact-f32 form (cnn_ws_h.hip): the fused 5x3 layer (pooled relu epilogue) and the unpadded 3x3 NH = 2 layers (simple epilogues)
 inline bool iss_ws_f32_fused_compiled(int kh, int kw) { return kh == 5 && kw == 3; }
 void iss_ws_launch_f32_fused_5x3(const ConvArgs& a, dim3 grid, hipStream_t st);
