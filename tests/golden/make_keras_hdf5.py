@@ -13,22 +13,22 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def model(rng):
+def model(rng, nmel=21, ncls=3):
     cfg = {'class_name': 'Sequential', 'config': {'name': 'sequential_1', 'layers': [
-        {'class_name': 'Conv2D', 'config': {'name': 'conv2d_1', 'batch_input_shape': [None, 68, 21, 1], 'filters': 8, 'kernel_size': [4, 5],
+        {'class_name': 'Conv2D', 'config': {'name': 'conv2d_1', 'batch_input_shape': [None, 68, nmel, 1], 'filters': 8, 'kernel_size': [4, 5],
                                              'strides': [1, 1], 'padding': 'valid', 'activation': 'linear', 'use_bias': True}},
         {'class_name': 'BatchNormalization', 'config': {'name': 'batch_normalization_1', 'axis': -1, 'epsilon': 0.001, 'center': True, 'scale': True}},
         {'class_name': 'Activation', 'config': {'name': 'activation_1', 'activation': 'relu'}},
         {'class_name': 'MaxPooling2D', 'config': {'name': 'max_pooling2d_1', 'pool_size': [2, 2], 'strides': [2, 2], 'padding': 'valid'}},
         {'class_name': 'Flatten', 'config': {'name': 'flatten_1'}},
         {'class_name': 'Dropout', 'config': {'name': 'dropout_1', 'rate': 0.2}},
-        {'class_name': 'Dense', 'config': {'name': 'dense_1', 'units': 3, 'activation': 'softmax', 'use_bias': True}}]}}
+        {'class_name': 'Dense', 'config': {'name': 'dense_1', 'units': ncls, 'activation': 'softmax', 'use_bias': True}}]}}
     w = {'conv2d_1': {'kernel:0': rng.normal(0, 0.3, (4, 5, 1, 8)).astype(np.float32), 'bias:0': rng.normal(0, 0.1, 8).astype(np.float32)},
          'batch_normalization_1': {'gamma:0': rng.uniform(0.8, 1.2, 8).astype(np.float32), 'beta:0': rng.normal(0, 0.1, 8).astype(np.float32),
                                    'moving_mean:0': rng.normal(0, 0.1, 8).astype(np.float32),
                                    'moving_variance:0': rng.uniform(0.5, 1.5, 8).astype(np.float32)},
          'activation_1': {}, 'max_pooling2d_1': {}, 'flatten_1': {}, 'dropout_1': {},
-         'dense_1': {'kernel:0': rng.normal(0, 0.05, (32 * 8 * 8, 3)).astype(np.float32), 'bias:0': np.zeros(3, np.float32)}}
+         'dense_1': {'kernel:0': rng.normal(0, 0.05, (32 * ((nmel - 4) // 2) * 8, ncls)).astype(np.float32), 'bias:0': np.zeros(ncls, np.float32)}}
     return cfg, w
 
 
@@ -86,6 +86,10 @@ def main():
             expected[f'{fname}|f16'] = np.asarray(f['a_float16_vector'])
         print(fname, os.path.getsize(path), 'bytes')
     np.savez_compressed(os.path.join(HERE, 'keras_hdf5_expected.npz'), **expected)
+    # a 24-band / 2-class sibling, so that a model directory with BOTH of the reference's file names can be staged
+    # (tests/test_gpu_segmenter.py::test_segmenter_loads_keras_hdf5_files_from_the_model_dir)
+    cfg2, w2 = model(np.random.default_rng(20250927), nmel=24, ncls=2)
+    write(os.path.join(HERE, 'keras2_like_gender.hdf5'), cfg2, w2, 'keras2')
 
 
 if __name__ == '__main__':

@@ -328,3 +328,30 @@ def test_other_topologies_through_the_file_pipeline(tmp_path, topology):
     got = single[2]
     assert [g[0] for g in got] == [w[0] for w in want] and [g[1:] for g in got] == [w[1:] for w in want], (got, want)
     s2.close()
+
+
+def test_segmenter_loads_keras_hdf5_files_from_the_model_dir(tmp_path, monkeypatch):
+    """The reference's default construction -- `Segmenter()` finds `keras_speech_music_noise_cnn.hdf5` / `keras_male_female_cnn.hdf5` in
+    the Keras cache directory (remote_utils.py:18-27, segmenter.py:129-131) -- with two small Keras-layout HDF5 files written by the real
+    h5py (tests/golden/make_keras_hdf5.py) staged under those names: found by locate_model, read by the package's own HDF5 reader (no
+    h5py in this image), lowered, loaded on the device, and the segmentation is what the oracle pipeline gives on the same layers."""
+    import shutil
+    from inaspeechsegmenter_amd import segmenter as S, keras_model as KM
+    d = tmp_path / 'keras_cache'
+    d.mkdir()
+    shutil.copy(os.path.join(GOLDEN, 'keras2_like.hdf5'), d / 'keras_speech_music_noise_cnn.hdf5')
+    shutil.copy(os.path.join(GOLDEN, 'keras2_like_gender.hdf5'), d / 'keras_male_female_cnn.hdf5')
+    monkeypatch.setattr(S, '_MODEL_DIRS', [str(d)])
+    s2 = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None)          # no `models=`: the files decide
+    vad_layers, shp = KM.load_model_file(str(d / 'keras_speech_music_noise_cnn.hdf5'))
+    gen_layers, shp2 = KM.load_model_file(str(d / 'keras_male_female_cnn.hdf5'))
+    assert shp == (68, 21, 1) and shp2 == (68, 24, 1) and len(s2.vad.layers) == len(vad_layers)
+    pcm = synth_pcm(91, 16000 * 25 + 77)
+    _wav(tmp_path / 'x.wav', pcm)
+    got = s2(str(tmp_path / 'x.wav'))
+    mspec, loge, difflen = osk.media2feats((pcm / 32768.0).astype(np.float32))
+    want = oseg.segment_feats(mspec, loge, difflen, 0, 'smn', lambda b: ocnn.forward(vad_layers, b), lambda b: ocnn.forward(gen_layers, b))
+    assert [g[0] for g in got] == [w[0] for w in want] and [g[1:] for g in got] == [w[1:] for w in want], (got, want)
+    with pytest.raises(FileNotFoundError):                                     # the sm engine's file is not there: the reference's message
+        Segmenter(vad_engine='sm', detect_gender=False, ffmpeg=None)
+    s2.close()
