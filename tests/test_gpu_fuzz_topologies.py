@@ -4,7 +4,7 @@ The reference's three nets are un-vendored release assets whose `model_config` i
 segmenter.py:129-131, run at :163): the engine must be right for whatever comes out of that file, not for the shapes the
 kernels were tuned on.  tests/topologies.py moves one design choice at a time; this file draws WHOLE nets from a grammar
 (filter shapes 1x3 ... 7x7, 'valid' / 'same', strides, 16 ... 128 channels incl. 48 / 96, BatchNorm before / after the
-activation, max / average / overlapping pools, flatten or global pooling heads) with a fixed seed and holds every one of them
+activation, elu / leaky relu / selu / softplus, max / average / overlapping pools, flatten or global pooling heads) with a fixed seed and holds every one of them
 to 1e-4 on probabilities, on the segmenter's overlapping window list (shared first layer where it applies), on scattered
 windows, and in the exact-f32 mode."""
 import numpy as np
@@ -15,7 +15,7 @@ import topologies as TP
 from test_gpu_topologies import _mspec, _oracle_probs
 
 pytestmark = pytest.mark.gpu
-NNETS = 28
+NNETS = 48
 
 
 def random_spec(rng):
@@ -26,7 +26,7 @@ def random_spec(rng):
     ch = int(rng.choice([16, 32, 48, 64, 64, 64]))
     nblocks = int(rng.integers(2, 5))
     for b in range(nblocks):
-        shapes = [(3, 3), (5, 3), (4, 5), (3, 5), (5, 5), (7, 7), (1, 3), (3, 1), (2, 2)] if b else [(4, 5), (3, 3), (5, 3), (5, 5), (3, 5)]
+        shapes = [(3, 3), (5, 3), (4, 5), (3, 5), (5, 5), (7, 7), (7, 7), (5, 5), (4, 5), (1, 3), (3, 1), (2, 2)] if b else [(4, 5), (3, 3), (5, 3), (5, 5), (3, 5)]
         shapes = [(kh, kw) for kh, kw in shapes if kh <= h - 2 and kw <= wmin - 1]
         kh, kw = shapes[int(rng.integers(0, len(shapes)))]
         pad = 'same' if rng.random() < 0.4 else 'valid'
@@ -34,7 +34,8 @@ def random_spec(rng):
         spec.append(('conv', kh, kw, ch, pad, stride))
         h = -(-h // stride) if pad == 'same' else (h - kh) // stride + 1
         wmin = -(-wmin // stride) if pad == 'same' else (wmin - kw) // stride + 1
-        spec.append([('bn_relu',), ('relu_bn',), ('relu',), ('bn_relu',)][int(rng.integers(0, 4))])
+        spec.append([('bn_relu',), ('relu_bn',), ('relu',), ('bn_relu',), ('bn_relu',), ('elu', 0.8), ('leaky_relu', 0.1), ('selu',),
+                     ('softplus',)][int(rng.integers(0, 9))])
         r = rng.random()
         if r < 0.5 and h >= 6 and wmin >= 4:
             kind = 'maxpool' if rng.random() < 0.75 else 'avgpool'

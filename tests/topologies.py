@@ -50,6 +50,10 @@ def build(spec, nmel, ncls, seed):
             L.append(_bn(rng, c))
         elif t == 'relu':
             L.append(dict(RELU))
+        elif t in ('elu', 'leaky_relu', 'selu', 'softplus'):             # ('elu', alpha) / ('leaky_relu', alpha) / ('selu',) / ('softplus',)
+            L.append(dict(type='activation', fn=t, **({'alpha': float(item[1])} if len(item) > 1 else {})))
+        elif t == 'bn':
+            L.append(_bn(rng, c))
         elif t == 'bn_relu':
             L += [_bn(rng, c), dict(RELU)]
         elif t == 'relu_bn':
