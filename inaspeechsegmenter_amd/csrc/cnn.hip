@@ -1382,6 +1382,18 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             if (it == n.fp_pix.end()) it = n.fp_pix.emplace(key, footprint_pixels(a, WS_TM)).first;
             ws_plain = it->second <= WS_PIX;
         }
+        // ... and the UNPADDED 3x3 stride-1 layers the two-column-half form does not take (64 / 96 output channels): they ran on
+        // conv_x3_fp_kernel (weights streamed per tap, 215-312 TF); simple transposed epilogue or pooled relu only (cnn_ws_c.hip)
+        bool ws_plain_u = false;
+        if (!no_ws && !(c->diag & ISS_DIAG_NO_WSU3) && !ws_nh2 && pend < 0 && x3 && a.mode == 0 && !padded && a.sh == 1 && a.sw == 1 && !a.res &&
+            issk::iss_ws_plain_compiled(a.H_k, a.kw) && a.Cin % F2_CH == 0 && a.Cin >= 2 * F2_CH && a.M < (1ll << 31) &&
+            (long long)bc * a.img_stride * 4 < (1ll << 32) &&
+            ((a.pp == 1 && a.Cout % 4 == 0 && issk::epi_is_simple_tr(a)) || (a.pp > 1 && issk::epi_is_pool_relu(a)))) {
+            const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 56);
+            auto it = n.fp_pix.find(key);
+            if (it == n.fp_pix.end()) it = n.fp_pix.emplace(key, footprint_pixels(a, WS_TM)).first;
+            ws_plain_u = it->second <= WS_PIX;
+        }
         bool fused = false;
         if (pend >= 0) {
             const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
@@ -1453,7 +1465,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         ws = ws && fused;
         iss_prof_begin(c, 0, fl);
-        iss_prof_tag(c, ws || ws_plain || ws_nh2 ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
+        iss_prof_tag(c, ws || ws_plain || ws_plain_u || ws_nh2 ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
         iss_prof_row(c, r);
         // one-channel 3x3 'same' first layer of a non-PATCH network: direct f32 kernel (either arithmetic mode)
         const bool no_direct = (c->diag & ISS_DIAG_NO_DIRECT1) != 0;
@@ -1515,6 +1527,12 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             if (padded && nh2_pad_pool) issk::iss_ws_launch_nh2_3x3_padded_pool(a, g2, c->stream);
             else if (padded) issk::iss_ws_launch_nh2_3x3_padded(a, g2, c->stream);
             else issk::iss_ws_launch_nh2_3x3(a, g2, c->stream, a.pp == 1 && a.Cout % 4 == 0);
+        } else if (ws_plain_u) {
+            const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
+            const unsigned per_n = std::max(1u, 256u / grid.y);
+            const bool tru = a.pp == 1;
+            iss_prof_inst(c, "conv_x3_ws_kernel<3,3,false,%s,false,1,1,plain>", tru ? "true" : "false");
+            issk::iss_ws_launch_plain_3x3_unpadded(a, dim3(std::min<unsigned>(ngroups, per_n), grid.y), c->stream, tru);
         } else if (ws_plain) {
             const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
             const unsigned per_n = std::max(1u, 256u / grid.y);                   // one 512-thread workgroup per CU in total

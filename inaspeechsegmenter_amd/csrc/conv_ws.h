@@ -721,6 +721,7 @@ void iss_ws_launch_f32_nh2_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, boo
 // pixels per 128 rows, 802 per 512 rows <= WS_PIX) -- they ran on the gather kernel at 6 x their bandwidth bound.
 inline bool iss_ws_plain_compiled(int kh, int kw) { return kh == 3 && kw == 3; }
 void iss_ws_launch_plain_3x3(const ConvArgs& a, dim3 grid, hipStream_t st);     // padded, transposed epilogue (cnn_ws_c.hip)
+void iss_ws_launch_plain_3x3_unpadded(const ConvArgs& a, dim3 grid, hipStream_t st, bool tr);   // tr: bias + relu transposed; else pooled relu
 // NH = 2 (see the kernel): unpadded 3x3 layers with a multiple of 128 output channels (cnn_ws_d.hip); tr: transposed epilogue
 inline bool iss_ws_nh2_compiled(int kh, int kw) { return kh == 3 && kw == 3; }
 void iss_ws_launch_nh2_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool tr);
