@@ -165,15 +165,26 @@ __global__ __launch_bounds__(256, NTN <= 4 ? 2 : 1) void conv_x3_kernel(const Co
 
     float4 ra[4];
     uint4 rbh[NBR], rbl[NBR];
-    int tap_ky = 0, tap_kx = 0, tap_c = 0;          // MODE 0: tap walked by the NEXT gather
+    int tap_ky = 0, tap_kx = 0, tap_c = 0;          // MODE 0 / 3: tap walked by the NEXT gather
+    // MODE 3 (shared first layer, see row_source): the first layer's weight sums / bias of the 4 channels of this k-tile and which of
+    // the 4 rows hold data (a zero-padded tap is a zero of the ACTIVATION, not of the raw row)
+    float4 f_s4 = make_float4(0.f, 0.f, 0.f, 0.f), f_b4 = f_s4;
+    unsigned f_valid = 0;
+    const float f_lob = p.f_act == 1 ? 0.f : -INFINITY;
     auto gather = [&](int kt) {
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 3) {
             const int off = (tap_ky * p.W + tap_kx) * p.Cin + tap_c + k8 * 4;
+            if (MODE == 3) {
+                f_s4 = *reinterpret_cast<const float4*>(p.f_wsum + tap_c + k8 * 4);
+                f_b4 = *reinterpret_cast<const float4*>(p.f_bias + tap_c + k8 * 4);
+                f_valid = 0;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int iy = rs[j].iy0 + tap_ky, ix = rs[j].ix0 + tap_kx;
-                ra[j] = ld4_or_zero(p.in, rs[j].base + off,
-                                    rs[j].ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W);
+                const bool okj = rs[j].ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                ra[j] = ld4_or_zero(p.in, rs[j].base + off, okj);
+                if (MODE == 3) f_valid |= okj ? 1u << j : 0u;
             }
             tap_c += XBK;
             if (tap_c >= p.Cin) { tap_c = 0; if (++tap_kx == p.kw) { tap_kx = 0; ++tap_ky; } }
@@ -194,6 +205,13 @@ __global__ __launch_bounds__(256, NTN <= 4 ? 2 : 1) void conv_x3_kernel(const Co
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bf16x4 h, l;
+            if (MODE == 3) {                             // the window's affine map + activation of the first layer, then the split
+                const float sc = rs[j].sd, mr = rs[j].mean;
+                float4 v = ra[j];
+                v.x = fmaxf(fmaf(v.x, sc, fmaf(f_s4.x, mr, f_b4.x)), f_lob); v.y = fmaxf(fmaf(v.y, sc, fmaf(f_s4.y, mr, f_b4.y)), f_lob);
+                v.z = fmaxf(fmaf(v.z, sc, fmaf(f_s4.z, mr, f_b4.z)), f_lob); v.w = fmaxf(fmaf(v.w, sc, fmaf(f_s4.w, mr, f_b4.w)), f_lob);
+                ra[j] = (f_valid >> j) & 1u ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             split4(ra[j], h, l);
             *reinterpret_cast<bf16x4*>(&sAh[buf][(lr + 32 * j) * XLD + k8 * 4]) = h;
             *reinterpret_cast<bf16x4*>(&sAl[buf][(lr + 32 * j) * XLD + k8 * 4]) = l;
@@ -1165,10 +1183,13 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         if (R2[ISS_C_OP] != ISS_OP_CONV || R2[ISS_C_INMODE] != 0 || R2[ISS_C_IN] != R1[ISS_C_OUT] || R2[ISS_C_RES] >= 0) return false;
         if (R2[ISS_C_CIN] != R1[ISS_C_COUT] || R2[ISS_C_CIN] % XBK != 0 || R2[ISS_C_H] != R1[ISS_C_HO] || R2[ISS_C_W] != R1[ISS_C_WO]) return false;
         const bool ring2 = valid1 && issk::iss_ws_ring_compiled(R2[ISS_C_KH], R2[ISS_C_KW]) && !(c->diag & (ISS_DIAG_NO_RING | ISS_DIAG_NO_WS));
-        if (R2[ISS_C_KH] * R2[ISS_C_KW] < 8 || (!fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW]) && !ring2)) return false;   // (>= 12 unless the weight-stationary kernel takes it, see conv_row)
-        // (a zero-padded second conv is fused by the weight-stationary kernel only; conv_row decides)
+        // a footprint kernel can take it: (a zero-padded second conv is fused by the weight-stationary kernel only; conv_row decides);
         // the footprint may touch two windows at most, and the x / W trick of the kernel needs a small W
-        if (R2[ISS_C_H] * R2[ISS_C_W] < FPIX + 32 || R2[ISS_C_W] > 128) return false;
+        const bool foot2 = R2[ISS_C_KH] * R2[ISS_C_KW] >= 8 && (fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW]) || ring2) &&   // (>= 12 unless the weight-stationary kernel takes it, see conv_row)
+                           R2[ISS_C_H] * R2[ISS_C_W] >= FPIX + 32 && R2[ISS_C_W] <= 128;
+        // ... or the generic gather kernel reads the shared rows itself (conv_x3_kernel<3>): any second conv, 'valid' first layer
+        const bool gath2 = x3mode && valid1 && R1[ISS_C_PSOFF] < 0 && !(c->diag & ISS_DIAG_NO_GFUSED);
+        if (!foot2 && !gath2) return false;
         for (int q = r + 2; q < n.nrows; ++q) {                  // nobody else may read the first layer's output
             const int32_t* Q = &n.prog[(size_t)q * ISS_PROG_COLS];
             if (Q[ISS_C_IN] == R1[ISS_C_OUT] || Q[ISS_C_RES] == R1[ISS_C_OUT]) return false;
@@ -1404,8 +1425,16 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             if (ws_f32 && !fused) { ws = false; fp = false; ws_f32 = false; }                                              // (exact-f32 mode has no other one)
         }
         if (!fused && (long long)bc * a.img_stride >= (1ll << 32)) fp = false;        // 32-bit offsets into the input batch
+        // no footprint kernel fuses it and none would run this conv anyway: the generic gather kernel reads the shared first-layer
+        // rows itself and applies the window's affine map + activation before its operand split (conv_x3_kernel<3>) -- the per-window
+        // first-layer tensor (283-333 KB per slot) is neither written nor read for ANY second conv on overlapping windows
+        bool gfused = false;
+        if (pend >= 0 && !fused && !fp && x3 && a.mode == 0 && !fs1 && d_winrow != nullptr && !(c->diag & ISS_DIAG_NO_GFUSED)) {
+            const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
+            gfused = Rp[ISS_C_PT] == 0 && Rp[ISS_C_PL] == 0 && Rp[ISS_C_PSOFF] < 0 && Rp[ISS_C_ACT] <= 1 && a.M < (1ll << 31);
+        }
         if (pend >= 0) {
-            if (!fused) {                                    // the deferred first layer runs on its own after all
+            if (!fused && !gfused) {                         // the deferred first layer runs on its own after all
                 const int rc = conv_row(pend, -1, -1, -1);
                 if (rc) return rc;
             } else {
@@ -1464,6 +1493,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             }
         }
         ws = ws && fused;
+        if (gfused) a.mode = 3;
         iss_prof_begin(c, 0, fl);
         iss_prof_tag(c, ws || ws_plain || ws_plain_u || ws_nh2 ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
         iss_prof_row(c, r);
@@ -1627,6 +1657,13 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             a.nblk_n = (unsigned)((a.Cout + 32 * ntn - 1) / (32 * ntn));
             const dim3 gridw(a.nblk * a.nblk_n);
             const bool no_pw = (c->diag & ISS_DIAG_NO_PW) != 0;
+            if (gfused) {
+                iss_prof_inst(c, "conv_x3_kernel<3,%s,2>", tr ? "true" : "false");
+                if (tr) hipLaunchKernelGGL((conv_x3_kernel<3, true, 2>), gridw, dim3(256), 0, c->stream, a);
+                else hipLaunchKernelGGL((conv_x3_kernel<3, false, 2>), gridw, dim3(256), 0, c->stream, a);
+                iss_prof_end(c);
+                return ISS_OK;
+            }
             const bool pointwise = !no_pw && a.mode == 0 && tr && a.H_k == 1 && a.kw == 1 && a.sh == 1 && a.sw == 1 && a.pt_ == 0 &&
                                    a.pl_ == 0 && R[ISS_C_HO] == a.H && R[ISS_C_WO] == a.W && a.Kpad == a.Cin;
             if (pointwise) iss_prof_tag(c, ISS_PROF_PW);

@@ -355,7 +355,16 @@ __device__ __forceinline__ RowSrc row_source(const ConvArgs& p, long long m) {
     r.iy0 = oy * p.sh - p.pt_;
     r.ix0 = ox * p.sw - p.pl_;
     r.mean = 0.f; r.sd = 1.f;
-    if (MODE == 2) {
+    if (MODE == 3) {
+        // shared first layer read by the generic kernel: `in` = the first conv on the RAW log-mel rows, once per row; GEMM row's sample
+        // b is a window whose first row is win_row[b].  mean / sd carry the window's affine map: value = relu(R * sd + (bias - mean' ...))
+        // with sd := 1 / std and mean := -mean / std (0 / 0 for a non-finite window: its outputs are replaced by the caller)
+        r.base = ((long long)(p.win_row[b] - p.f_rmin) + r.iy0) * p.row_stride + (long long)r.ix0 * p.pix_stride;
+        const bool live = p.finite[b] != 0;
+        const float rstd = live ? 1.0f / p.stats[2 * b + 1] : 0.f;
+        r.sd = rstd;
+        r.mean = live ? -p.stats[2 * b] * rstd : 0.f;
+    } else if (MODE == 2) {
         r.base = (long long)p.win_row[b] * 24 + (long long)r.iy0 * 24 + r.ix0;
         r.mean = p.stats[2 * b];
         r.sd = p.stats[2 * b + 1];

@@ -199,7 +199,8 @@ int iss_set_precision(iss_ctx* ctx, int mode);
 #define ISS_DIAG_NO_F32WS        0x8000u /* exact-f32 mode: conv_igemm_kernel everywhere (no F32 form of the weight-stationary kernel) */
 #define ISS_DIAG_NO_NCB1         0x10000u /* layers with <= 32 output channels on the 64-column forms (no NCB = 1 form)                 */
 #define ISS_DIAG_NO_WSU3         0x20000u /* unpadded 3x3 layers with 64 / 96 output channels on conv_x3_fp_kernel                      */
-#define ISS_DIAG_ALL             0x3ffffu
+#define ISS_DIAG_NO_GFUSED       0x40000u /* the generic gather kernel never reads the shared first-layer rows (per-window first layer)  */
+#define ISS_DIAG_ALL             0x7ffffu
 int iss_set_diag(iss_ctx* ctx, uint32_t flags);
 
 /* FLOPs (2*MAC of the conv/dense outputs actually computed) per sample of a loaded network. */
