@@ -1429,9 +1429,17 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         // rows itself and applies the window's affine map + activation before its operand split (conv_x3_kernel<3>) -- the per-window
         // first-layer tensor (283-333 KB per slot) is neither written nor read for ANY second conv on overlapping windows
         bool gfused = false;
-        if (pend >= 0 && !fused && !fp && x3 && a.mode == 0 && !fs1 && d_winrow != nullptr && !(c->diag & ISS_DIAG_NO_GFUSED)) {
+        if (pend >= 0 && !fused && x3 && a.mode == 0 && !fs1 && d_winrow != nullptr && !(c->diag & ISS_DIAG_NO_GFUSED)) {
             const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
             gfused = Rp[ISS_C_PT] == 0 && Rp[ISS_C_PL] == 0 && Rp[ISS_C_PSOFF] < 0 && Rp[ISS_C_ACT] <= 1 && a.M < (1ll << 31);
+            if (gfused && fp) {
+                // conv_x3_fp_kernel would run this conv (unfused) at ~330 TFLOP/s where the gather kernel does ~230, but needs the
+                // per-window first-layer tensor, written at ~2.1 TB/s (measured: conv1_patch_x3_kernel): the gather kernel wins when
+                // flops * (1/230e12 - 1/330e12) < bytes / 2.1e12, i.e. below ~360 flops per byte of that tensor (narrow nets)
+                const double bytes1 = (double)bc * Rp[ISS_C_HO] * Rp[ISS_C_WO] * Rp[ISS_C_COUT] * 4.0;
+                gfused = fl < 360.0 * bytes1;
+            }
+            if (gfused) fp = false;
         }
         if (pend >= 0) {
             if (!fused && !gfused) {                         // the deferred first layer runs on its own after all
