@@ -759,3 +759,22 @@ def test_resnet_compile_marks_projection_blocks_for_the_two_source_gemm():
         b = blob[r[N.C_DUALB] - 1:r[N.C_DUALB] - 1 + r[N.C_COUT]]
         assert np.array_equal(b, blob[r[N.C_BOFF]:r[N.C_BOFF] + r[N.C_COUT]] + blob[p[N.C_BOFF]:p[N.C_BOFF] + r[N.C_COUT]])
     assert all(r[N.C_DUALW] == 0 and r[N.C_DUALB] == 0 for i, r in enumerate(prog) if i not in rows)
+
+
+def test_every_diag_switch_of_the_abi_has_its_python_name():
+    """include/iss.h ISS_DIAG_* <-> _native.DIAG_BITS: the same bits under the lower-case names without the prefix (what the
+    ISS_DIAG environment variable and Context.set_diag take), ISS_DIAG_ALL = their union, and unknown names are refused."""
+    import re
+    from inaspeechsegmenter_amd import _native
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    defs = dict(re.findall(r'#define\s+ISS_DIAG_(\w+)\s+(0x[0-9a-fA-F]+)u', open(os.path.join(root, 'include', 'iss.h')).read()))
+    allbits = int(defs.pop('ALL'), 16)
+    assert {k.lower(): int(v, 16) for k, v in defs.items()} == _native.DIAG_BITS
+    union = 0
+    for v in _native.DIAG_BITS.values():
+        assert v and v & (v - 1) == 0 and not (union & v)               # one bit each, no bit twice
+        union |= v
+    assert union == allbits
+    assert _native.diag_flags('no_ring,no_fsame+no_gfused') == 0x2000 | 0x4000 | 0x40000
+    with pytest.raises(KeyError):
+        _native.diag_flags('no_such_switch')
