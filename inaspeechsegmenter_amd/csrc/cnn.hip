@@ -169,9 +169,31 @@ __global__ __launch_bounds__(256, NTN <= 4 ? 2 : 1) void conv_x3_kernel(const Co
     // MODE 3 (shared first layer, see row_source): the first layer's weight sums / bias of the 4 channels of this k-tile and which of
     // the 4 rows hold data (a zero-padded tap is a zero of the ACTIVATION, not of the raw row)
     float4 f_s4 = make_float4(0.f, 0.f, 0.f, 0.f), f_b4 = f_s4;
+    float4 f_sx[4];                                  // MODE 4: S[x][c] of each row's tap column (the weight sum depends on the column)
     unsigned f_valid = 0;
     const float f_lob = p.f_act == 1 ? 0.f : -INFINITY;
     auto gather = [&](int kt) {
+        if (MODE == 4) {
+            // zero-padded ('same') first layer, see conv_ws.h FS: row iy of window b is shared row (win_row[b] - rmin) + iy, except the first
+            // f_padt / last f_padb rows, which are the window's own edge rows f_erow0 + b * ne + e; the shift uses S[ix][c]
+            const int cofs = tap_c + k8 * 4;
+            f_b4 = *reinterpret_cast<const float4*>(p.f_bias + cofs);
+            f_valid = 0;
+            const int ne = p.f_padt + p.f_padb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = rs[j].iy0 + tap_ky, ix = rs[j].ix0 + tap_kx;
+                const bool okj = rs[j].ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const int yb = iy - (p.H - p.f_padb);
+                const int e = iy < p.f_padt ? iy : (yb >= 0 ? p.f_padt + yb : -1);
+                const long long row = e >= 0 ? (long long)p.f_erow0 + (long long)rs[j].b * ne + e : rs[j].base + iy;
+                ra[j] = ld4_or_zero(p.in, (row * p.W + ix) * p.Cin + cofs, okj);
+                f_sx[j] = *reinterpret_cast<const float4*>(p.f_wsum + (okj ? ix * p.Cin + cofs : cofs));
+                f_valid |= okj ? 1u << j : 0u;
+            }
+            tap_c += XBK;
+            if (tap_c >= p.Cin) { tap_c = 0; if (++tap_kx == p.kw) { tap_kx = 0; ++tap_ky; } }
+        } else
         if (MODE == 0 || MODE == 3) {
             const int off = (tap_ky * p.W + tap_kx) * p.Cin + tap_c + k8 * 4;
             if (MODE == 3) {
@@ -205,8 +227,9 @@ __global__ __launch_bounds__(256, NTN <= 4 ? 2 : 1) void conv_x3_kernel(const Co
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bf16x4 h, l;
-            if (MODE == 3) {                             // the window's affine map + activation of the first layer, then the split
+            if (MODE == 3 || MODE == 4) {                // the window's affine map + activation of the first layer, then the split
                 const float sc = rs[j].sd, mr = rs[j].mean;
+                if (MODE == 4) f_s4 = f_sx[j];
                 float4 v = ra[j];
                 v.x = fmaxf(fmaf(v.x, sc, fmaf(f_s4.x, mr, f_b4.x)), f_lob); v.y = fmaxf(fmaf(v.y, sc, fmaf(f_s4.y, mr, f_b4.y)), f_lob);
                 v.z = fmaxf(fmaf(v.z, sc, fmaf(f_s4.z, mr, f_b4.z)), f_lob); v.w = fmaxf(fmaf(v.w, sc, fmaf(f_s4.w, mr, f_b4.w)), f_lob);
@@ -1171,10 +1194,13 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         const bool valid1 = R1[ISS_C_PT] == 0 && R1[ISS_C_PL] == 0 && R1[ISS_C_HO] == R1[ISS_C_H] - R1[ISS_C_KH] + 1 &&
                             R1[ISS_C_WO] == R1[ISS_C_W] - R1[ISS_C_KW] + 1;                                                     // 'valid'
         // 'same' (zero-padded, output = input size): shared through conv_x3_ws_kernel<..., FS> (S table + per-window edge rows)
-        const bool same1 = !valid1 && R1[ISS_C_HO] == R1[ISS_C_H] && R1[ISS_C_WO] == R1[ISS_C_W] && R1[ISS_C_PT] <= R1[ISS_C_KH] - 1 &&
-                           R1[ISS_C_PL] <= R1[ISS_C_KW] - 1 && R1[ISS_C_KH] <= R1[ISS_C_H] && n.wsumx_off[r] >= 0 &&
-                           R1[ISS_C_W] * R1[ISS_C_COUT] * 4 <= issk::WS_STAB && !(c->diag & (ISS_DIAG_NO_FSAME | ISS_DIAG_NO_WS)) &&
-                           R1[ISS_C_PSOFF] < 0 && issk::iss_ws_fs_compiled(R2[ISS_C_KH], R2[ISS_C_KW]);
+        const bool same_geo = !valid1 && R1[ISS_C_HO] == R1[ISS_C_H] && R1[ISS_C_WO] == R1[ISS_C_W] && R1[ISS_C_PT] <= R1[ISS_C_KH] - 1 &&
+                              R1[ISS_C_PL] <= R1[ISS_C_KW] - 1 && R1[ISS_C_KH] <= R1[ISS_C_H] && n.wsumx_off[r] >= 0 && R1[ISS_C_PSOFF] < 0 &&
+                              !(c->diag & ISS_DIAG_NO_FSAME);
+        const bool same_ws = same_geo && R1[ISS_C_W] * R1[ISS_C_COUT] * 4 <= issk::WS_STAB && !(c->diag & ISS_DIAG_NO_WS) &&
+                             issk::iss_ws_fs_compiled(R2[ISS_C_KH], R2[ISS_C_KW]);
+        // ... or through the generic gather kernel (conv_x3_kernel<4>: any second conv)
+        const bool same1 = same_ws || (same_geo && x3mode && !(c->diag & ISS_DIAG_NO_GFUSED));
         if (!valid1 && !same1) return false;
         if (f32defer && (!valid1 || !issk::iss_ws_f32_fused_compiled(R2[ISS_C_KH], R2[ISS_C_KW]) || R2[ISS_C_SH] != 1 || R2[ISS_C_SW] != 1 ||
                          R2[ISS_C_PT] != 0 || R2[ISS_C_PL] != 0 || R1[ISS_C_PSOFF] >= 0)) return false;
@@ -1186,9 +1212,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         // a footprint kernel can take it: (a zero-padded second conv is fused by the weight-stationary kernel only; conv_row decides);
         // the footprint may touch two windows at most, and the x / W trick of the kernel needs a small W
         const bool foot2 = R2[ISS_C_KH] * R2[ISS_C_KW] >= 8 && (fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW]) || ring2) &&   // (>= 12 unless the weight-stationary kernel takes it, see conv_row)
-                           R2[ISS_C_H] * R2[ISS_C_W] >= FPIX + 32 && R2[ISS_C_W] <= 128;
+                           R2[ISS_C_H] * R2[ISS_C_W] >= FPIX + 32 && R2[ISS_C_W] <= 128 && (valid1 || same_ws);
         // ... or the generic gather kernel reads the shared rows itself (conv_x3_kernel<3>): any second conv, 'valid' first layer
-        const bool gath2 = x3mode && valid1 && R1[ISS_C_PSOFF] < 0 && !(c->diag & ISS_DIAG_NO_GFUSED);
+        const bool gath2 = x3mode && (valid1 || same_geo) && R1[ISS_C_PSOFF] < 0 && !(c->diag & ISS_DIAG_NO_GFUSED);
         if (!foot2 && !gath2) return false;
         for (int q = r + 2; q < n.nrows; ++q) {                  // nobody else may read the first layer's output
             const int32_t* Q = &n.prog[(size_t)q * ISS_PROG_COLS];
@@ -1374,7 +1400,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         // ... except the one transposed instantiation: unpadded 5x3 with bias + relu (cnn_ws_f.hip)
         const bool fs_tr = a.pp == 1 && a.Cout % 4 == 0;
         const bool fs_tr_ok = fs_tr && a.H_k == 5 && a.kw == 3 && !padded && issk::epi_is_simple_tr(a);
-        const bool ws_fs = fs1 && ws && issk::iss_ws_fs_compiled(a.H_k, a.kw) && (!fs_tr || fs_tr_ok) && a.sh == 1 && a.sw == 1 &&
+        const bool ws_fs = fs1 && ws && issk::iss_ws_fs_compiled(a.H_k, a.kw) && (!fs_tr || fs_tr_ok) && a.sh == 1 && a.sw == 1 && a.W * a.Cin * 4 <= issk::WS_STAB &&
                            a.Cin >= 2 * F2_CH && !(c->diag & ISS_DIAG_NO_FSAME);
         if (fs1 && !ws_fs) ws = false;
         // weight-stationary kernel with two column halves per workgroup (conv_ws.h, NH = 2): unpadded 3x3 stride-1 layers with
@@ -1429,9 +1455,10 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         // rows itself and applies the window's affine map + activation before its operand split (conv_x3_kernel<3>) -- the per-window
         // first-layer tensor (283-333 KB per slot) is neither written nor read for ANY second conv on overlapping windows
         bool gfused = false;
-        if (pend >= 0 && !fused && x3 && a.mode == 0 && !fs1 && d_winrow != nullptr && !(c->diag & ISS_DIAG_NO_GFUSED)) {
+        if (pend >= 0 && !fused && x3 && a.mode == 0 && d_winrow != nullptr && !(c->diag & ISS_DIAG_NO_GFUSED) && !(fs1 && (c->diag & ISS_DIAG_NO_FSAME))) {
             const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
-            gfused = Rp[ISS_C_PT] == 0 && Rp[ISS_C_PL] == 0 && Rp[ISS_C_PSOFF] < 0 && Rp[ISS_C_ACT] <= 1 && a.M < (1ll << 31);
+            gfused = (fs1 || (Rp[ISS_C_PT] == 0 && Rp[ISS_C_PL] == 0)) && Rp[ISS_C_PSOFF] < 0 && Rp[ISS_C_ACT] <= 1 && a.M < (1ll << 31) &&
+                     (!fs1 || n.wsumx_off[pend] >= 0);
             if (gfused && fp) {
                 // conv_x3_fp_kernel would run this conv (unfused) at ~330 TFLOP/s where the gather kernel does ~230, but needs the
                 // per-window first-layer tensor, written at ~2.1 TB/s (measured: conv1_patch_x3_kernel): the gather kernel wins when
@@ -1501,7 +1528,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             }
         }
         ws = ws && fused;
-        if (gfused) a.mode = 3;
+        if (gfused) a.mode = fs1 ? 4 : 3;
         iss_prof_begin(c, 0, fl);
         iss_prof_tag(c, ws || ws_plain || ws_plain_u || ws_nh2 ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
         iss_prof_row(c, r);
@@ -1666,8 +1693,10 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const dim3 gridw(a.nblk * a.nblk_n);
             const bool no_pw = (c->diag & ISS_DIAG_NO_PW) != 0;
             if (gfused) {
-                iss_prof_inst(c, "conv_x3_kernel<3,%s,2>", tr ? "true" : "false");
-                if (tr) hipLaunchKernelGGL((conv_x3_kernel<3, true, 2>), gridw, dim3(256), 0, c->stream, a);
+                iss_prof_inst(c, "conv_x3_kernel<%d,%s,2>", a.mode, tr ? "true" : "false");
+                if (a.mode == 4 && tr) hipLaunchKernelGGL((conv_x3_kernel<4, true, 2>), gridw, dim3(256), 0, c->stream, a);
+                else if (a.mode == 4) hipLaunchKernelGGL((conv_x3_kernel<4, false, 2>), gridw, dim3(256), 0, c->stream, a);
+                else if (tr) hipLaunchKernelGGL((conv_x3_kernel<3, true, 2>), gridw, dim3(256), 0, c->stream, a);
                 else hipLaunchKernelGGL((conv_x3_kernel<3, false, 2>), gridw, dim3(256), 0, c->stream, a);
                 iss_prof_end(c);
                 return ISS_OK;

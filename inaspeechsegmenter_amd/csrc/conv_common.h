@@ -344,6 +344,7 @@ struct RowSrc {
     int iy0, ix0;
     float mean, sd;
     bool ok;
+    int b;                   // MODE 4: the window (sample) of the row, for its edge rows
 };
 
 template <int MODE>
@@ -355,11 +356,14 @@ __device__ __forceinline__ RowSrc row_source(const ConvArgs& p, long long m) {
     r.iy0 = oy * p.sh - p.pt_;
     r.ix0 = ox * p.sw - p.pl_;
     r.mean = 0.f; r.sd = 1.f;
-    if (MODE == 3) {
+    r.b = b;
+    if (MODE == 3 || MODE == 4) {
         // shared first layer read by the generic kernel: `in` = the first conv on the RAW log-mel rows, once per row; GEMM row's sample
         // b is a window whose first row is win_row[b].  mean / sd carry the window's affine map: value = relu(R * sd + (bias - mean' ...))
         // with sd := 1 / std and mean := -mean / std (0 / 0 for a non-finite window: its outputs are replaced by the caller)
-        r.base = ((long long)(p.win_row[b] - p.f_rmin) + r.iy0) * p.row_stride + (long long)r.ix0 * p.pix_stride;
+        // (MODE 4, zero-padded first layer: base = the window's first shared row only -- the row of a tap is decided per tap, see gather)
+        r.base = MODE == 4 ? (long long)(p.win_row[b] - p.f_rmin)
+                           : ((long long)(p.win_row[b] - p.f_rmin) + r.iy0) * p.row_stride + (long long)r.ix0 * p.pix_stride;
         const bool live = p.finite[b] != 0;
         const float rstd = live ? 1.0f / p.stats[2 * b + 1] : 0.f;
         r.sd = rstd;

@@ -128,6 +128,8 @@ SPECS = {
                   ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 1)] + HEAD,
     'conv2_4x5_same': [('conv', 4, 5, 64), ('bn_relu',), ('conv', 4, 5, 64, 'same'), ('bn_relu',), ('maxpool', 2, 2),
                        ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 1)] + HEAD,
+    'conv1_same_conv2_stride2': [('conv', 4, 5, 64, 'same'), ('bn_relu',), ('conv', 5, 3, 64, 'valid', 2), ('bn_relu',),
+                                 ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 1)] + HEAD,
     'overlap_pool_avg': [('conv', 4, 5, 64), ('bn_relu',), ('conv', 5, 3, 64), ('bn_relu',), ('maxpool', 3, 3, 2, 2),
                          ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('avgpool', 2, 2)] + HEAD,
 }
