@@ -583,6 +583,39 @@ __global__ __launch_bounds__(256) void first_layer_raw_kernel(const float* __res
     }
 }
 
+// A first layer with a fused non-overlapping MAX pool (conv - relu - pool - conv nets), shared between windows: max-pool commutes with the
+// per-window map relu(R / std + t) (std > 0), so the pooled per-window activation is the map applied to maxpool(R).  A window's pool
+// windows start at its own first row: window rows wr with (wr - rmin) % ph == q pool the pairs of PHASE q, so the pooled rows are kept
+// in ph planes, plane q holding max over rows ph * r + q + {0..ph-1}, columns pw * x + {0..pw-1} of R; window b then reads plane q_b from
+// row (wr_b - rmin - q_b) / ph on -- winrow_pool_kernel writes that as one row index into the stacked planes, so the consumer
+// (conv_x3_kernel<3>) needs nothing but the transformed window list.  One thread per (plane, r, x, 4 channels).
+__global__ __launch_bounds__(256) void pool_rows_kernel(const float* __restrict__ R, float* __restrict__ P, long long total, int rrows, int W,
+                                                        int C, int ph, int pw, int plane_rows) {
+    const unsigned cg = (unsigned)C >> 2, Wp = (unsigned)(W / pw);
+    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const unsigned c4 = (unsigned)(idx % cg) * 4u;
+        long long t = idx / cg;
+        const unsigned x = (unsigned)(t % Wp); t /= Wp;
+        const int r = (int)(t % plane_rows), q = (int)(t / plane_rows);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int dy = 0; dy < ph; ++dy) {
+            int row = ph * r + q + dy;
+            row = row < rrows ? row : rrows - 1;                     // (beyond the last row: never read by a window)
+            for (int dx = 0; dx < pw; ++dx) {
+                const float4 v = *reinterpret_cast<const float4*>(R + ((size_t)row * W + (x * pw + dx)) * C + c4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(P + (size_t)idx * 4) = m;
+    }
+}
+__global__ void winrow_pool_kernel(const int32_t* __restrict__ win_row, int32_t* __restrict__ out, int n, int rmin, int ph, int plane_rows) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const int d = win_row[b] - rmin, q = d % ph;
+    out[b] = (d - q) / ph + q * plane_rows;
+}
+
 // Zero-padded ('same') first layer, the rows every window shares (conv_x3_ws_kernel<..., FS>): output row t of the recording,
 // column x, from ALL kh filter rows (input rows t - pt .. t - pt + kh - 1; a window reads row wr + y only for pt <= y < H - pb,
 // where these are its own rows) and the filter columns that see data at x (0 <= x - pl + kx < W: the padding of the normalised
@@ -1189,7 +1222,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         const int32_t* R2 = &n.prog[(size_t)(r + 1) * ISS_PROG_COLS];
         int ph, pw;
         fused_pool_of(R1, ph, pw);
-        if (R1[ISS_C_OP] != ISS_OP_CONV || R1[ISS_C_INMODE] != 1 || ph * pw != 1 || R1[ISS_C_RES] >= 0 || R1[ISS_C_ACT] > 1) return false;
+        const bool pool1 = ph * pw != 1;                 // fused non-overlapping pool behind the first layer: max only, gather path only
+        if (R1[ISS_C_OP] != ISS_OP_CONV || R1[ISS_C_INMODE] != 1 || R1[ISS_C_RES] >= 0 || R1[ISS_C_ACT] > 1) return false;
+        if (pool1 && (R1[ISS_C_POOLKIND] != 0 || !x3mode || (c->diag & ISS_DIAG_NO_GFUSED))) return false;
         if (R1[ISS_C_CIN] != 1 || R1[ISS_C_SH] != 1 || R1[ISS_C_SW] != 1) return false;
         const bool valid1 = R1[ISS_C_PT] == 0 && R1[ISS_C_PL] == 0 && R1[ISS_C_HO] == R1[ISS_C_H] - R1[ISS_C_KH] + 1 &&
                             R1[ISS_C_WO] == R1[ISS_C_W] - R1[ISS_C_KW] + 1;                                                     // 'valid'
@@ -1202,17 +1237,18 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         // ... or through the generic gather kernel (conv_x3_kernel<4>: any second conv)
         const bool same1 = same_ws || (same_geo && x3mode && !(c->diag & ISS_DIAG_NO_GFUSED));
         if (!valid1 && !same1) return false;
+        if (pool1 && !valid1) return false;
         if (f32defer && (!valid1 || !issk::iss_ws_f32_fused_compiled(R2[ISS_C_KH], R2[ISS_C_KW]) || R2[ISS_C_SH] != 1 || R2[ISS_C_SW] != 1 ||
                          R2[ISS_C_PT] != 0 || R2[ISS_C_PL] != 0 || R1[ISS_C_PSOFF] >= 0)) return false;
         if (R1[ISS_C_KH] * R1[ISS_C_KW] * R1[ISS_C_COUT] * 4 > 48 * 1024) return false;        // first_layer_raw_kernel's LDS weights
         if (R1[ISS_C_BOFF] < 0 || (R1[ISS_C_PSOFF] >= 0) != (R1[ISS_C_PTOFF] >= 0) || R1[ISS_C_COUT] % 4 != 0 || n.wsum_off[r] < 0) return false;
         if (R2[ISS_C_OP] != ISS_OP_CONV || R2[ISS_C_INMODE] != 0 || R2[ISS_C_IN] != R1[ISS_C_OUT] || R2[ISS_C_RES] >= 0) return false;
-        if (R2[ISS_C_CIN] != R1[ISS_C_COUT] || R2[ISS_C_CIN] % XBK != 0 || R2[ISS_C_H] != R1[ISS_C_HO] || R2[ISS_C_W] != R1[ISS_C_WO]) return false;
+        if (R2[ISS_C_CIN] != R1[ISS_C_COUT] || R2[ISS_C_CIN] % XBK != 0 || R2[ISS_C_H] != R1[ISS_C_HO] / ph || R2[ISS_C_W] != R1[ISS_C_WO] / pw) return false;
         const bool ring2 = valid1 && issk::iss_ws_ring_compiled(R2[ISS_C_KH], R2[ISS_C_KW]) && !(c->diag & (ISS_DIAG_NO_RING | ISS_DIAG_NO_WS));
         // a footprint kernel can take it: (a zero-padded second conv is fused by the weight-stationary kernel only; conv_row decides);
         // the footprint may touch two windows at most, and the x / W trick of the kernel needs a small W
         const bool foot2 = R2[ISS_C_KH] * R2[ISS_C_KW] >= 8 && (fp_shape_compiled(R2[ISS_C_KH], R2[ISS_C_KW]) || ring2) &&   // (>= 12 unless the weight-stationary kernel takes it, see conv_row)
-                           R2[ISS_C_H] * R2[ISS_C_W] >= FPIX + 32 && R2[ISS_C_W] <= 128 && (valid1 || same_ws);
+                           R2[ISS_C_H] * R2[ISS_C_W] >= FPIX + 32 && R2[ISS_C_W] <= 128 && (valid1 || same_ws) && !pool1;
         // ... or the generic gather kernel reads the shared rows itself (conv_x3_kernel<3>): any second conv, 'valid' first layer
         const bool gath2 = x3mode && (valid1 || same_geo) && R1[ISS_C_PSOFF] < 0 && !(c->diag & ISS_DIAG_NO_GFUSED);
         if (!foot2 && !gath2) return false;
@@ -1351,6 +1387,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         const bool no_ws = (c->diag & ISS_DIAG_NO_WS) != 0;
         // the deferred first layer in front is zero-padded ('same'): only the FS form of the weight-stationary kernel can fuse it
         const bool fs1 = pend >= 0 && (n.prog[(size_t)pend * ISS_PROG_COLS + ISS_C_HO] == n.prog[(size_t)pend * ISS_PROG_COLS + ISS_C_H]);
+        int ph1 = 1, pw1 = 1;                            // the deferred first layer's own fused (max) pool: the gather form only
+        if (pend >= 0) fused_pool_of(&n.prog[(size_t)pend * ISS_PROG_COLS], ph1, pw1);
+        const bool pool1 = ph1 * pw1 != 1;
         if (!no_ws && fp && pend >= 0 && a.H_k * a.kw >= 8 && a.H_k * a.kw <= WS_MAXNT && ws_shape_compiled(a.H_k, a.kw) &&
             a.Cin % F2_CH == 0 && a.H * a.W >= WS_PIX + 64 + (a.pt_ + 1) * a.W && ws_recip_exact(a.W, a.H * a.W + WS_PIX + a.W)) {
             const long long key = ((long long)r << 32) | (unsigned)bc | (1ll << 62);
@@ -1445,7 +1484,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         if (pend >= 0) {
             const int32_t* Rp = &n.prog[(size_t)pend * ISS_PROG_COLS];
             const long long edge_rows = fs1 ? (long long)bc * (Rp[ISS_C_KH] - 1) : 0;                          // per-window edge rows behind R
-            fused = fp && (ws || (!fs1 && !padded && a.H_k * a.kw >= 12)) && d_winrow != nullptr &&
+            fused = !pool1 && fp && (ws || (!fs1 && !padded && a.H_k * a.kw >= 12)) && d_winrow != nullptr &&
                     ((long long)(rmax - rmin) + Rp[ISS_C_HO] + edge_rows) * Rp[ISS_C_WO] * Rp[ISS_C_COUT] * 4 < (1ll << 32);   // 32-bit BYTE offsets into R
             if (ws_ring && !fused) { ws = false; fp = false; ws_ring = false; a.tmr = 0; }                                // (no footprint kernel of that shape)
             if (ws_f32 && !fused) { ws = false; fp = false; ws_f32 = false; }                                              // (exact-f32 mode has no other one)
@@ -1478,7 +1517,10 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 const long long rtot = rrows * R1[ISS_C_WO] * (R1[ISS_C_COUT] / 4);
                 const int f_ne = fs1 ? R1[ISS_C_KH] - 1 : 0;                         // zero-padded first layer: edge rows per window
                 const long long etot = (long long)bc * f_ne * R1[ISS_C_WO] * (R1[ISS_C_COUT] / 4);
-                { const int rc = iss_reserve(c, c->raw1, (size_t)(rtot + etot) * 16); if (rc) return rc; }
+                // pooled planes (ph1 of them) + the transformed window list behind R (see pool_rows_kernel)
+                const int plane_rows = pool1 ? (int)(rrows / ph1) + 2 : 0;
+                const long long ptot = pool1 ? (long long)ph1 * plane_rows * (R1[ISS_C_WO] / pw1) * (R1[ISS_C_COUT] / 4) : 0;
+                { const int rc = iss_reserve(c, c->raw1, (size_t)(rtot + etot + ptot) * 16 + (pool1 ? (size_t)bc * 4 + 16 : 0)); if (rc) return rc; }
                 float* Rraw = (float*)c->raw1.p;
                 iss_prof_begin(c, 2, 0);
                 if (fs1) {
@@ -1517,13 +1559,23 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                                        R1[ISS_C_WO], R1[ISS_C_COUT], R1[ISS_C_KH], R1[ISS_C_KW],
                                        (const float*)(n.d_blob + R1[ISS_C_WOFF]), n.kpad[pend], Rraw);
                 }
+                a.in = Rraw; a.win_row = d_winrow; a.f_rmin = rmin;
+                if (pool1) {
+                    if (ptot >= (1ll << 40)) return iss_fail(c, ISS_EINVAL, "internal: pooled first layer over %lld items", ptot);
+                    float* P = Rraw + (size_t)(rtot + etot) * 4;
+                    int32_t* wr2 = reinterpret_cast<int32_t*>(P + (size_t)ptot * 4);
+                    hipLaunchKernelGGL(pool_rows_kernel, dim3((unsigned)std::min<long long>((ptot + 255) / 256, 8192)), dim3(256), 0, c->stream,
+                                       (const float*)Rraw, P, ptot, (int)rrows, R1[ISS_C_WO], R1[ISS_C_COUT], ph1, pw1, plane_rows);
+                    hipLaunchKernelGGL(winrow_pool_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, c->stream, d_winrow, wr2, bc, rmin, ph1, plane_rows);
+                    a.in = P; a.win_row = wr2; a.f_rmin = 0;
+                }
                 iss_prof_end(c);
-                a.in = Rraw; a.win_row = d_winrow; a.stats = d_stats; a.finite = d_fin;
+                a.stats = d_stats; a.finite = d_fin;
                 a.f_bias = n.d_blob + R1[ISS_C_BOFF];
                 a.f_wsum = fs1 ? n.d_wsum + n.wsumx_off[pend] : n.d_wsum + n.wsum_off[pend];
                 a.f_ps = R1[ISS_C_PSOFF] >= 0 ? n.d_blob + R1[ISS_C_PSOFF] : nullptr;
                 a.f_pt = R1[ISS_C_PTOFF] >= 0 ? n.d_blob + R1[ISS_C_PTOFF] : nullptr;
-                a.f_act = R1[ISS_C_ACT]; a.f_rmin = rmin;
+                a.f_act = R1[ISS_C_ACT];
                 fl += 2.0 * R1[ISS_C_KH] * R1[ISS_C_KW] * (double)R1[ISS_C_COUT] * (double)bc * R1[ISS_C_HO] * R1[ISS_C_WO];
             }
         }

@@ -58,7 +58,7 @@ def test_topology_parity(ctx, name):
         # must be the kernel that ran, and switching it off (gather kernel / per-window first layer) must give the same
         # probabilities up to the summation order
         want_new = {'conv2_7x7': 'ring>', 'conv1_same': 'fs>', 'vgg_same_3x3': 'fs>', 'conv1_same_conv2_same': 'fs>',
-                    'conv1_same3x3_avg': 'fs>', 'conv2_7x7_same_avg': 'ring>', 'conv2_5x5': 'ring>', 'conv2_4x5_same': 'ring>', 'conv1_same_nopool': 'fs>', 'ch32_64': 'ncb1>', 'ch48_96': 'plain>', 'conv2_stride2': ',2>', 'conv1_same_conv2_stride2': ',2>'}.get(name)   # (',2>': conv_x3_kernel<3 | 4,..,2>)
+                    'conv1_same3x3_avg': 'fs>', 'conv2_7x7_same_avg': 'ring>', 'conv2_5x5': 'ring>', 'conv2_4x5_same': 'ring>', 'conv1_same_nopool': 'fs>', 'ch32_64': 'ncb1>', 'ch48_96': 'plain>', 'conv2_stride2': ',2>', 'conv1_same_conv2_stride2': ',2>', 'conv1_pool': ',2>'}.get(name)   # (',2>': conv_x3_kernel<3 | 4,..,2>)
         ctx.prof_enable(True)
         ctx.prof_reset()
         ctx.cnn_probs(5, rows)
