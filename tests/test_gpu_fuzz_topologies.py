@@ -6,7 +6,12 @@ kernels were tuned on.  tests/topologies.py moves one design choice at a time; t
 (filter shapes 1x3 ... 7x7, 'valid' / 'same', strides, 16 ... 128 channels incl. 48 / 96, BatchNorm before / after the
 activation, elu / leaky relu / selu / softplus, max / average / overlapping pools, flatten or global pooling heads) with a fixed seed and holds every one of them
 to 1e-4 on probabilities, on the segmenter's overlapping window list (shared first layer where it applies), on scattered
-windows, and in the exact-f32 mode."""
+windows, and in the exact-f32 mode.
+
+`ISS_FUZZ_NNETS` / `ISS_FUZZ_BASE` widen the draw for a one-off soak run (profiles/r05_scripts/r05_fuzz_soak.sh); the default
+48 nets from base 9000 are what the suite runs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -15,7 +20,8 @@ import topologies as TP
 from test_gpu_topologies import _mspec, _oracle_probs
 
 pytestmark = pytest.mark.gpu
-NNETS = 48
+NNETS = int(os.environ.get('ISS_FUZZ_NNETS', '48'))
+BASE = int(os.environ.get('ISS_FUZZ_BASE', '9000'))
 
 
 def random_spec(rng):
@@ -61,7 +67,7 @@ def random_spec(rng):
 
 @pytest.mark.parametrize('k', range(NNETS))
 def test_random_topology(ctx, k):
-    rng = np.random.default_rng(9000 + k)
+    rng = np.random.default_rng(BASE + k)
     spec = random_spec(rng)
     nmel, ncls = (21, 3) if k % 2 == 0 else (24, 2)
     layers, shp = TP.build(spec, nmel, ncls, seed=100 + k)
