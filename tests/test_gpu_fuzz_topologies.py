@@ -8,7 +8,7 @@ activation, elu / leaky relu / selu / softplus, max / average / overlapping pool
 to 1e-4 on probabilities, on the segmenter's overlapping window list (shared first layer where it applies), on scattered
 windows, and in the exact-f32 mode.
 
-`ISS_FUZZ_NNETS` / `ISS_FUZZ_BASE` widen the draw for a one-off soak run (profiles/r05_scripts/r05_fuzz_soak.sh); the default
+`ISS_FUZZ_NNETS` / `ISS_FUZZ_BASE` / `ISS_FUZZ_T` (frames of the recording) widen the draw for a one-off soak run (profiles/r05_scripts/r05_fuzz_soak.sh); the default
 48 nets from base 9000 are what the suite runs."""
 import os
 
@@ -22,6 +22,7 @@ from test_gpu_topologies import _mspec, _oracle_probs
 pytestmark = pytest.mark.gpu
 NNETS = int(os.environ.get('ISS_FUZZ_NNETS', '48'))
 BASE = int(os.environ.get('ISS_FUZZ_BASE', '9000'))
+FRAMES = int(os.environ.get('ISS_FUZZ_T', '700'))
 
 
 def random_spec(rng):
@@ -71,7 +72,7 @@ def test_random_topology(ctx, k):
     spec = random_spec(rng)
     nmel, ncls = (21, 3) if k % 2 == 0 else (24, 2)
     layers, shp = TP.build(spec, nmel, ncls, seed=100 + k)
-    T = 700
+    T = FRAMES
     mspec = _mspec(rng, T)
     mspec[300:302, 4] = -np.inf
     ctx.set_mspec(mspec)
