@@ -4,12 +4,16 @@ so this module walks the file format itself, like onnx_reader.py does for `final
 
 Covered (what h5py / Keras 2.x and tf.keras write, and a little more):
     superblock versions 0-3; object headers version 1 and 2 (continuation blocks included)
-    groups: symbol tables (B-tree v1 + local heap + SNOD) and compact link messages (new-style groups without dense storage)
-    datasets: contiguous, compact and chunked (B-tree v1) layouts; gzip (deflate) and shuffle filters
+    groups: symbol tables (B-tree v1 + local heap + SNOD), compact link messages, and dense link storage (fractal heap + name-index
+        B-tree v2: what libver='latest' writes once a group has more than eight members)
+    datasets: contiguous, compact and chunked layouts -- B-tree v1 index, and the version-4 layout's single-chunk, implicit and
+        fixed-array indexes; gzip (deflate), shuffle and fletcher32 filters
     datatypes: IEEE floats (16 / 32 / 64 bit), integers, fixed-length strings, variable-length strings (global heap)
-    attributes: message versions 1-3, scalars and arrays
-Not covered, and reported as NotImplementedError naming the feature: dense link / attribute storage (fractal heaps: groups with very
-many links, attributes over 64 KB), virtual / external storage, other filters, compound / array / reference datatypes.
+    attributes: message versions 1-3, scalars and arrays; dense attribute storage (more than eight attributes on a new-style object,
+        or an attribute over 64 KB -- a 'huge' fractal-heap object)
+Not covered, and reported as NotImplementedError naming the feature: extensible-array / B-tree-v2 chunk indexes (datasets with
+unlimited dimensions in libver='latest' files), filtered fractal heaps, virtual / external storage, other filters, compound / array /
+reference datatypes.
 
     f = File(path)
     f.attrs['model_config']                -> bytes / str
@@ -160,20 +164,26 @@ class _Obj:
     # ---- attributes
     def attributes(self):
         out = {}
-        if self.find(0x0015):                                       # attribute info: dense storage?
-            for _, _, body, _ in self.find(0x0015):
-                b = self.f.b
-                flags = b.d[body + 1]
-                p = body + 2 + (2 if flags & 1 else 0)
-                if b.off(p) != _UNDEF[b.so]:
-                    raise NotImplementedError('HDF5 dense attribute storage (fractal heap); attributes over 64 KB are stored that way')
+        for _, _, body, _ in self.find(0x0015):                     # attribute info: dense storage?
+            b = self.f.b
+            flags = b.d[body + 1]
+            p = body + 2 + (2 if flags & 1 else 0)
+            heap, index = b.off(p), b.off(p + b.so)
+            if heap != _UNDEF[b.so]:
+                fh = _FractalHeap(self.f, heap)
+                for rec in _btree2_records(self.f, index, 8):
+                    if rec[fh.id_len] & 2:
+                        raise NotImplementedError('shared HDF5 attribute message')
+                    blob = fh.get(rec[:fh.id_len])
+                    name, val = self._attribute(0, 0, _Buf(blob, b.so, b.sl))
+                    out[name] = val
         for _, mflags, body, _ in self.find(0x000C):
             name, val = self._attribute(body, mflags)
             out[name] = val
         return out
 
-    def _attribute(self, body, mflags):
-        b = self.f.b
+    def _attribute(self, body, mflags, b=None):
+        b = b or self.f.b                                           # (a dense attribute arrives as its own little buffer)
         if mflags & 2:
             raise NotImplementedError('shared HDF5 attribute message')
         ver = b.d[body]
@@ -195,6 +205,162 @@ class _Obj:
 
 class _Attrs(dict):
     pass
+
+
+def _link_message(b, body, links):
+    """One link message (compact: in the object header; dense: a fractal-heap object) -> links[name] = object header address."""
+    ver, flags = b.d[body], b.d[body + 1]
+    if ver != 1:
+        raise NotImplementedError(f'HDF5 link message version {ver}')
+    p = body + 2
+    ltype = 0
+    if flags & 0x08:
+        ltype = b.d[p]; p += 1
+    if flags & 0x04:
+        p += 8
+    if flags & 0x10:
+        p += 1
+    lsz = 1 << (flags & 3)
+    nlen = b.u(p, lsz); p += lsz
+    name = bytes(b.d[p:p + nlen]).decode('utf-8'); p += nlen
+    if ltype == 0:                                                  # (soft / external links are not followed)
+        links[name] = b.off(p)
+
+
+def _enc_size(limit):
+    """Bytes libhdf5 uses for a field that must hold values up to `limit` (H5VM_limit_enc_size)."""
+    return max(int(limit).bit_length() - 1, 0) // 8 + 1
+
+
+def _btree2_records(f, addr, want_type):
+    """All records (raw bytes) of a version-2 B-tree, in key order."""
+    b = f.b
+    if addr == _UNDEF[b.so]:
+        return []
+    if b.d[addr:addr + 4] != b'BTHD':
+        raise Hdf5Error(f'B-tree v2 header signature missing at {addr}')
+    btype, node_size, rec_size, depth = b.d[addr + 5], b.u(addr + 6, 4), b.u(addr + 10, 2), b.u(addr + 12, 2)
+    if btype != want_type:
+        raise Hdf5Error(f'B-tree v2 of type {btype} where type {want_type} was expected')
+    root, nroot = b.off(addr + 16), b.u(addr + 16 + b.so, 2)
+    # node capacities per level (H5B2_hdr_init): leaves first, then each internal level above them
+    max_nrec = [(node_size - 10) // rec_size]
+    cum_size = [0]
+    cum_max = [max_nrec[0]]
+    nrec_size = _enc_size(max_nrec[0])
+    for u in range(1, depth + 1):
+        ptr = b.so + nrec_size + cum_size[u - 1]
+        max_nrec.append((node_size - (10 + ptr)) // (rec_size + ptr))
+        cum_max.append((max_nrec[u] + 1) * cum_max[u - 1] + max_nrec[u])
+        cum_size.append(_enc_size(cum_max[u]))
+    out = []
+
+    def walk(node, nrec, level):
+        sig = b'BTIN' if level else b'BTLF'
+        if b.d[node:node + 4] != sig:
+            raise Hdf5Error(f'B-tree v2 node signature {sig!r} missing at {node}')
+        recs = [bytes(b.d[node + 6 + i * rec_size:node + 6 + (i + 1) * rec_size]) for i in range(nrec)]
+        if not level:
+            out.extend(recs)
+            return
+        p = node + 6 + nrec * rec_size
+        for i in range(nrec + 1):
+            child, cn = b.off(p), b.u(p + b.so, nrec_size)
+            p += b.so + nrec_size + (cum_size[level - 1] if level > 1 else 0)
+            walk(child, cn, level - 1)
+            if i < nrec:
+                out.append(recs[i])
+    if root != _UNDEF[b.so]:
+        walk(root, nroot, depth)
+    return out
+
+
+class _FractalHeap:
+    """Objects of one fractal heap (dense link / attribute storage) by heap ID: managed objects through the doubling table of
+    direct blocks, 'huge' objects through their own B-tree v2, 'tiny' objects from the ID itself."""
+
+    def __init__(self, f, addr):
+        self.f = f
+        b = f.b
+        if b.d[addr:addr + 4] != b'FRHP':
+            raise Hdf5Error(f'fractal heap signature missing at {addr}')
+        so, sl = b.so, b.sl
+        self.id_len, filt_len, self.flags = b.u(addr + 5, 2), b.u(addr + 7, 2), b.d[addr + 9]
+        if filt_len:
+            raise NotImplementedError('HDF5 fractal heap with I/O filters')
+        self.max_man = b.u(addr + 10, 4)
+        p = addr + 14 + sl
+        self.huge_btree = b.off(p)
+        p += so + sl + so + 8 * sl                                  # free space, managed space (4), huge (2) / tiny (2) sizes and counts
+        self.width, self.start, self.max_direct, self.max_heap_bits = b.u(p, 2), b.length(p + 2), b.length(p + 2 + sl), b.u(p + 2 + 2 * sl, 2)
+        p += 2 + 2 * sl + 2 + 2
+        self.root, self.root_rows = b.off(p), b.u(p + so, 2)
+        self.off_size = (self.max_heap_bits + 7) // 8
+        self.len_size = min(((self.max_direct.bit_length() - 1) + 7) // 8, _enc_size(self.max_man))
+        self.max_direct_rows = (self.max_direct.bit_length() - 1) - (self.start.bit_length() - 1) + 2
+        self.blocks = []                                            # (heap offset, file address, size) of every direct block
+        if self.root != _UNDEF[so]:
+            if self.root_rows == 0:
+                self.blocks.append((0, self.root, self.start))
+            else:
+                self._indirect(self.root, self.root_rows)
+        self._huge = None
+
+    def _row_size(self, row):
+        return self.start if row < 2 else self.start << (row - 1)
+
+    def _indirect(self, addr, nrows):
+        b = self.f.b
+        if b.d[addr:addr + 4] != b'FHIB':
+            raise Hdf5Error(f'fractal heap indirect block signature missing at {addr}')
+        base = b.u(addr + 5 + b.so, self.off_size)
+        p = addr + 5 + b.so + self.off_size
+        off = base
+        for row in range(nrows):
+            size = self._row_size(row)
+            for _ in range(self.width):
+                child = b.off(p); p += b.so
+                if child != _UNDEF[b.so]:
+                    if row < self.max_direct_rows:
+                        self.blocks.append((off, child, size))
+                    else:                                           # rows of a child indirect block: it spans `size` bytes of heap space
+                        self._indirect(child, (size.bit_length() - 1) - ((self.start * self.width).bit_length() - 1) + 1)
+                off += size
+
+    def get(self, hid):
+        b = self.f.b
+        kind = (hid[0] >> 4) & 3
+        if hid[0] >> 6:
+            raise NotImplementedError(f'HDF5 fractal heap ID version {hid[0] >> 6}')
+        if kind == 0:                                               # managed: offset and length in the heap's address space
+            off = int.from_bytes(hid[1:1 + self.off_size], 'little')
+            ln = int.from_bytes(hid[1 + self.off_size:1 + self.off_size + self.len_size], 'little')
+            for boff, baddr, bsize in self.blocks:
+                if boff <= off < boff + bsize:
+                    return bytes(b.d[baddr + off - boff:baddr + off - boff + ln])
+            raise Hdf5Error(f'fractal heap offset {off} lies in no direct block')
+        if kind == 2:                                               # tiny: the object is in the ID
+            if self.id_len <= 18:
+                ln = (hid[0] & 0x0F) + 1
+                return bytes(hid[1:1 + ln])
+            ln = (((hid[0] & 0x0F) << 8) | hid[1]) + 1
+            return bytes(hid[2:2 + ln])
+        if kind == 1:                                               # huge: stored outside the heap
+            if self.id_len - 1 >= b.so + b.sl:                      # address and length directly in the ID
+                addr, ln = int.from_bytes(hid[1:1 + b.so], 'little'), int.from_bytes(hid[1 + b.so:1 + b.so + b.sl], 'little')
+                return bytes(b.d[addr:addr + ln])
+            if self._huge is None:                                  # indirect: ID -> (address, length) through a B-tree v2 (type 1)
+                self._huge = {}
+                for rec in _btree2_records(self.f, self.huge_btree, 1):
+                    a, ln, key = (int.from_bytes(rec[:b.so], 'little'), int.from_bytes(rec[b.so:b.so + b.sl], 'little'),
+                                  int.from_bytes(rec[b.so + b.sl:b.so + 2 * b.sl], 'little'))
+                    self._huge[key] = (a, ln)
+            key = int.from_bytes(hid[1:1 + min(b.sl, self.id_len - 1)], 'little')
+            if key not in self._huge:
+                raise Hdf5Error(f'huge fractal-heap object {key} not found')
+            a, ln = self._huge[key]
+            return bytes(b.d[a:a + ln])
+        raise Hdf5Error(f'fractal heap ID of type {kind}')
 
 
 # ------------------------------------------------------------------------------ groups and datasets
@@ -226,28 +392,15 @@ class Group:
                 name = bytes(b.d[hdata + name_off:end]).decode('utf-8')
                 links[name] = oaddr
         for _, _, body, _ in self._obj.find(0x0006):                # new-style group, compact links
-            ver, flags = b.d[body], b.d[body + 1]
-            if ver != 1:
-                raise NotImplementedError(f'HDF5 link message version {ver}')
-            p = body + 2
-            ltype = 0
-            if flags & 0x08:
-                ltype = b.d[p]; p += 1
-            if flags & 0x04:
-                p += 8
-            if flags & 0x10:
-                p += 1
-            lsz = 1 << (flags & 3)
-            nlen = b.u(p, lsz); p += lsz
-            name = bytes(b.d[p:p + nlen]).decode('utf-8'); p += nlen
-            if ltype != 0:
-                continue                                            # soft / external links: not followed
-            links[name] = b.off(p)
+            _link_message(b, body, links)
         for _, _, body, _ in self._obj.find(0x0002):                # link info: dense storage?
             flags = b.d[body + 1]
             p = body + 2 + (8 if flags & 1 else 0)
-            if b.off(p) != _UNDEF[b.so]:
-                raise NotImplementedError('HDF5 dense link storage (fractal heap): a group with very many members')
+            heap, index = b.off(p), b.off(p + b.so)
+            if heap != _UNDEF[b.so]:
+                fh = _FractalHeap(f, heap)
+                for rec in _btree2_records(f, index, 5):            # name index: hash (4 bytes), heap ID
+                    _link_message(_Buf(fh.get(rec[4:4 + fh.id_len]), b.so, b.sl), 0, links)
         self._links = links
         return links
 
@@ -329,8 +482,8 @@ class Dataset:
         if ver not in (3, 4):
             raise NotImplementedError(f'HDF5 data layout message version {ver}')
         cls = b.d[body + 1]
-        if ver == 4 and cls >= 2:
-            raise NotImplementedError('HDF5 version-4 chunk indexes / virtual datasets (libver=latest chunked datasets)')
+        if ver == 4 and cls == 2:
+            return self._chunked_v4(body, shape, esz)
         if cls == 0:                                                # compact
             return f._decode(self._dt, shape, b.d, body + 4)
         if cls == 1:                                                # contiguous
@@ -365,14 +518,81 @@ class Dataset:
                 out.append((fid, cd))
         return out
 
+    def _chunked_v4(self, body, shape, esz):
+        """Version-4 layout message (libver='latest'): the chunk index is chosen per dataset -- one chunk, an implicit array of
+        early-allocated chunks, or a fixed array; datasets with unlimited dimensions use two more that are not read here."""
+        f, b = self._f, self._f.b
+        flags, rank, enc = b.d[body + 2], b.d[body + 3], b.d[body + 4]
+        dims = [b.u(body + 5 + i * enc, enc) for i in range(rank)]
+        p = body + 5 + rank * enc
+        itype = b.d[p]; p += 1
+        chunk = dims[:-1]
+        grid = [-(-s // c) for s, c in zip(shape, chunk)]
+        nchunks = int(np.prod(grid))
+        raw_size = int(np.prod(chunk)) * esz
+        offsets = [tuple(int(i) * c for i, c in zip(np.unravel_index(k, grid), chunk)) for k in range(nchunks)]
+        if itype == 1:                                              # single chunk
+            csize, fmask = raw_size, 0
+            if flags & 2:
+                csize, fmask = b.length(p), b.u(p + b.sl, 4); p += b.sl + 4
+            addr = b.off(p)
+            return self._chunked([(offsets[0], addr, csize, fmask)] if addr != _UNDEF[b.so] else [], chunk, shape, esz)
+        if itype == 2:                                              # implicit: all chunks allocated, back to back, never filtered
+            addr = b.off(p)
+            return self._chunked([(o, addr + k * raw_size, raw_size, 0) for k, o in enumerate(offsets)] if addr != _UNDEF[b.so] else [],
+                                 chunk, shape, esz)
+        if itype == 3:                                              # fixed array
+            addr = b.off(p + 1)
+            if addr == _UNDEF[b.so]:
+                return self._chunked([], chunk, shape, esz)
+            if b.d[addr:addr + 4] != b'FAHD':
+                raise Hdf5Error(f'fixed array header signature missing at {addr}')
+            client, entry, page_bits = b.d[addr + 5], b.d[addr + 6], b.d[addr + 7]
+            nelm, dblk = b.length(addr + 8), b.off(addr + 8 + b.sl)
+            if dblk == _UNDEF[b.so]:
+                return self._chunked([], chunk, shape, esz)
+            if b.d[dblk:dblk + 4] != b'FADB':
+                raise Hdf5Error(f'fixed array data block signature missing at {dblk}')
+            q = dblk + 6 + b.so
+            per_page = 1 << page_bits
+            starts = []                                             # file position of each element
+            if nelm > per_page:                                     # paged: bitmap of initialised pages, checksum, then the pages
+                npages = -(-nelm // per_page)
+                bitmap = b.d[q:q + (npages + 7) // 8]
+                q += (npages + 7) // 8 + 4
+                for pg in range(npages):
+                    cnt = min(per_page, nelm - pg * per_page)
+                    init = bitmap[pg // 8] & (0x80 >> (pg % 8))
+                    starts += [q + i * entry if init else None for i in range(cnt)]
+                    q += cnt * entry + 4                            # (every page has its place in the file, written or not)
+            else:
+                starts = [q + i * entry for i in range(nelm)]
+            chunks = []
+            for k, o in enumerate(offsets):
+                e = starts[k] if k < len(starts) else None
+                if e is None:
+                    continue
+                caddr = b.off(e)
+                if caddr == _UNDEF[b.so]:
+                    continue
+                if client == 1:                                     # filtered chunks: address, size on disk, filter mask
+                    nsz = entry - b.so - 4
+                    chunks.append((o, caddr, b.u(e + b.so, nsz), b.u(e + b.so + nsz, 4)))
+                else:
+                    chunks.append((o, caddr, raw_size, 0))
+            return self._chunked(chunks, chunk, shape, esz)
+        names = {4: 'extensible array', 5: 'B-tree v2'}
+        raise NotImplementedError(f'HDF5 chunk index of type {names.get(itype, itype)} (datasets with unlimited dimensions)')
+
     def _chunked(self, btree, chunk, shape, esz):
+        """`btree`: address of the version-1 chunk B-tree, or the chunk list [(offsets, address, bytes, filter mask)] itself."""
         if self._dt.np_dtype is None:
             raise NotImplementedError('chunked HDF5 dataset of a variable-length type')
         f, b = self._f, self._f.b
         filters = self._filters()
         out = np.zeros(shape, self._dt.np_dtype)
         rank = len(shape)
-        for offs, caddr, csize, fmask in f._chunk_btree(btree, rank):
+        for offs, caddr, csize, fmask in (btree if isinstance(btree, list) else f._chunk_btree(btree, rank)):
             raw = bytes(b.d[caddr:caddr + csize])
             for k, (fid, cd) in reversed(list(enumerate(filters))):
                 if fmask & (1 << k):
@@ -516,7 +736,7 @@ class File(Group):
         if shape is None:                                           # null dataspace
             return None
         if dt.kind == 'vlen_string':
-            b = self.b
+            b = _Buf(data, self.b.so, self.b.sl)                       # (the descriptors may sit in a heap object's own buffer)
             vals = []
             for i in range(n):
                 p = pos + i * (4 + b.so + 4)
