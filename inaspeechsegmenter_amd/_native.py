@@ -107,7 +107,7 @@ def lib():
 
 DIAG_BITS = {'no_shared_first': 0x001, 'no_flrows': 0x002, 'no_ws': 0x004, 'no_ws3': 0x008, 'no_direct1': 0x010,
              'no_nh2': 0x020, 'no_tr': 0x040, 'no_pw': 0x080, 'no_pws': 0x100, 'no_pws2': 0x200, 'no_wq': 0x400,
-             'no_dual': 0x800, 'no_chain': 0x1000, 'no_ring': 0x2000, 'no_fsame': 0x4000, 'no_f32ws': 0x8000, 'no_ncb1': 0x10000, 'no_wsu3': 0x20000, 'no_gfused': 0x40000}                                                                                         # include/iss.h ISS_DIAG_*
+             'no_dual': 0x800, 'no_chain': 0x1000, 'no_ring': 0x2000, 'no_fsame': 0x4000, 'no_f32ws': 0x8000, 'no_ncb1': 0x10000, 'no_wsu3': 0x20000, 'no_gfused': 0x40000, 'no_hl': 0x80000}                                                                                         # include/iss.h ISS_DIAG_*
 
 
 def diag_flags(names):

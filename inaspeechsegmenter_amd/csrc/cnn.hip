@@ -21,10 +21,12 @@
 //   pool_kernel          max / average pooling, NHWC (pools that cannot be fused)
 //   softmax_kernel       softmax over channels
 //   statpool_kernel      mean || std over time                           (resnet.py:123-127)
+#include <map>
 #include "conv_common.h"
 #include "conv_ws.h"
 #include "conv_wq.h"
 #include "conv_wq3.h"
+#include "conv_wq3h.h"
 #include "conv_pwc.h"
 #include "conv_pw.h"
 
@@ -1284,6 +1286,73 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
 #else
     constexpr bool asm_ring_ok = true;
 #endif
+    // ---- CHL hand-over between footprint kernels (conv_common.h, round 6).  hl_np[buffer] = pixels per plane while the tensor in
+    // that activation buffer is in the CHL layout (absent: f32 NHWC).  A producer writes CHL only when the NEXT row is the tensor's
+    // only reader and runs on conv_x3_wq3h_kernel (wq3_plan: the conditions conv_row launches conv_x3_wq3_kernel under).
+    std::map<int, unsigned> hl_np;
+    int hl_out_row = -1;                                         // the row conv_row has just launched with a CHL output ...
+    unsigned hl_out_np = 0;                                      // ... and its plane size
+    const bool no_hl = (c->diag & ISS_DIAG_NO_HL) != 0;
+    auto wq3_plan = [&](int q, int* tmr_out) -> int {            // -1, or the kind (0: bias + relu, 1: relu + 2 x 1 max-pool)
+        if (q < 0 || q >= n.nrows || !x3mode) return -1;
+        if (c->diag & (ISS_DIAG_NO_WS | ISS_DIAG_NO_WS3 | ISS_DIAG_NO_WQ)) return -1;
+        const int32_t* R = &n.prog[(size_t)q * ISS_PROG_COLS];
+        if (R[ISS_C_OP] != ISS_OP_CONV || R[ISS_C_INMODE] != 0 || R[ISS_C_IN] == ISS_BUF_INPUT || R[ISS_C_RES] >= 0 || R[ISS_C_DUALW] != 0) return -1;
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.H = R[ISS_C_H]; a.W = R[ISS_C_W]; a.Cin = R[ISS_C_CIN]; a.Cout = R[ISS_C_COUT];
+        fused_pool_of(R, a.ph, a.pw);
+        a.pp = a.ph * a.pw;
+        a.poolkind = R[ISS_C_POOLKIND];
+        a.Hq = R[ISS_C_HO] / a.ph; a.Wq = R[ISS_C_WO] / a.pw;
+        a.H_k = R[ISS_C_KH]; a.kw = R[ISS_C_KW];
+        a.sh = R[ISS_C_SH]; a.sw = R[ISS_C_SW]; a.pt_ = R[ISS_C_PT]; a.pl_ = R[ISS_C_PL];
+        a.act = R[ISS_C_ACT];
+        a.M = (long long)bc * a.Hq * a.Wq * a.pp;
+        a.img_stride = (long long)a.H * a.W * a.Cin;
+        const bool padded = a.pt_ != 0 || a.pl_ != 0 || (R[ISS_C_HO] - 1) * a.sh - a.pt_ + a.H_k > a.H || (R[ISS_C_WO] - 1) * a.sw - a.pl_ + a.kw > a.W;
+        if (a.Cin % XBK != 0 || padded || a.sh != 1 || a.sw != 1 || a.Cout % (2 * BN) != 0 || !issk::iss_ws_nh2_compiled(a.H_k, a.kw) || a.H_k != 3 || a.kw != 3 ||
+            a.Cin % F2_CH != 0 || a.Cin < 2 * F2_CH || a.M >= (1ll << 31) || (long long)bc * a.img_stride * 4 >= (1ll << 32)) return -1;
+        if (R[ISS_C_BOFF] < 0 || a.act != 1 || R[ISS_C_PSOFF] >= 0 || !ws_recip_exact(a.W, issk::WQ3_PIX + a.W)) return -1;
+        {
+            const long long key = ((long long)q << 32) | (unsigned)bc | (1ll << 60);
+            auto it = n.fp_pix.find(key);
+            if (it == n.fp_pix.end()) it = n.fp_pix.emplace(key, footprint_pixels(a, WS_TM)).first;
+            if (it->second > WS_PIX2) return -1;
+        }
+        int kind = -1;
+        if (a.pp == 1 && a.M * (long long)a.Cout * 4 < 0xFFF00000ll) kind = 0;
+        else if (a.pp == 2 && a.ph == 2 && a.poolkind == 0 && (a.M / 2) * (long long)a.Cout * 4 < 0xFFF00000ll) kind = 1;
+        if (kind < 0) return -1;
+        const long long key = ((long long)q << 32) | (unsigned)bc | (1ll << 58);
+        auto it = n.fp_pix.find(key);
+        if (it == n.fp_pix.end()) {
+            int tmr = 0;
+            for (int cand = issk::WQ3_TM; cand >= issk::WQ3_TM - 64 && !tmr; cand -= 4)
+                if (footprint_pixels(a, cand) <= issk::WQ3_PIX) tmr = cand;
+            it = n.fp_pix.emplace(key, tmr).first;
+        }
+        if (it->second <= 0) return -1;
+        if (tmr_out) *tmr_out = it->second;
+        return kind;
+    };
+    // row r's output (Cout channels, `npix` pixels for this call) may be written in the CHL layout: row r + 1 is a conv_x3_wq3h_kernel
+    // launch that reads it, and nobody else does before the buffer is written again
+    auto want_hl_out = [&](int r, long long npix) -> bool {
+        if (no_hl || r + 1 >= n.nrows) return false;
+        const int32_t* R = &n.prog[(size_t)r * ISS_PROG_COLS];
+        const int32_t* Q = &n.prog[(size_t)(r + 1) * ISS_PROG_COLS];
+        const int ob = R[ISS_C_OUT];
+        if (Q[ISS_C_IN] != ob || Q[ISS_C_OUT] == ob || Q[ISS_C_CIN] != R[ISS_C_COUT] || R[ISS_C_COUT] % (2 * BN) != 0 && R[ISS_C_COUT] != BN) return false;
+        if (npix != (long long)bc * Q[ISS_C_H] * Q[ISS_C_W] || !issk::chl_fits(npix, R[ISS_C_COUT])) return false;
+        if (wq3_plan(r + 1, nullptr) < 0) return false;
+        for (int t = r + 2; t < n.nrows; ++t) {
+            const int32_t* T = &n.prog[(size_t)t * ISS_PROG_COLS];
+            if (T[ISS_C_IN] == ob || T[ISS_C_RES] == ob) return false;
+            if (T[ISS_C_OUT] == ob) break;
+        }
+        return true;
+    };
     constexpr int kDualDeclined = -12345;                        // conv_row(r, -1, r - 1): the two-source launch is not possible for this call
     std::function<int(int, int, int, int)> conv_row = [&](int r, int pend, int dual, int chain) -> int {
         const int32_t* R = &n.prog[(size_t)r * ISS_PROG_COLS];
@@ -1312,6 +1381,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         a.M = (long long)bc * a.Hq * a.Wq * a.pp;
         const bool patch = R[ISS_C_INMODE] == 1;
         const bool x3 = c->precision == ISS_PREC_BF16X3;
+        const bool in_is_hl = R[ISS_C_IN] != ISS_BUF_INPUT && hl_np.count(R[ISS_C_IN]) != 0;     // (only conv_x3_wq3h_kernel reads that layout)
+        bool in_hl_taken = false;
         a.mode = patch ? 2 : ((a.Cin % (x3 ? XBK : 4) == 0) ? 0 : 1);
         const bool window = R[ISS_C_INMODE] == 2;
         if (patch) {
@@ -1638,8 +1709,16 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             if (wq3_kind >= 0) {
                 const unsigned qtiles = (unsigned)((a.M + a.tmr - 1) / a.tmr);
                 const dim3 qgrid(std::min<unsigned>((qtiles + 1) / 2, std::max(1u, 256u / ny)), ny);
+                if (in_is_hl) {                                  // the producer wrote the CHL layout for this launch (want_hl_out)
+                    a.in_hl = 1; a.in_np = hl_np[R[ISS_C_IN]];
+                    if (wq3_kind == 0 && want_hl_out(r, a.M)) { a.out_hl = 1; a.out_np = issk::chl_npad(a.M); hl_out_row = r; hl_out_np = a.out_np; }
+                    iss_prof_inst(c, "conv_x3_wq3h_kernel<%d,%s>", wq3_kind, a.out_hl ? "true" : "false");
+                    issk::iss_wq3h_launch(a, qgrid, c->stream, wq3_kind);
+                    in_hl_taken = true;
+                } else {
                 iss_prof_inst(c, "conv_x3_wq3_kernel<%d>", wq3_kind);
                 issk::iss_wq3_launch(a, qgrid, c->stream, wq3_kind);
+                }
             } else
             if (padded && nh2_pad_pool) issk::iss_ws_launch_nh2_3x3_padded_pool(a, g2, c->stream);
             else if (padded) issk::iss_ws_launch_nh2_3x3_padded(a, g2, c->stream);
@@ -1704,7 +1783,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             if (wq) {
                 const unsigned qtiles = (unsigned)((a.M + a.tmr - 1) / a.tmr);
                 const dim3 qgrid(std::min<unsigned>((qtiles + 1) / 2, 256u), grid.y);     // persistent: one 256-thread workgroup per CU
-                iss_prof_inst(c, "conv_x3_wq_kernel<%d,%d>", a.H_k, a.kw);
+                if (a.Cout % BN == 0 && want_hl_out(r, a.M / 4)) { a.out_hl = 1; a.out_np = issk::chl_npad(a.M / 4); hl_out_row = r; hl_out_np = a.out_np; }
+                iss_prof_inst(c, a.out_hl ? "conv_x3_wq_kernel<%d,%d,hl>" : "conv_x3_wq_kernel<%d,%d>", a.H_k, a.kw);
                 issk::iss_wq_launch_5x3(a, qgrid, c->stream);
             } else {
             {
@@ -1797,6 +1877,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             else hipLaunchKernelGGL(conv_igemm_kernel<2>, grid1, dim3(256), 0, c->stream, a);
         }
         iss_prof_end(c);
+        if (in_is_hl && !in_hl_taken) return iss_fail(c, ISS_EINVAL, "internal: row %d reads a CHL tensor on a kernel that expects f32", r);
         return ISS_OK;
     };
     int pending = -1;                                            // deferred PATCH first layer (see can_defer)
@@ -1813,7 +1894,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 const int rc2 = conv_row(r, -1, -1, r + 1);
                 if (rc2 == ISS_OK) {
                     ISS_HIP(c, hipGetLastError());
+                    hl_np.erase(R[ISS_C_OUT]);
                     ++r;
+                    hl_np.erase(n.prog[(size_t)r * ISS_PROG_COLS + ISS_C_OUT]);
                     *result = (float*)c->act[n.prog[(size_t)r * ISS_PROG_COLS + ISS_C_OUT]].p;
                     continue;
                 }
@@ -1826,13 +1909,16 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 const int rc2 = conv_row(r + 1, -1, r, -1);
                 if (rc2 == ISS_OK) {
                     ISS_HIP(c, hipGetLastError());
+                    hl_np.erase(R[ISS_C_OUT]);
                     ++r;
+                    hl_np.erase(n.prog[(size_t)r * ISS_PROG_COLS + ISS_C_OUT]);
                     *result = (float*)c->act[n.prog[(size_t)r * ISS_PROG_COLS + ISS_C_OUT]].p;
                     continue;
                 }
                 if (rc2 != kDualDeclined) return rc2;
             }
             const int rc = conv_row(r, pending, -1, -1);
+            if (pending >= 0) hl_np.erase(n.prog[(size_t)pending * ISS_PROG_COLS + ISS_C_OUT]);
             pending = -1;
             if (rc) return rc;
         } else if (op == ISS_OP_POOL) {
@@ -1865,6 +1951,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         ISS_HIP(c, hipGetLastError());
         *result = out;
+        if (hl_out_row == r) hl_np[R[ISS_C_OUT]] = hl_out_np; else hl_np.erase(R[ISS_C_OUT]);
+        if (op != ISS_OP_CONV && R[ISS_C_IN] != ISS_BUF_INPUT && hl_np.count(R[ISS_C_IN]))
+            return iss_fail(c, ISS_EINVAL, "internal: row %d reads a CHL tensor", r);
     }
     return ISS_OK;
 }
@@ -1884,7 +1973,7 @@ int plan_chunk(iss_ctx* c, IssNet& n, int total, int* bc_out) {
     if (bc > 8) bc -= bc % 8;
     if ((int)c->act.size() < n.nbuf) c->act.resize(n.nbuf);
     for (int i = 0; i < n.nbuf; ++i) {
-        int rc = iss_reserve(c, c->act[i], (size_t)bc * n.buf_elems[i] * sizeof(float));
+        int rc = iss_reserve(c, c->act[i], (size_t)bc * n.buf_elems[i] * sizeof(float) + issk::ISS_ACT_SLACK);
         if (rc) return rc;
     }
     *bc_out = (int)bc;

@@ -3,6 +3,7 @@
 
 namespace issk {
 void iss_wq_launch_5x3(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_x3_wq_kernel<5, 3>), grid, dim3(256), 0, st, a);
+    if (a.out_hl) hipLaunchKernelGGL((conv_x3_wq_kernel<5, 3, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_x3_wq_kernel<5, 3, false>), grid, dim3(256), 0, st, a);
 }
 }  // namespace issk

@@ -84,7 +84,29 @@ struct ConvArgs {
     const float* bias2;
     float* out2;
     int act2, Cout2;
+    // ---- split-bf16 activation tensors between two footprint kernels (the "CHL" layout, see chl_* below): in_hl / out_hl = the
+    // input / output of this launch is one; in_np / out_np = pixels per plane (chl_npad of the tensor's pixel count)
+    int in_hl, out_hl;
+    unsigned in_np, out_np;
 };
+
+// ------------------------------------------------------------------------------------------
+// CHL: the activation layout a footprint kernel's producer writes for a footprint kernel that consumes it (round 6).
+// An f32 NHWC tensor costs its consumer a global load into registers, ~7 VALU per element for the bf16 hi / lo operand split and two
+// LDS stores per float4, once per (tile, 16-channel chunk) -- and a 16-channel chunk of an NHWC pixel is 64 bytes, half a cache
+// line, so every line is fetched by two chunk passes.  CHL keeps the SAME 4 bytes per element, already split, laid out the way
+// the consumer's LDS footprint wants them: per 16-channel chunk four PLANES
+//     plane 4 ch + 2 kh + part : [pixel][8 x bf16]  = channels 16 ch + 8 kh + {0..7} of every pixel; part 0 = hi, 1 = lo
+// of `npad` pixels x 16 bytes each.  64 consecutive pixels of a plane are 1 KB of contiguous memory = one LDS-DMA
+// wave-instruction (global_load_lds_dwordx4: lane i -> LDS base + 16 i), and they land as 64 consecutive 16-byte MFMA
+// A fragments: no register, no VALU, no ds_write, every tap an immediate offset ((ky W + kx) * 16) from one lane address.
+// x = hi + lo with hi = bf16_rne(x), lo = bf16_rne(x - hi): the split the consumers do themselves on an f32 input, so the
+// MFMA operands -- and therefore the results -- are bit-identical either way (ISS_DIAG_NO_HL keeps f32 between the layers).
+// npad = pixel count rounded up to 64 + one footprint (512): a footprint DMA that starts at any valid pixel stays inside its plane.
+inline unsigned chl_npad(long long npix) { return (unsigned)((npix + 63) / 64 * 64 + 512); }
+inline size_t chl_bytes(long long npix, int C) { return (size_t)chl_npad(npix) * 16u * 4u * (size_t)(C / 16); }
+constexpr size_t ISS_ACT_SLACK = 1u << 20;           // bytes every activation buffer has beyond bc * elems * 4 (the padding of a CHL tensor)
+inline bool chl_fits(long long npix, int C) { return C % 16 == 0 && chl_bytes(npix, C) <= (size_t)npix * C * 4 + ISS_ACT_SLACK && chl_bytes(npix, C) < 0xFFF00000ull; }
 
 // Host: magic constants of ConvArgs::dv_* for divisor d >= 1 (mul == 0 means d == 1).
 inline void set_fast_div(ConvArgs& a, int slot, int d) {

@@ -50,7 +50,9 @@ constexpr int wq_lds_bytes(int nt) { return nt * F2_BST + 2 * WQ_FB; }
 #define ISS_WQ_EXP 0
 #endif
 
-template <int KH, int KW>
+// OUT_HL (round 6): the pooled output is written in the CHL layout (conv_common.h) for a footprint kernel that reads it by LDS-DMA
+// (conv_wq3h.h): per pooled value the operand split (4 VALU) and two 2-byte stores instead of one 4-byte store.
+template <int KH, int KW, bool OUT_HL = false>
 __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
     constexpr bool X_NOPIPE = ISS_WQ_EXP & 1, X_NOBAR = ISS_WQ_EXP & 2, X_NOEPI = ISS_WQ_EXP & 4, X_NOREAD = ISS_WQ_EXP & 8;
     constexpr bool X_BCAST = ISS_WQ_EXP & 16, X_HALF = ISS_WQ_EXP & 32, X_NOCHUNKBAR = ISS_WQ_EXP & 64;
@@ -269,7 +271,9 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
     const bool ecol0 = n0 + li < ep.cout, ecol1 = n0 + 32 + li < ep.cout;
     // Stores go through a buffer descriptor over `out`: an offset beyond its size is dropped by the hardware, so rows beyond
     // the tile (tmr) or the launch (M) and columns >= Cout need a select on the offset, not a branch.
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(ep.out, 0, (int)((unsigned)(M >> 2) * (unsigned)ep.cout * 4u), 0x00020000);
+    const unsigned hl_np16 = OUT_HL ? p.out_np * 16u : 0u;      // bytes per CHL plane
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(ep.out, 0, OUT_HL ? (int)(p.out_np * (unsigned)ep.cout * 4u)
+                                                                                              : (int)((unsigned)(M >> 2) * (unsigned)ep.cout * 4u), 0x00020000);
     constexpr unsigned E_INVALID = 0xFFFF0000u;      // + the largest scalar offset below (< 16 KB) stays below 2^32: no wrap-around;
                                                      // the host keeps the output below 0xFFF00000 bytes
     const int wrow = wv * 128 + 4 * lh;              // first row of the wave's pool windows of register group 0 inside the tile
@@ -287,17 +291,53 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
     };
     // vb0 / vb1: byte offset of (the wave's first pooled row + lh, column n0 [+ 32] + li) of the tile, or E_INVALID for a
     // column >= Cout; tile_rows: rows of the tile that exist
+    // OUT_HL pieces.  hipcc's fmaxf canonicalises each accumulator register first (two extra v_max per window) and rebuilds the
+    // row bound per unit (two v_mov): with the window maximum as v_max3 + v_max, the bound as one per-block register and the
+    // split's conversions written out, a CHL unit costs 12 VALU + 2 stores where the f32 unit costs 10 + 1
+    unsigned e_h = 0, e_l = 0;                       // bf16 bits (low half) of the value's hi / lo parts
+    int e_lim = 0;                                   // rows of the tile that exist - the lane's first row: unit (rb, g) is stored iff rb * 32 + 8 g < e_lim
+    unsigned e_inv = E_INVALID;
+    auto epih_a = [&](const floatx16& acc, int g) {
+        asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(e_x) : "v"(acc[4 * g]), "v"(acc[4 * g + 1]), "v"(acc[4 * g + 2]));
+    };
+    auto epih_b = [&](const floatx16& acc, int cb, int g) {
+        asm volatile("v_max_f32 %0, %0, %1" : "+v"(e_x) : "v"(acc[4 * g + 3]));
+        e_x = fmaxf(e_x + (cb ? ebias1 : ebias0), 0.f);
+        asm volatile("" : "+v"(e_x));
+    };
+    auto epi_s = [&]() {                             // x = hi + lo, as the consumers split an f32 input (conv_common.h split4)
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(e_h) : "v"(e_x));
+        const float r = e_x - __uint_as_float(e_h << 16);
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(e_l) : "v"(r));
+    };
+    auto epih_c = [&](int rb, int cb, int g, unsigned vb) {
+        // (the unit's pixel offset rides in the instruction's immediate field, the plane in the scalar offset: E_INVALID + 480 is
+        // still beyond the tensor)
+        unsigned sel;                                // (rb * 32 + 8 g < e_lim) ? vb : E_INVALID in two instructions (a literal beside vcc would
+                                                     // be a second constant-bus operand: the invalid offset waits in a register, e_inv)
+        asm volatile("v_cmp_lt_i32 vcc, %2, %3\n\tv_cndmask_b32 %0, %4, %1, vcc" : "=v"(sel) : "v"(vb), "n"(rb * 32 + 8 * g), "v"(e_lim), "v"(e_inv) : "vcc");
+        const unsigned vo = sel + (unsigned)((rb * 8 + 2 * g) * 16);
+        if (X_NOEPI) return;
+        unsigned np16 = hl_np16;
+        asm volatile("" : "+s"(np16));
+        // channel n0 + 32 cb + li = chunk (n0 >> 4) + 2 cb + (li >> 4): planes 8 cb further on; lo part: the next plane
+        __builtin_amdgcn_raw_buffer_store_b16((short)e_h, orsrc, (int)vo, cb ? (int)(np16 << 3) : 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((short)e_l, orsrc, (int)vo, cb ? (int)((np16 << 3) + np16) : (int)np16, 0);
+    };
     auto epi_c = [&](int rb, int cb, int g, unsigned vb0, unsigned vb1, int tile_rows) {
         int wr = wrow;
         asm volatile("" : "+v"(wr), "+s"(rowb));     // (keeps hipcc from hoisting 32 row indices / 32 scalar offsets out of the loop)
         const bool ok = wr < tile_rows - (rb * 32 + 8 * g);
         e_off = ok ? (cb ? vb1 : vb0) : E_INVALID;
-        if (!X_NOEPI)
+        if (X_NOEPI) return;
+        if (!OUT_HL)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e_x), orsrc, (int)e_off, (rb * 8 + 2 * g) * rowb, 0);
     };
     // byte offset in `out` of (pooled row (tile * tmr + wave's first row) / 4 + lh, column n0 + li); < 2^32 (host-checked)
     auto epi_base = [&](int tile, int cb) {
         const bool col = cb ? ecol1 : ecol0;
+        if (OUT_HL)      // CHL byte offset of (pooled pixel tile * tmr / 4 + wv * 32 + lh, channel n0 + li) -- hi part; the host guarantees Cout % 64 == 0
+            return (unsigned)(((unsigned)(((n0 >> 4) + (li >> 4)) * 4 + ((li >> 3) & 1) * 2) * p.out_np + (unsigned)(tile * (TMR >> 2) + wv * 32 + lh)) * 16u + (unsigned)((li & 7) * 2));
         return col ? (unsigned)(((tile * (TMR >> 2) + wv * 32 + lh) * ep.cout + n0 + cb * 32 + li) * 4) : E_INVALID;
     };
     auto tile_rows_of = [&](int tile) { const int r = M - tile * TMR; return tile < ntiles ? (r < TMR ? r : TMR) : 0; };
@@ -377,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
             const unsigned wbase = sF0 + (unsigned)((1 - t) * WQ_FB) + wofs;      // the OTHER footprint
             unsigned vb0 = E_INVALID, vb1 = E_INVALID;
             int erows = 0;
-            if (EP) { vb0 = epi_base(etile, 0); vb1 = epi_base(etile, 1); erows = tile_rows_of(etile); }
+            if (EP) { vb0 = epi_base(etile, 0); vb1 = epi_base(etile, 1); erows = tile_rows_of(etile); if (OUT_HL) { e_lim = erows - wrow; e_inv = E_INVALID; asm volatile("" : "+v"(e_inv)); } }
 #pragma unroll
             for (int v = 0; v < NT; ++v) {
                 const int cs = (v + t) & 1, ns = cs ^ 1;
@@ -493,7 +533,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
                     }
                     // ---- epilogue of the other accumulator set: 32 (accumulator, window) units of three pieces; slots 0..8 of the
                     // steps 1..11 carry one piece each beside their fragment read (three units per step)
-                    if (EP && v >= 1 && v <= 11 && s < 9) {
+                    if (!OUT_HL && EP && v >= 1 && v <= 11 && s < 9) {
                         const int unit = (v - 1) * 3 + s / 3;                  // 0..32
                         if (unit < 32) {
                             const int erb = unit >> 3, ecb = (unit >> 2) & 1, eg = unit & 3;
@@ -501,6 +541,18 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
                             if (s % 3 == 0) epi_a(oa, eg);
                             else if (s % 3 == 1) epi_b(oa, ecb, eg);
                             else epi_c(erb, ecb, eg, vb0, vb1, erows);
+                        }
+                    }
+                    // OUT_HL: four pieces per unit (+ the operand split), slots 0..11
+                    if (OUT_HL && EP && v >= 1 && v <= 11 && s < 12) {
+                        const int unit = (v - 1) * 3 + s / 4;
+                        if (unit < 32) {
+                            const int erb = unit >> 3, ecb = (unit >> 2) & 1, eg = unit & 3;
+                            const floatx16& oa = erb == 0 ? (ecb ? o01 : o00) : erb == 1 ? (ecb ? o11 : o10) : erb == 2 ? (ecb ? o21 : o20) : (ecb ? o31 : o30);
+                            if (s % 4 == 0) epih_a(oa, eg);
+                            else if (s % 4 == 1) epih_b(oa, ecb, eg);
+                            else if (s % 4 == 2) epi_s();
+                            else epih_c(erb, ecb, eg, vb0);
                         }
                     }
                 }
@@ -558,7 +610,8 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
         for (int unit = 0; unit < 32; ++unit) {
             const int erb = unit >> 3, ecb = (unit >> 2) & 1, eg = unit & 3;
             const floatx16& oa = erb == 0 ? (ecb ? c101 : c100) : erb == 1 ? (ecb ? c111 : c110) : erb == 2 ? (ecb ? c121 : c120) : (ecb ? c131 : c130);
-            epi_a(oa, eg); epi_b(oa, ecb, eg); epi_c(erb, ecb, eg, vb0, vb1, erows);
+            if (OUT_HL) { e_lim = erows - wrow; e_inv = E_INVALID; asm volatile("" : "+v"(e_inv)); epih_a(oa, eg); epih_b(oa, ecb, eg); epi_s(); epih_c(erb, ecb, eg, vb0); }
+            else { epi_a(oa, eg); epi_b(oa, ecb, eg); epi_c(erb, ecb, eg, vb0, vb1, erows); }
         }
     }
 #undef ISS_WQ_SET0
@@ -568,6 +621,6 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
 // host: does the weight-stationary quad kernel take this launch?  (fused first layer, unpadded, relu + 2 x 2 max-pool, 64 output
 // channels per workgroup, 5x3; tiles of ConvArgs::tmr rows within 800 pixels)
 inline bool iss_wq_compiled(int kh, int kw) { return kh == 5 && kw == 3; }
-void iss_wq_launch_5x3(const ConvArgs& a, dim3 grid, hipStream_t st);
+void iss_wq_launch_5x3(const ConvArgs& a, dim3 grid, hipStream_t st);       // a.out_hl: the CHL-output instantiation
 
 }  // namespace issk

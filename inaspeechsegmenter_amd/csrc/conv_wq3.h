@@ -34,6 +34,7 @@ constexpr int wq3_lds_bytes() { return WQ3_NV * F2_BST + 2 * WQ3_FB + 512; }    
 template <int KIND>
 __global__ __launch_bounds__(256, 1) void conv_x3_wq3_kernel(const ConvArgs p) {
     constexpr bool X_NOEPI = ISS_WQ3_EXP & 4, X_NOCHUNKBAR = ISS_WQ3_EXP & 64, X_NODMA = ISS_WQ3_EXP & 128, X_NOBAR = ISS_WQ3_EXP & 2;
+    constexpr bool X_NOFETCH = ISS_WQ3_EXP & 1, X_NOCONV = ISS_WQ3_EXP & 8;      // bit 0: no footprint loads, bit 3: no conversion / LDS stores
     constexpr int KH = 3, KW = 3, NT = 9, G = 2;
     constexpr bool TR = KIND == 0;
     static_assert(wq3_lds_bytes() <= 160 * 1024 && (WQ3_NV * F2_BST) % 4096 == 0 && WQ3_FB % 2048 == 0, "");
@@ -360,11 +361,15 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3_kernel(const ConvArgs p) {
                     if (last && t == 1 && s < WQ3_NV && !X_NODMA) load_weight_tile(nc0, s);
                     // ---- footprint pipeline: slices 2 k, 2 k + 1 are fetched in step k (two pieces each, slots 20..23) and converted
                     // in step k + 3 (four pieces each, slots 12..15 and 16..19), k = 0..3
-                    if (v <= 3 && s >= 20) {
+                    if (v <= 3 && s >= 20 && !X_NOFETCH) {
                         const int q = 2 * v + ((s - 20) >> 1);
                         if (((s - 20) & 1) == 0) fetch_1(un, q); else fetch_2(un, nc0, q);
                     }
-                    if (v >= 3 && v <= 6 && s >= 12 && s < 20) {
+                    if (X_NOCONV && !X_NOFETCH && v == 6 && s == 12) {
+#pragma unroll
+                        for (int q = 0; q < WQ3_NFV; ++q) asm volatile("" :: "v"(fv[q].x), "v"(fv[q].y), "v"(fv[q].z), "v"(fv[q].w));
+                    }
+                    if (v >= 3 && v <= 6 && s >= 12 && s < 20 && !X_NOCONV) {
                         const int q = 2 * (v - 3) + ((s - 12) >> 2);
                         Cv& c = s < 16 ? cva : cvb;
                         const int piece = (s - 12) & 3;

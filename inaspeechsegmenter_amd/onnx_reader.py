@@ -179,6 +179,9 @@ def resnet101_conv_names(m_channels=32, num_blocks=(3, 4, 23, 3)):
 
 
 _PASS_THROUGH = ('BatchNormalization', 'Relu', 'Identity', 'Cast')
+# shape-only ops an exporter puts between the graph input and the stem convolution: resnet.py:116 does `x.unsqueeze_(1)` on the
+# (1, feat, T) tensor the reference feeds (vbx_segmenter.py:265), so a torch export of `final.onnx` has an Unsqueeze there
+_SHAPE_ONLY = ('Unsqueeze', 'Squeeze', 'Reshape', 'Transpose', 'Flatten')
 
 
 def _order_convs_by_connectivity(path, nodes, convs, produced, consumers):
@@ -192,8 +195,17 @@ def _order_convs_by_connectivity(path, nodes, convs, produced, consumers):
         seen = 0
         while True:
             n = produced.get(t)
-            if n is None or n['op_type'] not in _PASS_THROUGH or not n['input']:
-                return id(n) if n is not None else None
+            if n is None:
+                return None
+            if n['op_type'] in _SHAPE_ONLY and n['input']:
+                # a shape-only op counts as transparent only on the way back to a GRAPH INPUT (the stem); anywhere else it would
+                # be a topology this reader does not know
+                u, hops = n['input'][0], 0
+                while u in produced and produced[u]['op_type'] in _SHAPE_ONLY + ('Identity', 'Cast') and produced[u]['input'] and hops < 16:
+                    u, hops = produced[u]['input'][0], hops + 1
+                return None if u not in produced else id(n)
+            if n['op_type'] not in _PASS_THROUGH or not n['input']:
+                return id(n)
             t = n['input'][0]
             seen += 1
             if seen > 64:
@@ -261,9 +273,11 @@ def _check_conv_geometry(path, convs, want):
         pd = a.get('pads') or [0, 0, 0, 0]
         st = [st] * 2 if isinstance(st, int) else list(st)
         pd = [pd] * 4 if isinstance(pd, int) else list(pd)
-        if st != [stride, stride] or pd != [k // 2] * 4 or (a.get('group') or 1) != 1 or (a.get('dilations') or [1, 1]) in ([2, 2],):
-            raise ValueError(f'{path}: {cname}: strides {st} pads {pd} group {a.get("group")}, resnet.py has strides '
-                             f'{[stride, stride]} pads {[k // 2] * 4} group 1')
+        dl = a.get('dilations') or [1, 1]
+        dl = [dl] * 2 if isinstance(dl, int) else list(dl)
+        if st != [stride, stride] or pd != [k // 2] * 4 or (a.get('group') or 1) != 1 or dl != [1, 1]:
+            raise ValueError(f'{path}: {cname}: strides {st} pads {pd} group {a.get("group")} dilations {dl}, resnet.py has strides '
+                             f'{[stride, stride]} pads {[k // 2] * 4} group 1 dilations [1, 1]')
 
 
 def load_resnet101_params(path):

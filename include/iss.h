@@ -200,7 +200,8 @@ int iss_set_precision(iss_ctx* ctx, int mode);
 #define ISS_DIAG_NO_NCB1         0x10000u /* layers with <= 32 output channels on the 64-column forms (no NCB = 1 form)                 */
 #define ISS_DIAG_NO_WSU3         0x20000u /* unpadded 3x3 layers with 64 / 96 output channels on conv_x3_fp_kernel                      */
 #define ISS_DIAG_NO_GFUSED       0x40000u /* the generic gather kernel never reads the shared first-layer rows (per-window first layer)  */
-#define ISS_DIAG_ALL             0x7ffffu
+#define ISS_DIAG_NO_HL           0x80000u /* f32 NHWC activations between the footprint kernels (no CHL layout: conv_x3_wq3_kernel instead of conv_x3_wq3h_kernel) */
+#define ISS_DIAG_ALL             0xfffffu
 int iss_set_diag(iss_ctx* ctx, uint32_t flags);
 
 /* FLOPs (2*MAC of the conv/dense outputs actually computed) per sample of a loaded network. */

@@ -357,15 +357,26 @@ def test_one_wave_per_simd_kernels_edge_sizes(ctx, nmel, nout):
         ctx.set_diag('no_wq')
         try:
             p_old, f_old = ctx.cnn_probs(3, rows)
+            # round 6: the 3x3 layers read the CHL layout their producers write (conv_x3_wq3h_kernel); 'no_hl' keeps f32 NHWC
+            # between the layers (conv_x3_wq3_kernel) -- the same operand split, the same MFMA order: bit-identical too
+            ctx.set_diag('no_hl')
+            ctx.prof_enable(True)
+            ctx.prof_reset()
+            p_f32, f_f32 = ctx.cnn_probs(3, rows)
+            used_f32 = {e['kernel'] for e in ctx.prof_instances()}
+            ctx.prof_enable(False)
         finally:
             ctx.set_diag(0)
-        assert np.array_equal(f_new, f_old)
+        assert np.array_equal(f_new, f_old) and np.array_equal(f_new, f_f32)
         ref, rfin = _oracle_probs(layers, mspec, nmel, rows)
         assert np.array_equal(f_new, rfin)
         assert np.abs(p_new - ref).max() < 1e-4, (T, np.abs(p_new - ref).max())
         assert np.array_equal(p_new, p_old), (T, sorted(used), np.abs(p_new - p_old).max())
+        assert np.array_equal(p_new, p_f32), (T, sorted(used), sorted(used_f32), np.abs(p_new - p_f32).max())
         if T >= 141:
-            assert any(k.startswith('conv_x3_wq_kernel') for k in used) and any(k.startswith('conv_x3_wq3_kernel') for k in used), (T, used)
+            assert any(k.startswith('conv_x3_wq_kernel') and 'hl' in k for k in used), (T, used)
+            assert sum(k.startswith('conv_x3_wq3h_kernel') for k in used) == 2, (T, used)          # conv3 (CHL out) and conv4
+            assert sum(k.startswith('conv_x3_wq3_kernel') for k in used_f32) == 2 and not any('hl' in k or 'wq3h' in k for k in used_f32), (T, used_f32)
     # irregular window lists (what the VAD-gated gender pass hands over): gaps, runs, repeats -- a footprint then spans two
     # windows whose first rows are unrelated
     mspec = _mspec(rng, 6000)
@@ -381,12 +392,15 @@ def test_one_wave_per_simd_kernels_edge_sizes(ctx, nmel, nout):
         ctx.set_diag('no_wq')
         try:
             p_old, f_old = ctx.cnn_probs(3, rows)
+            ctx.set_diag('no_hl')
+            p_f32, f_f32 = ctx.cnn_probs(3, rows)
         finally:
             ctx.set_diag(0)
         ref, rfin = _oracle_probs(layers, mspec, nmel, rows)
         assert np.array_equal(f_new, rfin) and np.array_equal(f_new, f_old)
         assert np.abs(p_new - ref).max() < 1e-4, (n, np.abs(p_new - ref).max())
         assert np.array_equal(p_new, p_old), (n, np.abs(p_new - p_old).max())
+        assert np.array_equal(p_new, p_f32), (n, np.abs(p_new - p_f32).max())
 
 
 @pytest.mark.parametrize('net,nmel,ncls', [('smn', 21, 3), ('gender', 24, 2)])

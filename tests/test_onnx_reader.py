@@ -63,7 +63,7 @@ def node(op, inputs, outputs, attrs=()):
     return b''.join(_str(1, i) for i in inputs) + b''.join(_str(2, o) for o in outputs) + _str(4, op) + b''.join(_ld(5, a) for a in attrs)
 
 
-def write_resnet_onnx(path, params, folded, tensor_style='raw', embed='gemm'):
+def write_resnet_onnx(path, params, folded, tensor_style='raw', embed='gemm', stem='direct'):
     """Serialise the ResNet-101 of resnet.py as an ONNX ModelProto: node order = torch's trace order."""
     nodes, inits = [], []
     counter = [0]
@@ -100,7 +100,15 @@ def write_resnet_onnx(path, params, folded, tensor_style='raw', embed='gemm'):
         nodes.append(node('Relu', [x], [y]))
         return y
 
-    x = relu(conv('input', 'conv1', 'bn1', 1, 1, 3))
+    x0 = 'input'
+    if stem == 'unsqueeze':
+        # what torch.onnx.export writes for resnet.py:116 (`x.unsqueeze_(1)` on the 3-D (1, feat, T) input of vbx_segmenter.py:265):
+        # an Unsqueeze (axes as a second input, opset >= 13) -- here behind a Cast, as some exporters add one
+        inits.append(tensor('onnx::Unsqueeze_axes', np.array([1], np.int64).astype(np.float32), tensor_style))
+        nodes.append(node('Cast', ['input'], ['input_f32']))
+        nodes.append(node('Unsqueeze', ['input_f32', 'onnx::Unsqueeze_axes'], ['input_4d']))
+        x0 = 'input_4d'
+    x = relu(conv(x0, 'conv1', 'bn1', 1, 1, 3))
     for li, (planes, nb, stride) in enumerate(zip((32, 64, 128, 256), (3, 4, 23, 3), (1, 2, 2, 2)), 1):
         for bi in range(nb):
             p = f'layer{li}.{bi}'
@@ -127,11 +135,13 @@ def write_resnet_onnx(path, params, folded, tensor_style='raw', embed='gemm'):
     open(path, 'wb').write(model)
 
 
-@pytest.mark.parametrize('folded,style,embed', [(False, 'raw', 'gemm'), (True, 'float_data', 'matmul'), (True, 'packed_dims', 'gemm')])
-def test_reader_reproduces_the_network(tmp_path, folded, style, embed):
+@pytest.mark.parametrize('folded,style,embed,stem', [(False, 'raw', 'gemm', 'direct'), (True, 'float_data', 'matmul', 'direct'),
+                                                     (True, 'packed_dims', 'gemm', 'direct'), (True, 'raw', 'gemm', 'unsqueeze'),
+                                                     (False, 'raw', 'matmul', 'unsqueeze')])
+def test_reader_reproduces_the_network(tmp_path, folded, style, embed, stem):
     params = KM.synthetic_resnet101(3)
     path = str(tmp_path / 'final.onnx')
-    write_resnet_onnx(path, params, folded, style, embed)
+    write_resnet_onnx(path, params, folded, style, embed, stem)
     got = OR.load_resnet101_params(path)
     if not folded:                                   # kept BatchNormalization: the original tensors, bit for bit
         assert set(got) == set(params)
