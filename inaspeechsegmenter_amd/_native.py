@@ -80,6 +80,9 @@ def lib():
         'iss_cnn_forward': (C.c_int, [vp, C.c_int, pf, i32, pf]),
         'iss_cnn_flops': (C.c_int, [vp, C.c_int, pd]),
         'iss_set_precision': (C.c_int, [vp, C.c_int]),
+        'iss_set_precision_guard': (C.c_int, [vp, C.c_float]),
+        'iss_cnn_precision_info': (C.c_int, [vp, C.c_int, pi32, pf, pi32, pi32]),
+        'iss_cnn_set_net_precision': (C.c_int, [vp, C.c_int, C.c_int]),
         'iss_vbx_tables': (C.c_int, [vp, pd, pd]),
         'iss_vbx_features': (C.c_int, [vp, pi32, pd, i64, pf, pi32]),
         'iss_vbx_set_dither': (C.c_int, [vp, pd, i64]),
@@ -380,6 +383,25 @@ class Context:
         self._ck(self._L.iss_set_precision(self._h, int(mode)), 'iss_set_precision')
         self.precision = int(mode)
 
+    def set_precision_guard(self, threshold):
+        """Precision guard (include/iss.h): max |d log p| between the split-bf16 and the exact-f32 arithmetic above which a
+        patch network's first call switches it to exact f32; <= 0 turns the probe off.  Default 5e-4."""
+        self._ck(self._L.iss_set_precision_guard(self._h, float(threshold)), 'iss_set_precision_guard')
+        self.guard_threshold = float(threshold)
+
+    def cnn_precision_info(self, net_id):
+        """{'mode': PREC_*, 'max_dlogp': probe figure or None, 'slots': windows compared, 'state': 'pending' | 'passed' |
+        'escalated' | 'fixed'} of one loaded network."""
+        mode, slots, state, d = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_float(0)
+        self._ck(self._L.iss_cnn_precision_info(self._h, int(net_id), C.byref(mode), C.byref(d), C.byref(slots), C.byref(state)),
+                 'iss_cnn_precision_info')
+        return {'mode': 'f32' if mode.value == PREC_F32 else 'bf16x3', 'max_dlogp': None if d.value < 0 else float(d.value),
+                'slots': slots.value, 'state': ('pending', 'passed', 'escalated', 'fixed')[state.value]}
+
+    def cnn_set_net_precision(self, net_id, mode):
+        """Arithmetic of ONE network: PREC_BF16X3 / PREC_F32, or -1 to follow the context again (and be probed again)."""
+        self._ck(self._L.iss_cnn_set_net_precision(self._h, int(net_id), int(mode)), 'iss_cnn_set_net_precision')
+
     def set_workspace_limit(self, nbytes):
         self._ck(self._L.iss_set_workspace_limit(self._h, int(nbytes)), 'iss_set_workspace_limit')
         self.workspace_limit = int(nbytes)
@@ -393,6 +415,8 @@ class Context:
             self.set_workspace_limit(other.workspace_limit)
         if getattr(other, 'diag', 0) != getattr(self, 'diag', 0):
             self.set_diag(other.diag)
+        if getattr(other, 'guard_threshold', None) is not None and other.guard_threshold != getattr(self, 'guard_threshold', None):
+            self.set_precision_guard(other.guard_threshold)
 
     def set_diag(self, flags):
         """Kernel-selection switches (include/iss.h ISS_DIAG_*): an int, or names like 'no_shared_first,no_pws2'."""

@@ -1137,6 +1137,33 @@ extern "C" int iss_set_precision(iss_ctx* c, int mode) {
     return ISS_OK;
 }
 
+extern "C" int iss_set_precision_guard(iss_ctx* c, float threshold) {
+    if (!c) return ISS_EINVAL;
+    if (!(threshold == threshold)) return iss_fail(c, ISS_EINVAL, "iss_set_precision_guard: threshold is NaN");
+    c->guard_threshold = threshold;
+    return ISS_OK;
+}
+
+extern "C" int iss_cnn_set_net_precision(iss_ctx* c, int id, int mode) {
+    if (!c || id < 0 || id >= ISS_MAX_NETS) return ISS_EINVAL;
+    if (mode != -1 && mode != ISS_PREC_BF16X3 && mode != ISS_PREC_F32) return iss_fail(c, ISS_EINVAL, "iss_cnn_set_net_precision: unknown mode %d", mode);
+    if (!c->nets[id].loaded) return iss_fail(c, ISS_ESTATE, "net %d not loaded", id);
+    c->nets[id].prec_override = mode;
+    c->nets[id].guard_state = mode == -1 ? ISS_GUARD_PENDING : ISS_GUARD_FIXED;
+    return ISS_OK;
+}
+
+extern "C" int iss_cnn_precision_info(iss_ctx* c, int id, int32_t* mode, float* max_dlogp, int32_t* slots, int32_t* state) {
+    if (!c || id < 0 || id >= ISS_MAX_NETS) return ISS_EINVAL;
+    const IssNet& n = c->nets[id];
+    if (!n.loaded) return iss_fail(c, ISS_ESTATE, "net %d not loaded", id);
+    if (mode) *mode = n.prec_override >= 0 ? n.prec_override : c->precision;
+    if (max_dlogp) *max_dlogp = n.guard_dlogp;
+    if (slots) *slots = n.guard_slots;
+    if (state) *state = n.guard_state;
+    return ISS_OK;
+}
+
 extern "C" int iss_set_diag(iss_ctx* c, uint32_t flags) {
     if (!c) return ISS_EINVAL;
     if (flags & ~(uint32_t)ISS_DIAG_ALL) return iss_fail(c, ISS_EINVAL, "iss_set_diag: unknown bits 0x%x", flags & ~(uint32_t)ISS_DIAG_ALL);
@@ -1210,7 +1237,8 @@ int footprint_pixels(const ConvArgs& a, int TM = BM) {      // largest pixel spa
 int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const float* d_stats,
                 const uint8_t* d_fin, const float* d_input, float** result, int rmin = 0, int rmax = -1,
                 bool share_first = false) {
-    const bool x3mode = c->precision == ISS_PREC_BF16X3;
+    const int prec = n.prec_override >= 0 ? n.prec_override : c->precision;          // (precision guard: one network may run exact f32)
+    const bool x3mode = prec == ISS_PREC_BF16X3;
     // A PATCH first layer directly in front of a footprint-kernel conv is not launched per window: it is computed once
     // per log-mel row and the second conv normalises it per window while staging its LDS footprint (ConvArgs::f_*,
     // conv_fp.h FUSED).  Static part of the test; the footprint-capacity part is decided when the second row is reached
@@ -1380,7 +1408,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         a.act = R[ISS_C_ACT]; a.Kpad = n.kpad[r];
         a.M = (long long)bc * a.Hq * a.Wq * a.pp;
         const bool patch = R[ISS_C_INMODE] == 1;
-        const bool x3 = c->precision == ISS_PREC_BF16X3;
+        const bool x3 = x3mode;
         const bool in_is_hl = R[ISS_C_IN] != ISS_BUF_INPUT && hl_np.count(R[ISS_C_IN]) != 0;     // (only conv_x3_wq3h_kernel reads that layout)
         bool in_hl_taken = false;
         a.mode = patch ? 2 : ((a.Cin % (x3 ? XBK : 4) == 0) ? 0 : 1);
@@ -1983,6 +2011,48 @@ int plan_chunk(iss_ctx* c, IssNet& n, int total, int* bc_out) {
 }  // namespace
 
 static int cnn_probs_impl(iss_ctx* c, int id, const int32_t* win_row, int32_t nslots, float* probs_out,
+                          uint8_t* finite_out, bool async, int64_t* ticket_out);
+
+// Precision guard (include/iss.h): the network's first call in split-bf16 mode.  Up to 256 of the call's windows -- four runs of
+// consecutive slots at the quarters of the list, so that each run takes the kernels the call itself will take (the shared first
+// layer needs overlapping windows) -- are evaluated in both arithmetic modes; max |d log p| decides.
+static int precision_guard(iss_ctx* c, int id, const int32_t* win_row, int32_t nslots) {
+    IssNet& n = c->nets[id];
+    const int eff = n.prec_override >= 0 ? n.prec_override : c->precision;
+    if (eff != ISS_PREC_BF16X3) { n.guard_state = ISS_GUARD_FIXED; return ISS_OK; }
+    if (!(c->guard_threshold > 0.f)) return ISS_OK;               // guard off: stays pending
+    const int runs = nslots >= 256 ? 4 : 1, per = nslots >= 256 ? 64 : nslots;
+    std::vector<float> px((size_t)per * n.out_dim), pf((size_t)per * n.out_dim);
+    std::vector<uint8_t> fx(per), ff(per);
+    double worst = 0.0;
+    int compared = 0, rc = ISS_OK;
+    c->in_guard = true;
+    for (int r = 0; r < runs && rc == ISS_OK; ++r) {
+        const int32_t* w = win_row + (runs == 1 ? 0 : (size_t)r * (nslots - per) / (runs - 1));
+        n.prec_override = ISS_PREC_BF16X3;
+        rc = cnn_probs_impl(c, id, w, per, px.data(), fx.data(), false, nullptr);
+        if (rc == ISS_OK) { n.prec_override = ISS_PREC_F32; rc = cnn_probs_impl(c, id, w, per, pf.data(), ff.data(), false, nullptr); }
+        if (rc != ISS_OK) break;
+        for (int i = 0; i < per; ++i) {
+            if (!fx[i] || !ff[i]) continue;                       // non-finite windows carry the constant 0.5 (segmenter.py:175)
+            ++compared;
+            for (int k = 0; k < n.out_dim; ++k) {
+                const float a = px[(size_t)i * n.out_dim + k], b = pf[(size_t)i * n.out_dim + k];
+                if (!(a > 1e-30f) || !(b > 1e-30f)) { if ((a > 1e-30f) != (b > 1e-30f)) worst = std::max(worst, 1.0); continue; }
+                worst = std::max(worst, std::fabs(std::log((double)a) - std::log((double)b)));
+            }
+        }
+    }
+    c->in_guard = false;
+    n.prec_override = -1;
+    if (rc != ISS_OK) return rc;
+    n.guard_dlogp = (float)worst; n.guard_slots = compared;
+    if (worst > (double)c->guard_threshold) { n.prec_override = ISS_PREC_F32; n.guard_state = ISS_GUARD_ESCALATED; }
+    else n.guard_state = ISS_GUARD_PASSED;
+    return ISS_OK;
+}
+
+static int cnn_probs_impl(iss_ctx* c, int id, const int32_t* win_row, int32_t nslots, float* probs_out,
                           uint8_t* finite_out, bool async, int64_t* ticket_out) {
     if (!c) return ISS_EINVAL;
     if (ticket_out) *ticket_out = -1;
@@ -1998,6 +2068,7 @@ static int cnn_probs_impl(iss_ctx* c, int id, const int32_t* win_row, int32_t ns
             return iss_fail(c, ISS_EINVAL, "iss_cnn_probs: window %d (row %d) outside the %d resident frames", i, win_row[i], c->T);
     ISS_HIP(c, hipSetDevice(c->device));
     int rc;
+    if (!c->in_guard && n.guard_state == ISS_GUARD_PENDING && (rc = precision_guard(c, id, win_row, nslots))) return rc;
     if ((rc = iss_reserve(c, c->d_winrow, (size_t)nslots * 4))) return rc;
     if ((rc = iss_reserve(c, c->d_stats, (size_t)nslots * 8))) return rc;
     if ((rc = iss_reserve(c, c->d_finite, (size_t)nslots))) return rc;

@@ -40,6 +40,11 @@ __device__ __forceinline__ void glds16(const void* gbase, unsigned byte_off, uns
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(byte_off), "s"(gbase), "s"(lds_dst) : "memory");
 }
+// The same without saving M0 (two scalar instructions fewer per piece): for kernels in which nothing but these statements uses M0
+// (gfx9 DS instructions do not read it; hipcc treats M0 as reserved and re-writes it before any use of its own).
+__device__ __forceinline__ void glds16_m0(const void* gbase, unsigned byte_off, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(byte_off), "s"(gbase), "s"(lds_dst) : "memory");
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");

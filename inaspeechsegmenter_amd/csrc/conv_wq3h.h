@@ -32,7 +32,7 @@ constexpr int wqh_lds_bytes() { return WQH_NSLOT * WQH_SLOT + 2 * WQH_FB + 512 +
 
 template <int KIND, bool OUT_HL>
 __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) {
-    constexpr bool X_NOEPI = ISS_WQH_EXP & 4, X_NODMA = ISS_WQH_EXP & 128, X_NOADMA = ISS_WQH_EXP & 1;
+    constexpr bool X_NOEPI = ISS_WQH_EXP & 4, X_NODMA = ISS_WQH_EXP & 128, X_NOADMA = ISS_WQH_EXP & 1, X_NOBAR = ISS_WQH_EXP & 2, X_NOFLAG = ISS_WQH_EXP & 16;      // timing-only experiment builds
     constexpr int KH = 3, KW = 3, NT = 9, G = 2;
     constexpr bool TR = KIND == 0;
     static_assert(!OUT_HL || TR, "the CHL epilogue is written for the transposed (kind 0) accumulators");
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
     auto load_weight_piece = [&](int c0, int v, int half, unsigned sw78) {     // v, half: compile-time; sw78: 0 or 2 * WQH_SLOT (uniform)
         const uint16_t* src = (w_plane ? p.wl : p.wh) + (v * p.Cin + c0);
         asm volatile("" : "+s"(wdst0));
-        if (!X_NODMA) glds16(src, boff_w[half], wdst0 + (unsigned)(v * WQH_SLOT + half * F2_BST) + (v >= 7 ? sw78 : 0u));
+        if (!X_NODMA) glds16_m0(src, boff_w[half], wdst0 + (unsigned)(v * WQH_SLOT + half * F2_BST) + (v >= 7 ? sw78 : 0u));
     };
     unsigned bread = sB_base + (unsigned)((2 * li + (lh ^ ((li >> 3) & 1))) * 16);
     unsigned bread78 = bread;                        // the same for taps 7, 8 of the current pass
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
         const unsigned char* src = reinterpret_cast<const unsigned char*>(in_hl) + (size_t)((unsigned)(c0 >> 4) * 4u + (unsigned)wv) * np16;
         const unsigned off = (unsigned)(p_lo + 64 * q + lane) * 16u;
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sF0 + (unsigned)(fb * WQH_FB) + (unsigned)(wv * WQH_PL + q * 1024)));
-        if (!X_NOADMA) glds16(src, off, dst);
+        if (!X_NOADMA) glds16_m0(src, off, dst);
     };
 
     struct AFr { bf16x8 h, l; };
@@ -158,9 +158,6 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
     float4 e_bb[2], e_v = make_float4(0.f, 0.f, 0.f, 0.f);
     e_bb[0] = e_v; e_bb[1] = e_v;
     float e_p0 = 0.f, e_p1 = 0.f;
-    bf16x4 e_hh, e_ll;                               // OUT_HL: the unit's four values, split
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { e_hh[i] = (__bf16)0.f; e_ll[i] = (__bf16)0.f; }
     typedef const f32x4 __attribute__((address_space(3)))* LdsRF4;
     const unsigned bias_rd = sBias + (unsigned)(lh * 16);
     auto epi0_a = [&](int unit) {                    // the bias of unit `unit` (channels 32 cb + 8 g + 4 lh + {0..3}) into set unit & 1
@@ -175,34 +172,50 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
                           fmaxf(acc[4 * g + 2] + e_b.z, 0.f), fmaxf(acc[4 * g + 3] + e_b.w, 0.f));
         asm volatile("" : "+v"(e_v.x), "+v"(e_v.y), "+v"(e_v.z), "+v"(e_v.w));
     };
-    auto epi0_h = [&]() {                            // OUT_HL: hi parts, residuals
-        e_hh[0] = (__bf16)e_v.x; e_hh[1] = (__bf16)e_v.y; e_hh[2] = (__bf16)e_v.z; e_hh[3] = (__bf16)e_v.w;
-        e_v.x = e_v.x - (float)e_hh[0]; e_v.y = e_v.y - (float)e_hh[1];
-        asm volatile("" : "+v"(e_v.x), "+v"(e_v.y));
+    // OUT_HL: x = hi + lo per value, as the consumers split an f32 input (conv_common.h split4).  Written out: hipcc converts the
+    // hi parts twice and SLP-packs the residuals into v_pk_add_f32 (an anti-lever beside MFMAs, MI355X_MICROARCH.md): 12 VALU per unit
+    unsigned e_h01 = 0, e_h23 = 0, e_l01 = 0, e_l23 = 0;
+    auto cvt_pk = [&](float a, float b) { unsigned r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto epi0_h = [&]() {                            // hi parts; residuals of the first pair
+        e_h01 = cvt_pk(e_v.x, e_v.y); e_h23 = cvt_pk(e_v.z, e_v.w);
+        e_v.x = e_v.x - __uint_as_float(e_h01 << 16);
+        asm volatile("" : "+v"(e_v.x));
+        e_v.y = e_v.y - __uint_as_float(e_h01 & 0xffff0000u);
+        asm volatile("" : "+v"(e_v.y));
     };
-    auto epi0_l = [&]() {                            // OUT_HL: lo parts
-        e_v.z = e_v.z - (float)e_hh[2]; e_v.w = e_v.w - (float)e_hh[3];
-        e_ll[0] = (__bf16)e_v.x; e_ll[1] = (__bf16)e_v.y; e_ll[2] = (__bf16)e_v.z; e_ll[3] = (__bf16)e_v.w;
+    auto epi0_l = [&]() {                            // residuals of the second pair; lo parts
+        e_v.z = e_v.z - __uint_as_float(e_h23 << 16);
+        asm volatile("" : "+v"(e_v.z));
+        e_v.w = e_v.w - __uint_as_float(e_h23 & 0xffff0000u);
+        asm volatile("" : "+v"(e_v.w));
+        e_l01 = cvt_pk(e_v.x, e_v.y); e_l23 = cvt_pk(e_v.z, e_v.w);
     };
+    int e_lim = 0;                                   // rows of the tile that exist - the lane's first row: row block rb is stored iff rb * 32 < e_lim
+    unsigned e_inv = E_INVALID;
     // kind 0, f32 output.  vb: byte offset of (row tile * tmr + wv * 64 + li, channel n0 + 4 lh) in `out`
     // OUT_HL: vb = CHL byte offset of (pixel tile * tmr + wv * 64 + li, chunk n0 / 16, k-half 0, hi) + 8 lh
     auto epi0_c = [&](int rb, int cb, int g, unsigned vb, int tile_rows) {
-        int wr = wrow;
-        asm volatile("" : "+v"(wr), "+s"(rowb));
-        const bool ok = wr < tile_rows - rb * 32;
-        const unsigned off = ok ? vb : E_INVALID;
-        if (X_NOEPI) return;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         if (OUT_HL) {
+            unsigned sel;                            // (rb * 32 < e_lim) ? vb : E_INVALID (the invalid offset waits in a register: a literal beside vcc would be a
+            asm volatile("v_cmp_lt_i32 vcc, %2, %3\n\tv_cndmask_b32 %0, %4, %1, vcc" : "=v"(sel) : "v"(vb), "n"(rb * 32), "v"(e_lim), "v"(e_inv) : "vcc");     // second constant-bus operand)
+            if (X_NOEPI) return;
             // channels n0 + 32 cb + 8 g + 4 lh + {0..3}: chunk 2 cb + (g >> 1), k-half g & 1 -> plane 8 cb + 4 (g >> 1) + 2 (g & 1) (+ 1: lo)
             unsigned np16o = out_np16;
             asm volatile("" : "+s"(np16o));
             const unsigned so = (unsigned)(8 * cb + 4 * (g >> 1) + 2 * (g & 1)) * np16o;
-            const unsigned vo = off + (unsigned)(rb * 32 * 16);     // (immediate field; E_INVALID + 512 is still beyond the tensor)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, e_hh), orsrc, (int)vo, (int)so, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, e_ll), orsrc, (int)vo, (int)(so + np16o), 0);
+            const unsigned vo = sel + (unsigned)(rb * 32 * 16);     // (immediate field; E_INVALID + 512 is still beyond the tensor)
+            u32x2 dh, dl;
+            dh[0] = e_h01; dh[1] = e_h23; dl[0] = e_l01; dl[1] = e_l23;
+            __builtin_amdgcn_raw_buffer_store_b64(dh, orsrc, (int)vo, (int)so, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(dl, orsrc, (int)vo, (int)(so + np16o), 0);
         } else {
+            int wr = wrow;
+            asm volatile("" : "+v"(wr), "+s"(rowb));
+            const bool ok = wr < tile_rows - rb * 32;
+            const unsigned off = ok ? vb : E_INVALID;
+            if (X_NOEPI) return;
             u32x4 d;
             d[0] = __float_as_uint(e_v.x); d[1] = __float_as_uint(e_v.y); d[2] = __float_as_uint(e_v.z); d[3] = __float_as_uint(e_v.w);
             __builtin_amdgcn_raw_buffer_store_b128(d, orsrc, (int)off, rb * 32 * rowb + (32 * cb + 8 * g) * 4, 0);
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
             const unsigned sw_next = (pass & 1u) ? 0u : (unsigned)(2 * WQH_SLOT);    // taps 7, 8 of pass + 1
             unsigned vb = E_INVALID;
             int erows = 0;
-            if (EP) { vb = epi_base(etile); erows = tile_rows_of(etile); }
+            if (EP) { vb = epi_base(etile); erows = tile_rows_of(etile); if (OUT_HL) { e_lim = erows - wrow; e_inv = E_INVALID; asm volatile("" : "+v"(e_inv)); } }
 #pragma unroll
             for (int v = 0; v < NT; ++v) {
                 const int cs = (v + t) & 1, ns = cs ^ 1;
@@ -310,8 +323,10 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
                     // every fragment read of this block has been issued; this wave's DMA pieces (the other footprint, and in a
                     // chunk's second block the next chunk's weights) have landed; then meet
                     __builtin_amdgcn_sched_barrier(0);
+                    if (!X_NOBAR) {
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (t == 1) {                    // the next chunk's weights are resident from here on
                         bread78 = bread + sw_next;
@@ -360,34 +375,39 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
                     // ---- weights of the next chunk (a chunk's second block only).  Step 0: taps 7, 8 into the free slot pair; step v + 1
                     // (v = 0..6): tap v, which every wave has read for the last time in slot 3 of its step v (published in slot 5)
                     if (t == 1) {
-                        if (v <= 6 && s == 5) publish(v, pass + 1u);
+                        if (v <= 6 && s == 5 && !X_NOFLAG) publish(v, pass + 1u);
                         if (v == 0 && s >= 12 && s < 16) load_weight_piece(nc0, 7 + ((s - 12) >> 1), (s - 12) & 1, sw_next);
-                        if (v >= 1 && v <= 7 && s == 16) await(v - 1, pass + 1u);
+                        if (v >= 1 && v <= 7 && s == 16 && !X_NOFLAG) await(v - 1, pass + 1u);
                         if (v >= 1 && v <= 7 && (s == 17 || s == 18)) load_weight_piece(nc0, v - 1, s - 17, 0u);
                     }
                     // ---- footprint of the next block: slices 2 v, 2 v + 1 in step v (v = 0..3), slots 20 and 22
                     if (v <= 3 && (s == 20 || s == 22)) load_slice(pn, nc0, 2 * v + ((s - 20) >> 1), 1 - t);
                     // ---- epilogue of the other accumulator set: 32 units (rb, cb, g)
-                    if (EP && TR && !OUT_HL && v <= 7 && s < 12) {
-                        const int unit = v * 4 + s / 3;
-                        const int erb = unit >> 4, ecb = (unit >> 2) & 3, eg = unit & 3;
-                        const floatx16& oa = erb == 0 ? (ecb == 0 ? o00 : ecb == 1 ? o01 : ecb == 2 ? o02 : o03) : (ecb == 0 ? o10 : ecb == 1 ? o11 : ecb == 2 ? o12 : o13);
-                        if (s % 3 == 0) { if (unit == 0) epi0_a(0); if (unit + 1 < 32) epi0_a(unit + 1); }
-                        else if (s % 3 == 1) epi0_b(oa, unit);
-                        else epi0_c(erb, ecb, eg, vb, erows);
+                    // (the block's barrier waits vmcnt(0) for its LDS-DMA pieces, which also waits for every store issued before it:
+                    // the units are packed into the first steps so that the last store is two to four steps old by then)
+                    if (EP && TR && !OUT_HL && v <= 5 && s < 18) {            // three pieces per unit, six units per step
+                        const int unit = v * 6 + s / 3;
+                        if (unit < 32) {
+                            const int erb = unit >> 4, ecb = (unit >> 2) & 3, eg = unit & 3;
+                            const floatx16& oa = erb == 0 ? (ecb == 0 ? o00 : ecb == 1 ? o01 : ecb == 2 ? o02 : o03) : (ecb == 0 ? o10 : ecb == 1 ? o11 : ecb == 2 ? o12 : o13);
+                            if (s % 3 == 0) { if (unit == 0) epi0_a(0); if (unit + 1 < 32) epi0_a(unit + 1); }
+                            else if (s % 3 == 1) epi0_b(oa, unit);
+                            else epi0_c(erb, ecb, eg, vb, erows);
+                        }
                     }
-                    if (EP && TR && OUT_HL && v <= 7 && s < 20) {             // five pieces per unit, four units per step
-                        const int unit = v * 4 + s / 5;
-                        const int erb = unit >> 4, ecb = (unit >> 2) & 3, eg = unit & 3;
-                        const floatx16& oa = erb == 0 ? (ecb == 0 ? o00 : ecb == 1 ? o01 : ecb == 2 ? o02 : o03) : (ecb == 0 ? o10 : ecb == 1 ? o11 : ecb == 2 ? o12 : o13);
-                        if (s % 5 == 0) { if (unit == 0) epi0_a(0); if (unit + 1 < 32) epi0_a(unit + 1); }
-                        else if (s % 5 == 1) epi0_b(oa, unit);
-                        else if (s % 5 == 2) epi0_h();
-                        else if (s % 5 == 3) epi0_l();
-                        else epi0_c(erb, ecb, eg, vb, erows);
+                    if (EP && TR && OUT_HL && v <= 5) {                      // four pieces per unit, six units per step
+                        const int unit = v * 6 + s / 4;
+                        if (unit < 32) {
+                            const int erb = unit >> 4, ecb = (unit >> 2) & 3, eg = unit & 3;
+                            const floatx16& oa = erb == 0 ? (ecb == 0 ? o00 : ecb == 1 ? o01 : ecb == 2 ? o02 : o03) : (ecb == 0 ? o10 : ecb == 1 ? o11 : ecb == 2 ? o12 : o13);
+                            if (s % 4 == 0) { if (unit == 0) epi0_a(0); if (unit + 1 < 32) epi0_a(unit + 1); epi0_b(oa, unit); }
+                            else if (s % 4 == 1) epi0_h();
+                            else if (s % 4 == 2) epi0_l();
+                            else epi0_c(erb, ecb, eg, vb, erows);
+                        }
                     }
-                    if (EP && !TR && v <= 7 && s < 8) {
-                        const int unit = v * 4 + s / 2;
+                    if (EP && !TR && v <= 3 && s < 16) {                     // two pieces per unit, eight units per step
+                        const int unit = v * 8 + s / 2;
                         const int erb = unit >> 4, ecb = (unit >> 2) & 3, eg = unit & 3;
                         const floatx16& oa = erb == 0 ? (ecb == 0 ? o00 : ecb == 1 ? o01 : ecb == 2 ? o02 : o03) : (ecb == 0 ? o10 : ecb == 1 ? o11 : ecb == 2 ? o12 : o13);
                         if (s % 2 == 0) epi1_a(oa, ecb, eg); else epi1_b(erb, ecb, eg, vb, erows);
@@ -432,6 +452,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
     {
         const unsigned vb = epi_base(prev_tile1);
         const int erows = tile_rows_of(prev_tile1);
+        e_lim = erows - wrow; e_inv = E_INVALID; asm volatile("" : "+v"(e_inv));
 #pragma unroll
         for (int unit = 0; unit < 32; ++unit) {
             const int erb = unit >> 4, ecb = (unit >> 2) & 3, eg = unit & 3;

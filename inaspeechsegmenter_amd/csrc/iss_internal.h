@@ -36,6 +36,11 @@ struct IssNet {
     int in_h = 0, in_w = 0, in_c = 0, out_dim = 0;
     double flops_per_sample = 0;
     std::unordered_map<long long, int> fp_pix;   // (row << 32 | samples) -> pixels a 128-row tile's LDS footprint spans
+    // precision guard (iss_set_precision_guard / iss_cnn_precision_info)
+    int prec_override = -1;               // -1: the context's mode; else ISS_PREC_* for this network only
+    int guard_state = 0;                  // ISS_GUARD_*
+    float guard_dlogp = -1.f;             // max |log p(split bf16) - log p(exact f32)| of the probe, -1 = never probed
+    int guard_slots = 0;                  // windows the probe compared
 };
 
 struct iss_ctx {
@@ -65,6 +70,8 @@ struct iss_ctx {
     IssNet nets[ISS_MAX_NETS];
     uint64_t ws_limit = 12ull << 30;
     int precision = ISS_PREC_BF16X3;
+    float guard_threshold = 5e-4f;        // precision guard: escalate a patch network to exact f32 above this max |d log p| (<= 0: guard off)
+    bool in_guard = false;
     uint32_t diag = 0;                    // ISS_DIAG_* kernel-selection switches (iss_set_diag; 0 in production)
     std::vector<DevBuf> act;              // activation buffers (grown on demand)
     DevBuf d_winrow, d_stats, d_finite, d_out, d_in;

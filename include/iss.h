@@ -177,6 +177,24 @@ int iss_cnn_forward(iss_ctx* ctx, int net_id, const float* x, int32_t n, float* 
 #define ISS_PREC_F32    1
 int iss_set_precision(iss_ctx* ctx, int mode);
 
+/* Precision guard for weights nobody has measured (north star: "frame logits within 1e-3 fp32"; segmenter.py:163,176 --
+ * the reference's emissions are log(predict(...)) in f32).  The default arithmetic (ISS_PREC_BF16X3) sits 2.5-3.7x inside that
+ * bound on the stand-in networks (profiles/r06_precision_emulation.txt); whether it does on the weights actually loaded depends on
+ * their activation ranges.  So the FIRST iss_cnn_probs / iss_cnn_probs_async call of a patch network in split-bf16 mode first runs
+ * up to 256 of the call's own windows (four runs of consecutive slots spread over the list) in both modes, records
+ * max |log p_bf16x3 - log p_f32| over every class of every finite window, and -- when that exceeds `threshold` (default 5e-4,
+ * half the bound) -- switches THIS network to ISS_PREC_F32 for the rest of its life (slower, reference-grade).
+ * iss_set_precision_guard: threshold <= 0 disables the probe (networks loaded later are not probed; already decided ones keep their mode).
+ * iss_cnn_precision_info: mode in use for the network (ISS_PREC_*), the probe's figure (-1 if not probed), the windows it compared,
+ * ISS_GUARD_* state.  iss_cnn_set_net_precision: caller's override for one network (-1 = follow the context again); marks it decided. */
+#define ISS_GUARD_PENDING   0   /* not probed yet                                              */
+#define ISS_GUARD_PASSED    1   /* probed: within the threshold, split-bf16 kept               */
+#define ISS_GUARD_ESCALATED 2   /* probed: above the threshold, the network now runs exact f32 */
+#define ISS_GUARD_FIXED     3   /* mode set by the caller (iss_cnn_set_net_precision) or the context is in exact-f32 mode anyway */
+int iss_set_precision_guard(iss_ctx* ctx, float threshold);
+int iss_cnn_precision_info(iss_ctx* ctx, int id, int32_t* mode, float* max_dlogp, int32_t* slots, int32_t* state);
+int iss_cnn_set_net_precision(iss_ctx* ctx, int id, int mode);
+
 /* Kernel-selection switches for same-box A/B measurements and for the tests that compare two device paths with each
  * other (e.g. the shared first layer against the per-window one).  0 (default) = production selection.  The library never
  * reads the environment for these: inaspeechsegmenter_amd/_native.py maps the ISS_DIAG environment variable (a

@@ -4,6 +4,6 @@
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd $ROOT
 L=$ROOT/inaspeechsegmenter_amd
-SPECS="base"
+SPECS="base f32:ISS_DIAG=no_hl"
 for x in $L/libiss_hip_x*.so; do [ -e "$x" ] || continue; t=$(basename $x .so); t=${t#libiss_hip_}; SPECS="$SPECS $t:ISS_LIB=$x"; done
 AB_ARGS="${AB_ARGS:---minutes 20}" bash tools/ab_env.sh segmenter $SPECS

@@ -436,3 +436,66 @@ def test_exact_f32_mode_takes_the_weight_stationary_kernels(ctx, net, nmel, ncls
     e_or, e_old, e_x3 = np.abs(p_f32 - ref).max(), np.abs(p_f32 - p_old).max(), np.abs(p_f32 - p_x3).max()
     print(f'{net}: f32 ws vs oracle {e_or:.2e}, vs conv_igemm_kernel {e_old:.2e}, vs bf16x3 {e_x3:.2e}')
     assert e_or < 1e-4 and e_old < 2e-5 and e_x3 < 1e-4
+
+
+def test_precision_guard_escalates_a_net_with_inflated_activation_range(ctx):
+    """Round 6 (include/iss.h, iss_set_precision_guard): the first iss_cnn_probs call of a patch network in split-bf16 mode compares
+    both arithmetic modes on up to 256 of its own windows.  The calibrated stand-in passes (max |d log p| a few 1e-4 at most, mode
+    kept); the same network with its last two layers scaled so that its logits are ~30 x larger -- what confident real weights
+    look like -- trips the 5e-4 threshold, is switched to exact f32 by the library, and its results then sit within the north
+    star's 1e-3 of the oracle's log-probabilities, which the split-bf16 results (guard off) do not."""
+    import bench
+    nmel, ncls = 21, 3
+    pcm = bench.synth_recording(0, 60 * 16000, 'cpu').numpy()            # the bench generator's audio: silence, noise, a voiced source, chords
+    ctx.set_signal(pcm)
+    T = ctx.sidekit()
+    mspec = ctx.get_mspec()
+    rows = S._window_rows(T)
+    layers, shp = KM.synthetic_ina_like(nmel, ncls, seed=1)
+    ctx.set_precision_guard(5e-4)                                        # (the shared test context runs with the guard off)
+    ctx.cnn_load(3, KM.compile_layers(layers, shp))
+    assert ctx.cnn_precision_info(3)['state'] == 'pending'
+    p0, f0 = ctx.cnn_probs(3, rows)
+    info = ctx.cnn_precision_info(3)
+    print('stand-in:', info)
+    assert info['state'] == 'passed' and info['mode'] == 'bf16x3' and 0 <= info['max_dlogp'] < 5e-4 and info['slots'] > 100, info
+    ref0, _ = _oracle_probs(layers, mspec, nmel, rows)
+    assert np.abs(p0 - ref0).max() < 1e-4, np.abs(p0 - ref0).max()
+
+    hot = [dict(L) for L in layers]
+    for i in (-2, -1):                                                   # dense(192, 128, relu), dense(128, ncls, softmax)
+        hot[i]['W'] = (hot[i]['W'] * 5.5).astype(np.float32)
+        hot[i]['b'] = (hot[i]['b'] * 5.5).astype(np.float32)
+    ref, fin = _oracle_probs(hot, mspec, nmel, rows)
+    ok = fin[:, None] & (ref > 1e-30)
+
+    def dlogp(p):
+        with np.errstate(divide='ignore'):
+            return np.abs(np.log(p.astype(np.float64)) - np.log(ref.astype(np.float64)))[ok & (p > 1e-30)].max()
+
+    ctx.set_precision_guard(0)                                           # guard off: split-bf16 on a net it is too coarse for
+    try:
+        ctx.cnn_load(3, KM.compile_layers(hot, shp))
+        p_x3, _ = ctx.cnn_probs(3, rows)
+        assert ctx.cnn_precision_info(3)['state'] == 'pending'
+    finally:
+        ctx.set_precision_guard(5e-4)
+    ctx.cnn_load(3, KM.compile_layers(hot, shp))                         # guard on (the library's default)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    p_g, f_g = ctx.cnn_probs(3, rows)
+    ctx.prof_enable(False)
+    info = ctx.cnn_precision_info(3)
+    print('inflated:', info, 'split-bf16 max |d log p| vs oracle', dlogp(p_x3), 'guarded', dlogp(p_g))
+    assert info['state'] == 'escalated' and info['mode'] == 'f32' and info['max_dlogp'] > 5e-4, info
+    assert np.array_equal(f_g, fin)
+    assert dlogp(p_g) < 1e-3, dlogp(p_g)
+    assert dlogp(p_x3) > dlogp(p_g)
+    p_again, _ = ctx.cnn_probs(3, rows)                                  # decided once: no second probe, same arithmetic
+    assert np.array_equal(p_again, p_g) and ctx.cnn_precision_info(3)['slots'] == info['slots']
+    # the caller's own choice wins and is never probed
+    ctx.cnn_load(3, KM.compile_layers(hot, shp))
+    ctx.cnn_set_net_precision(3, _native.PREC_BF16X3)
+    p_fix, _ = ctx.cnn_probs(3, rows)
+    assert ctx.cnn_precision_info(3)['state'] == 'fixed' and np.array_equal(p_fix, p_x3)
+    ctx.set_precision_guard(0)
