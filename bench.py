@@ -451,6 +451,25 @@ def viterbi_min_margin(logp, trans):
     return float((srt[:, -1] - srt[:, -2]).min()) if np.isfinite(best).all() else 0.0
 
 
+def _own_flops_share(seg, kernel_name):
+    """Share of a first-layer-fused launch's credited flops that its own convolution performs: the library credits the fused first
+    layer as the reference computes it (once per window, segmenter.py:82-84) although it runs once per log-mel row.  1.0 for any
+    other kernel; both networks' second convolutions weighted by their flops (they alternate, the same slots each)."""
+    from inaspeechsegmenter_amd import _native as N
+    if 'wq_kernel' not in kernel_name and 'FUSED' not in kernel_name and ',true,1' not in kernel_name:
+        return 1.0
+    own = cred = 0.0
+    for net in (seg.vad, seg.gender if seg.detect_gender else None):
+        if net is None:
+            continue
+        rows = [r for r in net.compiled.prog if r[N.C_OP] == N.OP_CONV]
+        if len(rows) < 2:
+            return 1.0
+        f = [2.0 * r[N.C_KH] * r[N.C_KW] * r[N.C_CIN] * r[N.C_COUT] * r[N.C_HO] * r[N.C_WO] for r in rows[:2]]
+        own += f[1]; cred += f[0] + f[1]
+    return own / cred if cred else 1.0
+
+
 def parity_check(seg, pcm_host, nsec, det):
     """GPU vs oracle on the cpu_baseline sample: identical segments; max |p_gpu - p_oracle| and the number of slots whose
     arg-max class differs, over every slot the oracle evaluated (VAD net on its energy slots, gender net on its speech
@@ -587,8 +606,8 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind, seg=None, comm=
     own_seg = seg is None
     if own_seg:
         seg = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models='synthetic', device=local_rank)
-    x3 = args.precision == 'bf16x3'
-    seg.ctx.set_precision(_native.PREC_BF16X3 if x3 else _native.PREC_F32)
+    x3 = args.precision != 'f32'
+    seg.ctx.set_precision({'bf16x3': _native.PREC_BF16X3, 'f16x3': _native.PREC_F16X3, 'f32': _native.PREC_F32}[args.precision])
     dense = bool(args.dense_files if dense is None else dense)
     seg.dense_batches = dense                        # both networks on every slot of every file (comparable with the resident-path figure)
     if comm is None and world > 1:
@@ -713,7 +732,7 @@ def bench_files(args, torch, dev, local_rank, rank, world, kind, seg=None, comm=
             "metric": "hours-of-audio segmented/sec (smn+gender, 16 kHz mono)",
             "value": value, "unit": "hours-of-audio/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (bf16x3 split-operand MFMA, f32 accumulate; f64 FFT)" if x3 else "f32 (f32 MFMA; f64 FFT)"),
+            "dtype": (f"f32 ({args.precision} split-operand MFMA, f32 accumulate; f64 FFT)" if x3 else "f32 (f32 MFMA; f64 FFT)"),
             "data": "synthetic", "x_realtime_per_gpu": value * 3600.0 / world,
             "config": {"workload": (f"BASELINE.json configs[2]: {nfiles} x {minutes:g} min synthetic 16 kHz mono PCM16 WAV files in {args.dir} "
                                     "through Segmenter.batch_process" if kind == 'batch' else
@@ -772,7 +791,7 @@ def bench_vbx(args, torch, dev, local_rank, rank, world, steps=None, warmup=None
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
     ctx = _native.Context(local_rank)
-    ctx.set_precision(_native.PREC_BF16X3 if args.precision == 'bf16x3' else _native.PREC_F32)
+    ctx.set_precision({'bf16x3': _native.PREC_BF16X3, 'f16x3': _native.PREC_F16X3, 'f32': _native.PREC_F32}[args.precision])
     if args.workspace_mb:
         ctx.set_workspace_limit(args.workspace_mb << 20)
     fe = V.FeatureExtractor(ctx)
@@ -807,7 +826,7 @@ def bench_vbx(args, torch, dev, local_rank, rank, world, steps=None, warmup=None
     step()
     conv_ms, conv_launches, conv_flops = ctx.prof_get(0)
     fb_ms, _, _ = ctx.prof_get(1)                    # vbx_fbank_kernel alone (HIP events on the library's stream)
-    ktab, kdom = gemm_kernel_table([ctx], MFMA_BF16_PEAK_TF if args.precision == 'bf16x3' else MFMA_F32_PEAK_TF, _pmc_static())
+    ktab, kdom = gemm_kernel_table([ctx], MFMA_BF16_PEAK_TF if args.precision != 'f32' else MFMA_F32_PEAK_TF, _pmc_static())
     ctx.prof_enable(False)
     # feature stage: algorithmic bytes = PCM16 in + the cached dither stream (f64) + (T, 64) f32 out
     T = n // 160
@@ -841,7 +860,7 @@ def bench_vbx(args, torch, dev, local_rank, rank, world, steps=None, warmup=None
     line = {"metric": "hours-of-audio through the vbx x-vector path per second", "value": steps * hours / dt,
             "unit": "hours-of-audio/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "x_realtime": steps * hours * 3600 / dt,
-            "higher_is_better": True, "dtype": "f32 (bf16x3 split-operand MFMA; f64 fbank front end)", "data": "synthetic",
+            "higher_is_better": True, "dtype": f"f32 ({args.precision} split-operand MFMA; f64 fbank front end)", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[4]: {args.minutes:g} min synthetic audio, get_features + ResNet-101 on "
                                    f"{nwin} windows (seeded stand-in weights); PCM16 in page-locked host memory -> device, features stay in HBM",
                        "features_ms_per_step": tf / steps * 1e3, "xvectors_ms_per_step": tx / steps * 1e3},
@@ -948,8 +967,8 @@ def main():
     ap.add_argument('--batch-seconds', type=float, default=0, help='batch / archive: audio per device pass at most (0 = library default, 2400 s)')
     ap.add_argument('--workers', type=int, default=0, help='batch / archive: device contexts taking super-batches in turn (0 = library default, 4)')
     ap.add_argument('--workspace-mb', type=int, default=0, help='activation workspace cap (0 = library default)')
-    ap.add_argument('--precision', choices=['bf16x3', 'f32'], default='bf16x3',
-                    help='conv/dense GEMM arithmetic: split-bf16 MFMA (default) or exact-f32 MFMA')
+    ap.add_argument('--precision', choices=['bf16x3', 'f16x3', 'f32'], default='f16x3',
+                    help='conv/dense GEMM arithmetic: split-fp16 MFMA (ISS_PREC_F16X3, the library default), split-bf16 MFMA or exact-f32 MFMA')
     ap.add_argument('--comm', choices=['rccl', 'torch', 'gloo'], default='rccl',
                     help="N > 1 exchange step: rccl = iss_allgather_segments (ncclAllGather through the C-ABI; the default and the only "
                          "multi-GPU data path -- a failed rendezvous is an error, there is no fallback); torch = a torch.distributed nccl "
@@ -1000,8 +1019,8 @@ def main():
     from inaspeechsegmenter_amd import Segmenter, _native
 
     seg = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models='synthetic', device=local_rank)
-    x3 = args.precision == 'bf16x3'
-    seg.ctx.set_precision(_native.PREC_BF16X3 if x3 else _native.PREC_F32)
+    x3 = args.precision != 'f32'
+    seg.ctx.set_precision({'bf16x3': _native.PREC_BF16X3, 'f16x3': _native.PREC_F16X3, 'f32': _native.PREC_F32}[args.precision])
     if args.workspace_mb:
         seg.ctx.set_workspace_limit(args.workspace_mb << 20)
     comm, comm_kind = make_comm(seg.ctx, rank, world, dev, args.comm)
@@ -1063,14 +1082,16 @@ def main():
                 "achieved": kd["achieved"], "peak": peak_tf, "unit": "TFLOP/s", "frac": kd["frac"],
                 "traffic": kd.get("traffic_per_launch_static"), "traffic_source": traffic_src,
                 "traffic_pmc_run_mean_launch": kd.get("traffic_per_launch_pmc_run"), "traffic_scale_to_this_run": kd.get("traffic_scale_to_this_run"),
+                "frac_own_flops": kd["frac"] * _own_flops_share(seg, kd["kernel"]),
                 "flops_per_launch": kd["flops_per_launch"], "avg_launch_ms": kd["avg_launch_ms"],
                 "launches_per_step": kd["launches"], "kernel_ms_per_step": kd["ms_per_step"],
                 "mfma_executed_tflops": kd["achieved"] * (3 if x3 else 1),
                 "what": ("the kernel INSTANTIATION with the most HIP-event time in one dense step (template arguments spelled out: "
                          "<KH,KW,PADDED,TR,FUSED,NH,EPI>); achieved = its algorithmic flops per launch / its average launch duration. "
-                         "bf16x3: three v_mfma_f32_32x32x16_bf16 per k-step on bf16 hi/lo operand splits -- the matrix pipe executes "
-                         "3 x the algorithmic flops, so frac <= 1/3 by construction; the first layer of a fused launch (1.9 % of its "
-                         "flops) is counted as the reference computes it (once per window) although it runs once per log-mel row")
+                         "split modes (f16x3 / bf16x3): three v_mfma_f32_32x32x16_{f16,bf16} per k-step on 16-bit hi/lo operand halves -- the "
+                         "matrix pipe executes 3 x the algorithmic flops, so frac <= 1/3 by construction; the first layer of a fused launch "
+                         "(2.5 % of its flops) is counted as the reference computes it (once per window) although it runs once per log-mel "
+                         "row: frac_own_flops leaves that credit out")
                         if x3 else "conv_igemm_kernel (conv2d/dense implicit GEMM on v_mfma_f32_32x32x2_f32)",
                 "kernels": ktab,
                 "all_gemm_launches": {"achieved": all_tf, "frac": all_tf / peak_tf, "kernel_ms_per_step": conv_ms, "launches_per_step": conv_launches,
@@ -1094,10 +1115,10 @@ def main():
         step(True)
         c_ms, c_n, c_fl = seg.ctx.prof_get(0)
         seg.ctx.prof_enable(False)
-        seg.ctx.set_precision(_native.PREC_BF16X3)
+        seg.ctx.set_precision({'bf16x3': _native.PREC_BF16X3, 'f16x3': _native.PREC_F16X3, 'f32': _native.PREC_F32}[args.precision])
         tf32 = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
         f32c = {"value": world * hours / dt32, "unit": "hours-of-audio/s", "ms_per_step": dt32 * 1e3, "achieved": tf32,
-                "peak": MFMA_F32_PEAK_TF, "frac": tf32 / MFMA_F32_PEAK_TF, "segments_equal_bf16x3": lseg32 == lseg,
+                "peak": MFMA_F32_PEAK_TF, "frac": tf32 / MFMA_F32_PEAK_TF, "segments_equal_split_mode": lseg32 == lseg,
                 "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact f32 products and accumulation)"}
 
     cpu = par = None
@@ -1135,7 +1156,7 @@ def main():
             "metric": "hours-of-audio segmented/sec (smn+gender, 16 kHz mono)",
             "value": value, "unit": "hours-of-audio/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (bf16x3 split-operand MFMA, f32 accumulate; f64 FFT)" if x3 else "f32 (f32 MFMA; f64 FFT)"),
+            "dtype": (f"f32 ({args.precision} split-operand MFMA, f32 accumulate; f64 FFT)" if x3 else "f32 (f32 MFMA; f64 FFT)"),
             "data": "synthetic",
             "x_realtime_per_gpu": value * 3600.0 / world,
             "config": {"workload": f"BASELINE.json configs[1] input ({args.minutes:g} min synthetic 16 kHz mono PCM16 per GPU, "

@@ -15,7 +15,7 @@ PROG_COLS = 32
 OP_CONV, OP_POOL, OP_SOFTMAX, OP_STATPOOL, OP_ACT = 1, 2, 3, 4, 5
 (C_OP, C_IN, C_OUT, C_RES, C_H, C_W, C_CIN, C_HO, C_WO, C_COUT, C_KH, C_KW, C_SH, C_SW, C_PT, C_PL,
  C_ACT, C_WOFF, C_BOFF, C_PSOFF, C_PTOFF, C_INMODE, C_POOLKIND, C_ORDER, C_FPOOLH, C_FPOOLW, C_DUALW, C_DUALB, C_ACTPARAM) = range(29)
-PREC_BF16X3, PREC_F32 = 0, 1
+PREC_BF16X3, PREC_F32, PREC_F16X3 = 0, 1, 2
 K_ALIGN = 32          # conv weight rows are padded to a multiple of this many k
 BUF_INPUT = -2
 MAX_NETS = 8
@@ -81,7 +81,7 @@ def lib():
         'iss_cnn_flops': (C.c_int, [vp, C.c_int, pd]),
         'iss_set_precision': (C.c_int, [vp, C.c_int]),
         'iss_set_precision_guard': (C.c_int, [vp, C.c_float]),
-        'iss_cnn_precision_info': (C.c_int, [vp, C.c_int, pi32, pf, pi32, pi32]),
+        'iss_cnn_precision_info': (C.c_int, [vp, C.c_int, pi32, pf, pi32, pi32, pf]),
         'iss_cnn_set_net_precision': (C.c_int, [vp, C.c_int, C.c_int]),
         'iss_vbx_tables': (C.c_int, [vp, pd, pd]),
         'iss_vbx_features': (C.c_int, [vp, pi32, pd, i64, pf, pi32]),
@@ -392,10 +392,11 @@ class Context:
     def cnn_precision_info(self, net_id):
         """{'mode': PREC_*, 'max_dlogp': probe figure or None, 'slots': windows compared, 'state': 'pending' | 'passed' |
         'escalated' | 'fixed'} of one loaded network."""
-        mode, slots, state, d = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_float(0)
-        self._ck(self._L.iss_cnn_precision_info(self._h, int(net_id), C.byref(mode), C.byref(d), C.byref(slots), C.byref(state)),
+        mode, slots, state, d, du = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_float(0), C.c_float(0)
+        self._ck(self._L.iss_cnn_precision_info(self._h, int(net_id), C.byref(mode), C.byref(d), C.byref(slots), C.byref(state), C.byref(du)),
                  'iss_cnn_precision_info')
-        return {'mode': 'f32' if mode.value == PREC_F32 else 'bf16x3', 'max_dlogp': None if d.value < 0 else float(d.value),
+        return {'mode': {PREC_F32: 'f32', PREC_F16X3: 'f16x3'}.get(mode.value, 'bf16x3'), 'max_dlogp': None if d.value < 0 else float(d.value),
+                'max_dlogp_in_use': None if du.value < 0 else float(du.value),
                 'slots': slots.value, 'state': ('pending', 'passed', 'escalated', 'fixed')[state.value]}
 
     def cnn_set_net_precision(self, net_id, mode):

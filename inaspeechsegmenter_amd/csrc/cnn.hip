@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256, NTN <= 4 ? 2 : 1) void conv_x3_kernel(const Co
 // workgroups walk the XCD-aware tile order and the register prefetch runs ACROSS tiles (the next tile's first k-tile is
 // fetched during the current tile's last one, its stores drain behind the next tile's MFMAs); no row decomposition
 // (row m of the GEMM is pixel m).
+template <bool F16>                                // fp16 instead of bf16 operand halves (ISS_PREC_F16X3, conv_common.h)
 __global__ __launch_bounds__(256, 2) void conv_x3_pw_kernel(const ConvArgs p) {
     __shared__ __attribute__((aligned(16))) uint16_t sAh[2][BM * XLD];
     __shared__ __attribute__((aligned(16))) uint16_t sAl[2][BM * XLD];
@@ -349,10 +350,17 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pw_kernel(const ConvArgs p) {
                           "+v"(r.a[3].z), "+v"(r.a[3].w));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if constexpr (F16) {
+                uint2 h, l;
+                split4_pk<true>(r.a[j], h.x, h.y, l.x, l.y);
+                *reinterpret_cast<uint2*>(&sAh[buf][(lr + 32 * j) * XLD + k8 * 4]) = h;
+                *reinterpret_cast<uint2*>(&sAl[buf][(lr + 32 * j) * XLD + k8 * 4]) = l;
+            } else {
             bf16x4 h, l;
             split4(r.a[j], h, l);
             *reinterpret_cast<bf16x4*>(&sAh[buf][(lr + 32 * j) * XLD + k8 * 4]) = h;
             *reinterpret_cast<bf16x4*>(&sAl[buf][(lr + 32 * j) * XLD + k8 * 4]) = l;
+            }
         }
         *reinterpret_cast<uint4*>(&sBh[buf][br * XLD + bseg * 8]) = r.bh;
         *reinterpret_cast<uint4*>(&sBl[buf][br * XLD + bseg * 8]) = r.bl;
@@ -400,12 +408,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pw_kernel(const ConvArgs p) {
             const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + 32 * XLD + ks * 16]);
             const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + 32 * XLD + ks * 16]);
             // C^T: rows = channels, columns = pixels (epilogue_tr); two independent accumulators alternate
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0h, al, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1h, al, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0l, ah, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1l, ah, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0h, ah, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1h, ah, acc1, 0, 0, 0);
+            acc0 = mfma_x3<F16>(b0h, al, acc0);
+            acc1 = mfma_x3<F16>(b1h, al, acc1);
+            acc0 = mfma_x3<F16>(b0l, ah, acc0);
+            acc1 = mfma_x3<F16>(b1l, ah, acc1);
+            acc0 = mfma_x3<F16>(b0h, ah, acc0);
+            acc1 = mfma_x3<F16>(b1h, ah, acc1);
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -985,6 +993,8 @@ int iss_cnn_free(iss_ctx* c, int id) {
     if (n.d_blob) (void)hipFree(n.d_blob);
     if (n.d_wh) (void)hipFree(n.d_wh);
     if (n.d_wl) (void)hipFree(n.d_wl);
+    if (n.d_wh16) (void)hipFree(n.d_wh16);
+    if (n.d_wl16) (void)hipFree(n.d_wl16);
     if (n.d_wsum) (void)hipFree(n.d_wsum);
     if (n.d_ktab) (void)hipFree(n.d_ktab);
     n = IssNet();
@@ -1081,6 +1091,20 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
             hi[i] = bf16_rne(blob[i]);
             lo[i] = bf16_rne(blob[i] - bf16_to_f32(hi[i]));
         }
+        // fp16 split of the same values (ISS_PREC_F16X3); a value outside fp16's range makes the whole network ineligible
+        std::vector<uint16_t> hi16((size_t)blob_floats), lo16((size_t)blob_floats);
+        n.f16_ok = true;
+        for (int64_t i = 0; i < blob_floats; ++i) {
+            const float x = blob[i];
+            if (!(std::fabs(x) < 65504.f)) { n.f16_ok = false; hi16[i] = lo16[i] = 0; continue; }
+            const _Float16 h = (_Float16)x;
+            const _Float16 l = (_Float16)(x - (float)h);
+            memcpy(&hi16[i], &h, 2); memcpy(&lo16[i], &l, 2);
+        }
+        ISS_HIP(c, hipMalloc((void**)&n.d_wh16, (size_t)blob_floats * 2 + 16));
+        ISS_HIP(c, hipMalloc((void**)&n.d_wl16, (size_t)blob_floats * 2 + 16));
+        ISS_HIP(c, hipMemcpy(n.d_wh16, hi16.data(), (size_t)blob_floats * 2, hipMemcpyHostToDevice));
+        ISS_HIP(c, hipMemcpy(n.d_wl16, lo16.data(), (size_t)blob_floats * 2, hipMemcpyHostToDevice));
         ISS_HIP(c, hipMalloc((void**)&n.d_wh, (size_t)blob_floats * 2 + 16));
         ISS_HIP(c, hipMalloc((void**)&n.d_wl, (size_t)blob_floats * 2 + 16));
         ISS_HIP(c, hipMemcpy(n.d_wh, hi.data(), (size_t)blob_floats * 2, hipMemcpyHostToDevice));
@@ -1132,7 +1156,7 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
 
 extern "C" int iss_set_precision(iss_ctx* c, int mode) {
     if (!c) return ISS_EINVAL;
-    if (mode != ISS_PREC_BF16X3 && mode != ISS_PREC_F32) return iss_fail(c, ISS_EINVAL, "iss_set_precision: unknown mode %d", mode);
+    if (mode != ISS_PREC_BF16X3 && mode != ISS_PREC_F32 && mode != ISS_PREC_F16X3) return iss_fail(c, ISS_EINVAL, "iss_set_precision: unknown mode %d", mode);
     c->precision = mode;
     return ISS_OK;
 }
@@ -1146,14 +1170,14 @@ extern "C" int iss_set_precision_guard(iss_ctx* c, float threshold) {
 
 extern "C" int iss_cnn_set_net_precision(iss_ctx* c, int id, int mode) {
     if (!c || id < 0 || id >= ISS_MAX_NETS) return ISS_EINVAL;
-    if (mode != -1 && mode != ISS_PREC_BF16X3 && mode != ISS_PREC_F32) return iss_fail(c, ISS_EINVAL, "iss_cnn_set_net_precision: unknown mode %d", mode);
+    if (mode != -1 && mode != ISS_PREC_BF16X3 && mode != ISS_PREC_F32 && mode != ISS_PREC_F16X3) return iss_fail(c, ISS_EINVAL, "iss_cnn_set_net_precision: unknown mode %d", mode);
     if (!c->nets[id].loaded) return iss_fail(c, ISS_ESTATE, "net %d not loaded", id);
     c->nets[id].prec_override = mode;
     c->nets[id].guard_state = mode == -1 ? ISS_GUARD_PENDING : ISS_GUARD_FIXED;
     return ISS_OK;
 }
 
-extern "C" int iss_cnn_precision_info(iss_ctx* c, int id, int32_t* mode, float* max_dlogp, int32_t* slots, int32_t* state) {
+extern "C" int iss_cnn_precision_info(iss_ctx* c, int id, int32_t* mode, float* max_dlogp, int32_t* slots, int32_t* state, float* dlogp_in_use) {
     if (!c || id < 0 || id >= ISS_MAX_NETS) return ISS_EINVAL;
     const IssNet& n = c->nets[id];
     if (!n.loaded) return iss_fail(c, ISS_ESTATE, "net %d not loaded", id);
@@ -1161,6 +1185,7 @@ extern "C" int iss_cnn_precision_info(iss_ctx* c, int id, int32_t* mode, float* 
     if (max_dlogp) *max_dlogp = n.guard_dlogp;
     if (slots) *slots = n.guard_slots;
     if (state) *state = n.guard_state;
+    if (dlogp_in_use) *dlogp_in_use = n.guard_dlogp_chosen;
     return ISS_OK;
 }
 
@@ -1238,7 +1263,18 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 const uint8_t* d_fin, const float* d_input, float** result, int rmin = 0, int rmax = -1,
                 bool share_first = false) {
     const int prec = n.prec_override >= 0 ? n.prec_override : c->precision;          // (precision guard: one network may run exact f32)
-    const bool x3mode = prec == ISS_PREC_BF16X3;
+    const bool x3mode = prec != ISS_PREC_F32;                    // a split-operand mode (bf16 or fp16 halves)
+    // ISS_PREC_F16X3: the launches with an fp16 instantiation (the one-wave-per-SIMD conv2 / conv3 / conv4 kernels and the long-K
+    // dense kernel: > 99.9 % of the segmenter nets' arithmetic) take fp16 operand halves; a SMALL layer without one runs in exact
+    // f32 (conv_igemm_kernel: tests/precision_emulation.py -- the last dense layers in bf16 halves would undo most of the gain),
+    // anything else keeps bf16 halves
+    const bool f16mode = prec == ISS_PREC_F16X3 && n.f16_ok && n.d_wh16 != nullptr;
+    double net_flops = 0.0;
+    if (f16mode)
+        for (int q = 0; q < n.nrows; ++q) {
+            const int32_t* Q = &n.prog[(size_t)q * ISS_PROG_COLS];
+            if (Q[ISS_C_OP] == ISS_OP_CONV) net_flops += 2.0 * Q[ISS_C_KH] * Q[ISS_C_KW] * Q[ISS_C_CIN] * (double)Q[ISS_C_COUT] * Q[ISS_C_HO] * Q[ISS_C_WO];
+        }
     // A PATCH first layer directly in front of a footprint-kernel conv is not launched per window: it is computed once
     // per log-mel row and the second conv normalises it per window while staging its LDS footprint (ConvArgs::f_*,
     // conv_fp.h FUSED).  Static part of the test; the footprint-capacity part is decided when the second row is reached
@@ -1318,6 +1354,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
     // that activation buffer is in the CHL layout (absent: f32 NHWC).  A producer writes CHL only when the NEXT row is the tensor's
     // only reader and runs on conv_x3_wq3h_kernel (wq3_plan: the conditions conv_row launches conv_x3_wq3_kernel under).
     std::map<int, unsigned> hl_np;
+    std::map<int, bool> hl_f16;                                  // ... and holds fp16 (not bf16) planes
+    bool hl_out_f16 = false;
     int hl_out_row = -1;                                         // the row conv_row has just launched with a CHL output ...
     unsigned hl_out_np = 0;                                      // ... and its plane size
     const bool no_hl = (c->diag & ISS_DIAG_NO_HL) != 0;
@@ -1408,7 +1446,12 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         a.act = R[ISS_C_ACT]; a.Kpad = n.kpad[r];
         a.M = (long long)bc * a.Hq * a.Wq * a.pp;
         const bool patch = R[ISS_C_INMODE] == 1;
-        const bool x3 = x3mode;
+        // (fp16 mode) a small layer -- under 0.5 % of the network's arithmetic -- that no fp16 kernel takes: exact f32
+        const double row_flops = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * R[ISS_C_CIN] * (double)R[ISS_C_COUT] * R[ISS_C_HO] * R[ISS_C_WO];
+        const bool small_row = f16mode && pend < 0 && row_flops < 0.005 * net_flops && row_flops < 2e6 &&      // (and small in absolute terms: a
+                               R[ISS_C_INMODE] == 0 && !can_defer(r);                                         //  ResNet-101 has 105 layers under 1 %)
+        const bool x3 = x3mode && !small_row;
+        bool row_f16 = f16mode;                                  // cleared below where the launch has no fp16 form
         const bool in_is_hl = R[ISS_C_IN] != ISS_BUF_INPUT && hl_np.count(R[ISS_C_IN]) != 0;     // (only conv_x3_wq3h_kernel reads that layout)
         bool in_hl_taken = false;
         a.mode = patch ? 2 : ((a.Cin % (x3 ? XBK : 4) == 0) ? 0 : 1);
@@ -1739,8 +1782,10 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 const dim3 qgrid(std::min<unsigned>((qtiles + 1) / 2, std::max(1u, 256u / ny)), ny);
                 if (in_is_hl) {                                  // the producer wrote the CHL layout for this launch (want_hl_out)
                     a.in_hl = 1; a.in_np = hl_np[R[ISS_C_IN]];
+                    if (hl_f16.count(R[ISS_C_IN])) { a.f16 = 1; a.wh = n.d_wh16 + R[ISS_C_WOFF]; a.wl = n.d_wl16 + R[ISS_C_WOFF]; }
                     if (wq3_kind == 0 && want_hl_out(r, a.M)) { a.out_hl = 1; a.out_np = issk::chl_npad(a.M); hl_out_row = r; hl_out_np = a.out_np; }
-                    iss_prof_inst(c, "conv_x3_wq3h_kernel<%d,%s>", wq3_kind, a.out_hl ? "true" : "false");
+                    if (a.out_hl && a.f16) hl_out_f16 = true;
+                    iss_prof_inst(c, a.f16 ? "conv_x3_wq3h_kernel<%d,%s,f16>" : "conv_x3_wq3h_kernel<%d,%s>", wq3_kind, a.out_hl ? "true" : "false");
                     issk::iss_wq3h_launch(a, qgrid, c->stream, wq3_kind);
                     in_hl_taken = true;
                 } else {
@@ -1812,7 +1857,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 const unsigned qtiles = (unsigned)((a.M + a.tmr - 1) / a.tmr);
                 const dim3 qgrid(std::min<unsigned>((qtiles + 1) / 2, 256u), grid.y);     // persistent: one 256-thread workgroup per CU
                 if (a.Cout % BN == 0 && want_hl_out(r, a.M / 4)) { a.out_hl = 1; a.out_np = issk::chl_npad(a.M / 4); hl_out_row = r; hl_out_np = a.out_np; }
-                iss_prof_inst(c, a.out_hl ? "conv_x3_wq_kernel<%d,%d,hl>" : "conv_x3_wq_kernel<%d,%d>", a.H_k, a.kw);
+                if (row_f16) { a.f16 = 1; a.wh = n.d_wh16 + R[ISS_C_WOFF]; a.wl = n.d_wl16 + R[ISS_C_WOFF]; if (a.out_hl) hl_out_f16 = true; }
+                iss_prof_inst(c, a.f16 ? (a.out_hl ? "conv_x3_wq_kernel<%d,%d,hl,f16>" : "conv_x3_wq_kernel<%d,%d,f16>")
+                                       : (a.out_hl ? "conv_x3_wq_kernel<%d,%d,hl>" : "conv_x3_wq_kernel<%d,%d>"), a.H_k, a.kw);
                 issk::iss_wq_launch_5x3(a, qgrid, c->stream);
             } else {
             {
@@ -1887,8 +1934,14 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 iss_prof_inst(c, "conv_x3_pws_kernel<%s,%s>", a.res ? "true" : "false", simple_pw ? "true" : "false");
                 issk::iss_pws_launch(a, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), c->stream);
             } else if (pointwise) {
+                if (row_f16) {
+                    a.f16 = 1; a.wh = n.d_wh16 + R[ISS_C_WOFF]; a.wl = n.d_wl16 + R[ISS_C_WOFF];
+                    iss_prof_inst(c, "conv_x3_pw_kernel<f16>");
+                    hipLaunchKernelGGL(conv_x3_pw_kernel<true>, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), dim3(256), 0, c->stream, a);
+                } else {
                 iss_prof_inst(c, "conv_x3_pw_kernel");
-                hipLaunchKernelGGL(conv_x3_pw_kernel, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), dim3(256), 0, c->stream, a);
+                hipLaunchKernelGGL(conv_x3_pw_kernel<false>, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), dim3(256), 0, c->stream, a);
+                }
             } else {
             iss_prof_inst(c, "conv_x3_kernel<%d,%s,2>", a.mode, (a.mode != 2 && tr) ? "true" : "false");
             if (ntn == 4) hipLaunchKernelGGL((conv_x3_kernel<0, true, 4>), gridw, dim3(256), 0, c->stream, a);
@@ -1979,7 +2032,9 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         ISS_HIP(c, hipGetLastError());
         *result = out;
-        if (hl_out_row == r) hl_np[R[ISS_C_OUT]] = hl_out_np; else hl_np.erase(R[ISS_C_OUT]);
+        if (hl_out_row == r) { hl_np[R[ISS_C_OUT]] = hl_out_np; if (hl_out_f16) hl_f16[R[ISS_C_OUT]] = true; else hl_f16.erase(R[ISS_C_OUT]); }
+        else { hl_np.erase(R[ISS_C_OUT]); hl_f16.erase(R[ISS_C_OUT]); }
+        hl_out_f16 = false;
         if (op != ISS_OP_CONV && R[ISS_C_IN] != ISS_BUF_INPUT && hl_np.count(R[ISS_C_IN]))
             return iss_fail(c, ISS_EINVAL, "internal: row %d reads a CHL tensor", r);
     }
@@ -2019,35 +2074,60 @@ static int cnn_probs_impl(iss_ctx* c, int id, const int32_t* win_row, int32_t ns
 static int precision_guard(iss_ctx* c, int id, const int32_t* win_row, int32_t nslots) {
     IssNet& n = c->nets[id];
     const int eff = n.prec_override >= 0 ? n.prec_override : c->precision;
-    if (eff != ISS_PREC_BF16X3) { n.guard_state = ISS_GUARD_FIXED; return ISS_OK; }
+    if (eff == ISS_PREC_F32) { n.guard_state = ISS_GUARD_FIXED; return ISS_OK; }
     if (!(c->guard_threshold > 0.f)) return ISS_OK;               // guard off: stays pending
     const int runs = nslots >= 256 ? 4 : 1, per = nslots >= 256 ? 64 : nslots;
-    std::vector<float> px((size_t)per * n.out_dim), pf((size_t)per * n.out_dim);
-    std::vector<uint8_t> fx(per), ff(per);
-    double worst = 0.0;
-    int compared = 0, rc = ISS_OK;
-    c->in_guard = true;
-    for (int r = 0; r < runs && rc == ISS_OK; ++r) {
-        const int32_t* w = win_row + (runs == 1 ? 0 : (size_t)r * (nslots - per) / (runs - 1));
-        n.prec_override = ISS_PREC_BF16X3;
-        rc = cnn_probs_impl(c, id, w, per, px.data(), fx.data(), false, nullptr);
-        if (rc == ISS_OK) { n.prec_override = ISS_PREC_F32; rc = cnn_probs_impl(c, id, w, per, pf.data(), ff.data(), false, nullptr); }
-        if (rc != ISS_OK) break;
-        for (int i = 0; i < per; ++i) {
-            if (!fx[i] || !ff[i]) continue;                       // non-finite windows carry the constant 0.5 (segmenter.py:175)
-            ++compared;
-            for (int k = 0; k < n.out_dim; ++k) {
-                const float a = px[(size_t)i * n.out_dim + k], b = pf[(size_t)i * n.out_dim + k];
-                if (!(a > 1e-30f) || !(b > 1e-30f)) { if ((a > 1e-30f) != (b > 1e-30f)) worst = std::max(worst, 1.0); continue; }
-                worst = std::max(worst, std::fabs(std::log((double)a) - std::log((double)b)));
+    const size_t od = (size_t)n.out_dim;
+    std::vector<float> pref((size_t)runs * per * od), pm((size_t)per * od);
+    std::vector<uint8_t> fref((size_t)runs * per), fm(per);
+    auto window_run = [&](int r) { return win_row + (runs == 1 ? 0 : (size_t)r * (nslots - per) / (runs - 1)); };
+    int rc = ISS_OK, compared = 0;
+    // max |log p_mode - log p_f32| over every class of every finite window (non-finite ones carry the constant 0.5, segmenter.py:175);
+    // a NaN (an activation beyond fp16's range) counts as a failure; classes below 1e-30 in either mode are skipped
+    auto probe = [&](int mode, double& worst) {
+        worst = 0.0; compared = 0;
+        for (int r = 0; r < runs && rc == ISS_OK; ++r) {
+            n.prec_override = mode;
+            rc = cnn_probs_impl(c, id, window_run(r), per, pm.data(), fm.data(), false, nullptr);
+            if (rc != ISS_OK) return;
+            for (int i = 0; i < per; ++i) {
+                if (!fm[i] || !fref[(size_t)r * per + i]) continue;
+                ++compared;
+                for (size_t k = 0; k < od; ++k) {
+                    const float a = pm[(size_t)i * od + k], b = pref[((size_t)r * per + i) * od + k];
+                    if (!(a == a)) { worst = 1e30; continue; }
+                    if (!(a > 1e-30f) || !(b > 1e-30f)) continue;      // (an underflowing class: a real disagreement shows in the window's other classes)
+                    worst = std::max(worst, std::fabs(std::log((double)a) - std::log((double)b)));
+                }
             }
+        }
+    };
+    c->in_guard = true;
+    for (int r = 0; r < runs && rc == ISS_OK; ++r) {              // the reference: exact f32
+        n.prec_override = ISS_PREC_F32;
+        rc = cnn_probs_impl(c, id, window_run(r), per, pref.data() + (size_t)r * per * od, fref.data() + (size_t)r * per, false, nullptr);
+    }
+    double worst = 0.0;
+    int chosen = eff;
+    if (rc == ISS_OK) probe(eff, worst);
+    const double first = worst;
+    if (rc == ISS_OK && worst > (double)c->guard_threshold) {
+        chosen = ISS_PREC_F32;
+        // the other split mode first (the same speed as the one that failed): fp16 halves where bf16 ones are too coarse, bf16 halves
+        // where an activation left fp16's range
+        const int other = eff == ISS_PREC_BF16X3 ? ISS_PREC_F16X3 : ISS_PREC_BF16X3;
+        if (other == ISS_PREC_BF16X3 || n.f16_ok) {
+            double w2 = 0.0;
+            probe(other, w2);
+            if (rc == ISS_OK && w2 <= (double)c->guard_threshold) { chosen = other; worst = w2; }
         }
     }
     c->in_guard = false;
     n.prec_override = -1;
     if (rc != ISS_OK) return rc;
-    n.guard_dlogp = (float)worst; n.guard_slots = compared;
-    if (worst > (double)c->guard_threshold) { n.prec_override = ISS_PREC_F32; n.guard_state = ISS_GUARD_ESCALATED; }
+    n.guard_dlogp = (float)std::min(first, 1e30); n.guard_slots = compared;
+    n.guard_dlogp_chosen = chosen == eff ? n.guard_dlogp : (chosen == ISS_PREC_F32 ? 0.f : (float)worst);
+    if (chosen != eff) { n.prec_override = chosen; n.guard_state = ISS_GUARD_ESCALATED; }
     else n.guard_state = ISS_GUARD_PASSED;
     return ISS_OK;
 }

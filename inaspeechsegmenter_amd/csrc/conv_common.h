@@ -88,6 +88,8 @@ struct ConvArgs {
     // input / output of this launch is one; in_np / out_np = pixels per plane (chl_npad of the tensor's pixel count)
     int in_hl, out_hl;
     unsigned in_np, out_np;
+    int f16;                 // operand halves are fp16, not bf16 (ISS_PREC_F16X3): wh / wl point at the fp16 split of the weights, a CHL
+                             // input / output holds fp16 planes; only the kernels with an F16 instantiation are launched with it
 };
 
 // ------------------------------------------------------------------------------------------
@@ -430,6 +432,46 @@ __device__ __forceinline__ void gemm_tile_of_block(unsigned bid, unsigned nblk_m
         mtile = groups * 8 + r / nblk_n;
         ntile = r % nblk_n;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Operand halves of the split arithmetic, by 16-bit type (round 6: ISS_PREC_F16X3).  x = hi + lo with hi = rne16(x),
+// lo = rne16(x - hi): bf16 keeps 8 + 8 mantissa bits (|x - hi - lo| <= 2^-17 |x|, the dropped lo x lo term 2^-16), fp16
+// 11 + 11 (2^-23 / 2^-22) at the same three MFMAs per k-step -- tests/precision_emulation.py: 10-15 x less error in the
+// log-probabilities -- for operands inside fp16's range (|x| < 65504; the lo part of a small x is a SUBNORMAL fp16, which
+// v_mfma_f32_32x32x16_f16 honours exactly: tools/microbench/mfma_f16_denorm.hip).  The 16-bit pairs travel in `unsigned`s and
+// the fragments in bf16x8 registers whatever the type: only the conversions and the MFMA opcode differ.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <bool F16>
+__device__ __forceinline__ floatx16 mfma_x3(const bf16x8& a, const bf16x8& b, const floatx16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// (lo 16 bits = rne16(a), hi 16 bits = rne16(b)) -- one instruction either way on gfx950
+template <bool F16>
+__device__ __forceinline__ unsigned cvt_pk16(float a, float b) {
+    unsigned r;
+    if constexpr (F16) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <bool F16>
+__device__ __forceinline__ float unpk16_lo(unsigned u) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));
+    else return __uint_as_float(u << 16);
+}
+template <bool F16>
+__device__ __forceinline__ float unpk16_hi(unsigned u) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+    else return __uint_as_float(u & 0xffff0000u);
+}
+// split of four values into (h01, h23, l01, l23)
+template <bool F16>
+__device__ __forceinline__ void split4_pk(const float4 v, unsigned& h01, unsigned& h23, unsigned& l01, unsigned& l23) {
+    h01 = cvt_pk16<F16>(v.x, v.y); h23 = cvt_pk16<F16>(v.z, v.w);
+    l01 = cvt_pk16<F16>(v.x - unpk16_lo<F16>(h01), v.y - unpk16_hi<F16>(h01));
+    l23 = cvt_pk16<F16>(v.z - unpk16_lo<F16>(h23), v.w - unpk16_hi<F16>(h23));
 }
 
 // x = hi + lo with hi = bf16(x), lo = bf16(x - hi)  (v_cvt_pk_bf16_f32, round to nearest even)

@@ -52,7 +52,8 @@ constexpr int wq_lds_bytes(int nt) { return nt * F2_BST + 2 * WQ_FB; }
 
 // OUT_HL (round 6): the pooled output is written in the CHL layout (conv_common.h) for a footprint kernel that reads it by LDS-DMA
 // (conv_wq3h.h): per pooled value the operand split (4 VALU) and two 2-byte stores instead of one 4-byte store.
-template <int KH, int KW, bool OUT_HL = false>
+// F16 (round 6): fp16 instead of bf16 operand halves (conv_common.h mfma_x3 / cvt_pk16): the same instruction count.
+template <int KH, int KW, bool OUT_HL = false, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
     constexpr bool X_NOPIPE = ISS_WQ_EXP & 1, X_NOBAR = ISS_WQ_EXP & 2, X_NOEPI = ISS_WQ_EXP & 4, X_NOREAD = ISS_WQ_EXP & 8;
     constexpr bool X_BCAST = ISS_WQ_EXP & 16, X_HALF = ISS_WQ_EXP & 32, X_NOCHUNKBAR = ISS_WQ_EXP & 64;
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
     const unsigned wofs = (unsigned)(prow * WQ_ROW + (cg >> 1) * 32 + (cg & 1) * 8);
     const int wsgn = (cg >> 1) ? -32 : 32;           // ^ 32 on an address whose bit 5 is (cg >> 1), as an add
     // conversion of slice q in six pieces of <= 6 instructions; two register sets (steps 12 and 13 convert two slices each)
+    typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
     struct Cv { float sc, ta, tb, tc, td; float4 v; bf16x4 h; };
     auto convert_1 = [&](Cv& c, int q) {             // select the window's scale / shifts
         const bool second = fm[q] & 1u;
@@ -220,14 +222,24 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
         c.v.x = fmaxf(c.v.x, f_lob); c.v.y = fmaxf(c.v.y, f_lob); c.v.z = fmaxf(c.v.z, f_lob); c.v.w = fmaxf(c.v.w, f_lob);
     };
     auto convert_4 = [&](Cv& c) {                    // hi parts
-        c.h[0] = (__bf16)c.v.x; c.h[1] = (__bf16)c.v.y; c.h[2] = (__bf16)c.v.z; c.h[3] = (__bf16)c.v.w;
+        if constexpr (F16) { u32x2h hh; hh[0] = cvt_pk16<true>(c.v.x, c.v.y); hh[1] = cvt_pk16<true>(c.v.z, c.v.w); c.h = __builtin_bit_cast(bf16x4, hh); }
+        else { c.h[0] = (__bf16)c.v.x; c.h[1] = (__bf16)c.v.y; c.h[2] = (__bf16)c.v.z; c.h[3] = (__bf16)c.v.w; }
     };
     auto convert_5 = [&](Cv& c) {                    // residuals
-        c.v = make_float4(c.v.x - (float)c.h[0], c.v.y - (float)c.h[1], c.v.z - (float)c.h[2], c.v.w - (float)c.h[3]);
+        if constexpr (F16) {
+            const u32x2h hh = __builtin_bit_cast(u32x2h, c.h);
+            c.v = make_float4(c.v.x - unpk16_lo<true>(hh[0]), c.v.y - unpk16_hi<true>(hh[0]), c.v.z - unpk16_lo<true>(hh[1]), c.v.w - unpk16_hi<true>(hh[1]));
+        } else c.v = make_float4(c.v.x - (float)c.h[0], c.v.y - (float)c.h[1], c.v.z - (float)c.h[2], c.v.w - (float)c.h[3]);
     };
     auto convert_6 = [&](Cv& c, int q, unsigned wbase) {      // lo parts + the two 8-byte stores; wbase = footprint base + wofs
         bf16x4 l;
+        if constexpr (F16) {
+            u32x2h ll;
+            ll[0] = cvt_pk16<true>(c.v.x, c.v.y); ll[1] = cvt_pk16<true>(c.v.z, c.v.w);
+            l = __builtin_bit_cast(bf16x4, ll);
+        } else {
         l[0] = (__bf16)c.v.x; l[1] = (__bf16)c.v.y; l[2] = (__bf16)c.v.z; l[3] = (__bf16)c.v.w;
+        }
         const unsigned a = wbase + (unsigned)(wsgn * (int)((fm[q] >> 1) & 1u));
         // the last slice is half a slice (32 pixels = the threads of waves 0 and 1): a wave-uniform (scalar) branch
         static_assert(WQ_PIX % 64 == 0 || WQ_PIX % 64 == 32, "");
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
                                                      // on; the last tap's (read in front of the block's barrier) has a set of its own
     const unsigned wstep2 = (unsigned)(2 * p.W * WQ_ROW);       // two filter rows down
     auto mfma = [&](const bf16x8& a, const bf16x8& b, const floatx16& c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        return mfma_x3<F16>(a, b, c);
     };
 
     // accumulators: acc<tile><row block><column block>, named (arrays passed by reference end up in scratch)
@@ -306,9 +318,9 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq_kernel(const ConvArgs p) {
         asm volatile("" : "+v"(e_x));
     };
     auto epi_s = [&]() {                             // x = hi + lo, as the consumers split an f32 input (conv_common.h split4)
-        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(e_h) : "v"(e_x));
-        const float r = e_x - __uint_as_float(e_h << 16);
-        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(e_l) : "v"(r));
+        e_h = cvt_pk16<F16>(e_x, e_x);
+        const float r = e_x - unpk16_lo<F16>(e_h);
+        e_l = cvt_pk16<F16>(r, r);
     };
     auto epih_c = [&](int rb, int cb, int g, unsigned vb) {
         // (the unit's pixel offset rides in the instruction's immediate field, the plane in the scalar offset: E_INVALID + 480 is

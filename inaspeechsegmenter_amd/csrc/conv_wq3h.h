@@ -30,7 +30,7 @@ constexpr int wqh_lds_bytes() { return WQH_NSLOT * WQH_SLOT + 2 * WQH_FB + 512 +
 #define ISS_WQH_EXP 0
 #endif
 
-template <int KIND, bool OUT_HL>
+template <int KIND, bool OUT_HL, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) {
     constexpr bool X_NOEPI = ISS_WQH_EXP & 4, X_NODMA = ISS_WQH_EXP & 128, X_NOADMA = ISS_WQH_EXP & 1, X_NOBAR = ISS_WQH_EXP & 2, X_NOFLAG = ISS_WQH_EXP & 16;      // timing-only experiment builds
     constexpr int KH = 3, KW = 3, NT = 9, G = 2;
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
     struct AFr { bf16x8 h, l; };
     const unsigned wstep = (unsigned)(p.W * 16);     // one filter row down
     auto mfma = [&](const bf16x8& a, const bf16x8& b, const floatx16& c) {
-        if (TR) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        if (TR) return mfma_x3<F16>(b, a, c);
+        return mfma_x3<F16>(a, b, c);
     };
 
     // accumulators: acc<tile><row block><column block>
@@ -175,18 +175,18 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
     // OUT_HL: x = hi + lo per value, as the consumers split an f32 input (conv_common.h split4).  Written out: hipcc converts the
     // hi parts twice and SLP-packs the residuals into v_pk_add_f32 (an anti-lever beside MFMAs, MI355X_MICROARCH.md): 12 VALU per unit
     unsigned e_h01 = 0, e_h23 = 0, e_l01 = 0, e_l23 = 0;
-    auto cvt_pk = [&](float a, float b) { unsigned r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+    auto cvt_pk = [&](float a, float b) { return cvt_pk16<F16>(a, b); };
     auto epi0_h = [&]() {                            // hi parts; residuals of the first pair
         e_h01 = cvt_pk(e_v.x, e_v.y); e_h23 = cvt_pk(e_v.z, e_v.w);
-        e_v.x = e_v.x - __uint_as_float(e_h01 << 16);
+        e_v.x = e_v.x - unpk16_lo<F16>(e_h01);
         asm volatile("" : "+v"(e_v.x));
-        e_v.y = e_v.y - __uint_as_float(e_h01 & 0xffff0000u);
+        e_v.y = e_v.y - unpk16_hi<F16>(e_h01);
         asm volatile("" : "+v"(e_v.y));
     };
     auto epi0_l = [&]() {                            // residuals of the second pair; lo parts
-        e_v.z = e_v.z - __uint_as_float(e_h23 << 16);
+        e_v.z = e_v.z - unpk16_lo<F16>(e_h23);
         asm volatile("" : "+v"(e_v.z));
-        e_v.w = e_v.w - __uint_as_float(e_h23 & 0xffff0000u);
+        e_v.w = e_v.w - unpk16_hi<F16>(e_h23);
         asm volatile("" : "+v"(e_v.w));
         e_l01 = cvt_pk(e_v.x, e_v.y); e_l23 = cvt_pk(e_v.z, e_v.w);
     };

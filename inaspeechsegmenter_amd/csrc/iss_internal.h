@@ -23,6 +23,9 @@ struct IssNet {
     float* d_blob = nullptr;              // parameters (conv weights [Cout][Kpad])
     uint16_t* d_wh = nullptr;             // bf16 hi part of every blob element (same offsets)
     uint16_t* d_wl = nullptr;             // bf16 lo part
+    uint16_t* d_wh16 = nullptr;           // fp16 hi / lo parts (ISS_PREC_F16X3)
+    uint16_t* d_wl16 = nullptr;
+    bool f16_ok = false;                  // every parameter is inside fp16's range
     float* d_wsum = nullptr;              // patch-mode first layers: sum_k w[c][k] per output channel (shared first layer)
     std::vector<int64_t> wsum_off;        // per row: offset into d_wsum, -1 = none
     std::vector<int64_t> wsumx_off;       // per row: offset of S[W][Cout] (zero-padded first layers: per-column weight sums), -1 = none
@@ -39,7 +42,8 @@ struct IssNet {
     // precision guard (iss_set_precision_guard / iss_cnn_precision_info)
     int prec_override = -1;               // -1: the context's mode; else ISS_PREC_* for this network only
     int guard_state = 0;                  // ISS_GUARD_*
-    float guard_dlogp = -1.f;             // max |log p(split bf16) - log p(exact f32)| of the probe, -1 = never probed
+    float guard_dlogp = -1.f;             // max |log p(mode asked for) - log p(exact f32)| of the probe, -1 = never probed
+    float guard_dlogp_chosen = -1.f;      // the same figure for the mode the network runs in after the probe
     int guard_slots = 0;                  // windows the probe compared
 };
 
@@ -69,7 +73,7 @@ struct iss_ctx {
     // CNN engine
     IssNet nets[ISS_MAX_NETS];
     uint64_t ws_limit = 12ull << 30;
-    int precision = ISS_PREC_BF16X3;
+    int precision = ISS_PREC_F16X3;
     float guard_threshold = 5e-4f;        // precision guard: escalate a patch network to exact f32 above this max |d log p| (<= 0: guard off)
     bool in_guard = false;
     uint32_t diag = 0;                    // ISS_DIAG_* kernel-selection switches (iss_set_diag; 0 in production)

@@ -168,31 +168,40 @@ int iss_wait(iss_ctx* ctx, int64_t ticket);
  * of resnet.py:78-135, one launch sequence for many windows instead of batch 1).  */
 int iss_cnn_forward(iss_ctx* ctx, int net_id, const float* x, int32_t n, float* out /* n*out_dim */);
 
-/* Arithmetic mode of the conv/dense GEMMs (default ISS_PREC_BF16X3):
- *   ISS_PREC_BF16X3  both operands split into bf16 hi+lo, three v_mfma_f32_32x32x16_bf16 per k-step,
- *                    f32 accumulate: operand error 2^-16 relative (float32-class results, measured
- *                    <= 1e-5 on probabilities), 16/3 x the f32-MFMA rate;
- *   ISS_PREC_F32     v_mfma_f32_32x32x2_f32, bit-wise an fmaf chain (reference-grade, slower).        */
+/* Arithmetic mode of the conv/dense GEMMs.  gfx950 has no xf32 / TF32 and its f32-input MFMA runs at 1/16 of the 16-bit rate, so
+ * both operands are split x = hi + lo into 16-bit halves and every k-step issues three MFMAs (lo.hi + hi.lo + hi.hi, f32 accumulate):
+ *   ISS_PREC_F16X3   (default since round 6) fp16 halves, 11 + 11 mantissa bits, v_mfma_f32_32x32x16_f16, in the kernels that carry the
+ *                    segmenter nets' arithmetic (conv_x3_wq_kernel, conv_x3_wq3h_kernel, conv_x3_pw_kernel); exact f32 for their
+ *                    small trailing layers; bf16 halves in every kernel without an fp16 instantiation.  Needs parameters and
+ *                    activations inside fp16's range (|x| < 65504): parameters are checked at load (a network with a larger one
+ *                    runs ISS_PREC_BF16X3), activations by the precision guard's probe.  max |d log p| against exact f32 on the
+ *                    stand-ins: 4.7e-5 (profiles/r06_f16_ab.txt), the speed of ISS_PREC_BF16X3 within 1 %;
+ *   ISS_PREC_BF16X3  bf16 halves, 8 + 8 mantissa bits, v_mfma_f32_32x32x16_bf16, in every GEMM kernel: operand error 2^-16 relative,
+ *                    max |d log p| 2.9e-4 on the same data (the default of rounds 1-5);
+ *   ISS_PREC_F32     v_mfma_f32_32x32x2_f32, bit-wise an fmaf chain (reference-grade, ~3 x slower).                          */
 #define ISS_PREC_BF16X3 0
 #define ISS_PREC_F32    1
+#define ISS_PREC_F16X3  2
 int iss_set_precision(iss_ctx* ctx, int mode);
 
 /* Precision guard for weights nobody has measured (north star: "frame logits within 1e-3 fp32"; segmenter.py:163,176 --
- * the reference's emissions are log(predict(...)) in f32).  The default arithmetic (ISS_PREC_BF16X3) sits 2.5-3.7x inside that
- * bound on the stand-in networks (profiles/r06_precision_emulation.txt); whether it does on the weights actually loaded depends on
- * their activation ranges.  So the FIRST iss_cnn_probs / iss_cnn_probs_async call of a patch network in split-bf16 mode first runs
- * up to 256 of the call's own windows (four runs of consecutive slots spread over the list) in both modes, records
- * max |log p_bf16x3 - log p_f32| over every class of every finite window, and -- when that exceeds `threshold` (default 5e-4,
- * half the bound) -- switches THIS network to ISS_PREC_F32 for the rest of its life (slower, reference-grade).
+ * the reference's emissions are log(predict(...)) in f32).  How far inside that bound a split mode sits depends on the activation
+ * ranges of the weights actually loaded (tests/precision_emulation.py, profiles/r06_precision_emulation.txt).  So the FIRST
+ * iss_cnn_probs / iss_cnn_probs_async call of a patch network in a split mode first runs up to 256 of the call's own windows
+ * (four runs of consecutive slots spread over the list) in that mode and in exact f32, records max |log p_split - log p_f32| over
+ * every class of every finite window, and -- when that exceeds `threshold` (default 5e-4, half the bound; a NaN, i.e. an activation
+ * beyond fp16's range, always does) -- switches THIS network for the rest of its life: to the other split mode if that one passes
+ * the same probe (the same speed), else to ISS_PREC_F32.
  * iss_set_precision_guard: threshold <= 0 disables the probe (networks loaded later are not probed; already decided ones keep their mode).
- * iss_cnn_precision_info: mode in use for the network (ISS_PREC_*), the probe's figure (-1 if not probed), the windows it compared,
- * ISS_GUARD_* state.  iss_cnn_set_net_precision: caller's override for one network (-1 = follow the context again); marks it decided. */
+ * iss_cnn_precision_info: mode in use for the network (ISS_PREC_*), the probe's figure for the mode that was asked for (-1 if not
+ * probed), the windows it compared, ISS_GUARD_* state, and the figure of the mode in use (0 for exact f32).
+ * iss_cnn_set_net_precision: caller's override for one network (-1 = follow the context again); marks it decided. */
 #define ISS_GUARD_PENDING   0   /* not probed yet                                              */
-#define ISS_GUARD_PASSED    1   /* probed: within the threshold, split-bf16 kept               */
-#define ISS_GUARD_ESCALATED 2   /* probed: above the threshold, the network now runs exact f32 */
+#define ISS_GUARD_PASSED    1   /* probed: within the threshold, mode kept                     */
+#define ISS_GUARD_ESCALATED 2   /* probed: above the threshold, the network runs another mode  */
 #define ISS_GUARD_FIXED     3   /* mode set by the caller (iss_cnn_set_net_precision) or the context is in exact-f32 mode anyway */
 int iss_set_precision_guard(iss_ctx* ctx, float threshold);
-int iss_cnn_precision_info(iss_ctx* ctx, int id, int32_t* mode, float* max_dlogp, int32_t* slots, int32_t* state);
+int iss_cnn_precision_info(iss_ctx* ctx, int id, int32_t* mode, float* max_dlogp, int32_t* slots, int32_t* state, float* dlogp_in_use);
 int iss_cnn_set_net_precision(iss_ctx* ctx, int id, int mode);
 
 /* Kernel-selection switches for same-box A/B measurements and for the tests that compare two device paths with each

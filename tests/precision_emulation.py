@@ -41,9 +41,16 @@ def split(x, kind):
     return h, l
 
 
+def _same_pad(size, k, s):
+    """Keras 'same': total = max((ceil(size / s) - 1) * s + k - size, 0), the smaller half in front."""
+    total = max((-(-size // s) - 1) * s + k - size, 0)
+    return total // 2, total - total // 2
+
+
 def fold(layers):
-    """conv/dense + following batchnorm (+ activation) -> [(kind, W f32, b f32, act, pool)] the way keras_model folds them
-    (BatchNorm in float64 into the weights when it follows the linear op directly)."""
+    """conv / dense + a DIRECTLY following batchnorm (+ activation) -> one linear op the way keras_model folds them (BatchNorm
+    in float64 into the weights); every other layer is kept as it is (a BatchNorm behind an activation stays an affine map,
+    pools, flatten, dropout, activations)."""
     out = []
     i = 0
     while i < len(layers):
@@ -60,17 +67,15 @@ def fold(layers):
                 W = W * sc
                 b = (b - B['mean']) * sc + B['beta']
                 j += 1
-            if act == 'linear' and j < len(layers) and layers[j]['type'] == 'activation':
+            if act == 'linear' and j < len(layers) and layers[j]['type'] == 'activation' and layers[j]['fn'] in ('relu', 'softmax'):
                 act = layers[j]['fn']
                 j += 1
             out.append(dict(type=ty, W=W.astype(np.float32), b=b.astype(np.float32), act=act,
                             strides=L.get('strides', (1, 1)), padding=L.get('padding', 'valid')))
             i = j
-        elif ty in ('maxpool', 'flatten', 'dropout'):
+        else:
             out.append(L)
             i += 1
-        else:
-            raise ValueError(ty)
     return out
 
 
@@ -84,24 +89,33 @@ def forward_mode(folded, x, mode, batch=256):
         for s in range(0, len(x), batch):
             t = torch.from_numpy(np.ascontiguousarray(x[s:s + batch])).to(torch.float64).permute(0, 3, 1, 2)
             first = True
-            flat = False
-            for L in folded:
+            lin = [i for i, L_ in enumerate(folded) if L_['type'] in ('conv2d', 'dense')]
+            exact_here = False
+            for li_, L in enumerate(folded):
                 ty = L['type']
+                # 'f16x3_tail<k>bf16': f16 splits everywhere except the last k linear layers (bf16 splits there)
+                if mode.startswith('f16x3_tail'):
+                    kind = 'bf16' if li_ in lin[len(lin) - int(mode[10:-4]):] else 'f16'
+                # '<kind>x3_last<k>f32': the last k linear layers in exact f32 (conv_igemm_kernel), the split arithmetic in front of them
+                exact_here = '_last' in mode and li_ in lin[len(lin) - int(mode.split('_last')[1][:-3]):]
                 if ty in ('conv2d', 'dense'):
                     w = torch.from_numpy(L['W']).to(torch.float64)
                     b = torch.from_numpy(L['b']).to(torch.float64)
                     a32 = t.to(torch.float32).to(torch.float64)          # activations are stored as f32 between layers
+                    if ty == 'conv2d' and L['padding'] == 'same':
+                        (pt, pb), (pl, pr) = _same_pad(a32.shape[2], w.shape[0], L['strides'][0]), _same_pad(a32.shape[3], w.shape[1], L['strides'][1])
+                        a32 = F.pad(a32, (pl, pr, pt, pb))
 
                     def op(a, w_):
                         if ty == 'conv2d':
                             return F.conv2d(a, w_.permute(3, 2, 0, 1), None, stride=tuple(L['strides']))
                         return a @ w_
-                    if first or mode == 'f32':
+                    if first or mode == 'f32' or exact_here:
                         y = op(a32, w)
                     else:
                         ah, al = split(a32, kind)
                         wh, wl = split(w, kind)
-                        if mode.endswith('x3'):
+                        if mode.endswith('x3') or mode.startswith('f16x3_tail') or '_last' in mode:
                             y = op(ah, wh) + op(al, wh) + op(ah, wl)
                         elif mode.endswith('x2_w'):
                             y = op(ah + al, wh)
@@ -115,15 +129,30 @@ def forward_mode(folded, x, mode, batch=256):
                     y = y + (b[None, :, None, None] if ty == 'conv2d' else b)
                     if L['act'] == 'relu':
                         y = torch.relu(y)
-                    elif L['act'] == 'softmax':
-                        pass                                          # logits out
-                    elif L['act'] != 'linear':
+                    elif L['act'] not in ('linear', 'softmax'):              # ('softmax': logits out)
                         raise ValueError(L['act'])
                     t = y
-                elif ty == 'maxpool':
-                    t = F.max_pool2d(t, tuple(L['pool']), tuple(L.get('strides') or L['pool']))
+                elif ty in ('maxpool', 'avgpool'):
+                    ph, pw = L['pool']
+                    sh, sw = L.get('strides') or L['pool']
+                    if L.get('padding', 'valid') == 'same':
+                        raise ValueError('padded pools are not emulated')
+                    t = F.max_pool2d(t, (ph, pw), (sh, sw)) if ty == 'maxpool' else F.avg_pool2d(t, (ph, pw), (sh, sw))
+                elif ty == 'globalavgpool':
+                    t = t.mean((2, 3))
                 elif ty == 'flatten':
-                    t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1); flat = True
+                    t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1)
+                elif ty == 'batchnorm':
+                    sc = torch.from_numpy(L['gamma'].astype(np.float64) / np.sqrt(L['var'].astype(np.float64) + L['eps']))
+                    sh_ = torch.from_numpy(L['beta'].astype(np.float64) - L['mean'].astype(np.float64) * sc.numpy())
+                    t = t * (sc[None, :, None, None] if t.dim() == 4 else sc) + (sh_[None, :, None, None] if t.dim() == 4 else sh_)
+                elif ty == 'activation':
+                    if L['fn'] == 'relu':
+                        t = torch.relu(t)
+                    elif L['fn'] != 'softmax':
+                        raise ValueError(L['fn'])
+                elif ty != 'dropout':
+                    raise ValueError(ty)
             outs.append(t.numpy())
     return np.concatenate(outs)
 
@@ -138,6 +167,8 @@ def main():
     ap.add_argument('--seconds', type=int, default=90, help='seconds of the bench generator recording')
     ap.add_argument('--modes', default='bf16x3,bf16x2_w,bf16x2_a,f16x3,f16x2_a,f16x2_w,f16x1')
     ap.add_argument('--out', default=None)
+    ap.add_argument('--topologies', default='', help="'all' or a comma-separated list of tests/topologies.py names: their nets instead of the stand-ins, "
+                                                      "on the generator recording only")
     args = ap.parse_args()
     import torch
     torch.set_num_threads(os.cpu_count() or 1)
@@ -153,10 +184,20 @@ def main():
     mus = np.frombuffer(w.readframes(w.getnframes()), np.int16)
     srcs['musanmix'] = (mus / 32768.0).astype(np.float32)
     nets = {'smn': KM.synthetic_ina_like(21, 3, 1)[0], 'gender': KM.synthetic_ina_like(24, 2, 2)[0]}
+    if args.topologies:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import topologies as TP
+        names = list(TP.SPECS) if args.topologies == 'all' else args.topologies.split(',')
+        nets = {}
+        for nm in names:
+            two = TP.nets(nm)
+            nets[nm + ':smn'] = two['vad'][0]
+            nets[nm + ':gender'] = two['gender'][0]
+        srcs.pop('musanmix')
     for sname, sig in srcs.items():
         mspec, loge, difflen = osk.media2feats(sig)
         for nname, layers in nets.items():
-            nmel = 21 if nname == 'smn' else 24
+            nmel = 21 if nname.endswith('smn') else 24
             patches, finite = oseg.get_patches(mspec[:, :nmel].copy(), 68, 2)
             x = patches[finite][:, :, :, None].astype(np.float32)
             folded = fold(layers)
@@ -171,7 +212,7 @@ def main():
                          max_dp=float(np.abs(np.exp(lp) - np.exp(ref)).max()), argmax_mismatch=int(mism.sum()),
                          min_margin_all=float(margin.min()))
                 res[f'{sname}/{nname}/{mode}'] = r
-                print(f'{sname:10s} {nname:7s} {mode:9s} max|dlogp| {r["max_dlogp"]:.2e}  p99.9 {r["p999_dlogp"]:.2e}  '
+                print(f'{sname:10s} {nname:32s} {mode:9s} max|dlogp| {r["max_dlogp"]:.2e}  p99.9 {r["p999_dlogp"]:.2e}  '
                       f'max|dp| {r["max_dp"]:.2e}  argmax mismatches {r["argmax_mismatch"]} / {len(x)}', flush=True)
     if args.out:
         json.dump(res, open(args.out, 'w'), indent=1)

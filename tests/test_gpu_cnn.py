@@ -441,7 +441,7 @@ def test_exact_f32_mode_takes_the_weight_stationary_kernels(ctx, net, nmel, ncls
 def test_precision_guard_escalates_a_net_with_inflated_activation_range(ctx):
     """Round 6 (include/iss.h, iss_set_precision_guard): the first iss_cnn_probs call of a patch network in split-bf16 mode compares
     both arithmetic modes on up to 256 of its own windows.  The calibrated stand-in passes (max |d log p| a few 1e-4 at most, mode
-    kept); the same network with its last two layers scaled so that its logits are ~30 x larger -- what confident real weights
+    kept); the same network with its last two layers scaled so that its logits are ~6 x larger -- what confident real weights
     look like -- trips the 5e-4 threshold, is switched to exact f32 by the library, and its results then sit within the north
     star's 1e-3 of the oracle's log-probabilities, which the split-bf16 results (guard off) do not."""
     import bench
@@ -464,8 +464,8 @@ def test_precision_guard_escalates_a_net_with_inflated_activation_range(ctx):
 
     hot = [dict(L) for L in layers]
     for i in (-2, -1):                                                   # dense(192, 128, relu), dense(128, ncls, softmax)
-        hot[i]['W'] = (hot[i]['W'] * 5.5).astype(np.float32)
-        hot[i]['b'] = (hot[i]['b'] * 5.5).astype(np.float32)
+        hot[i]['W'] = (hot[i]['W'] * 2.5).astype(np.float32)
+        hot[i]['b'] = (hot[i]['b'] * 2.5).astype(np.float32)
     ref, fin = _oracle_probs(hot, mspec, nmel, rows)
     ok = fin[:, None] & (ref > 1e-30)
 
@@ -487,10 +487,25 @@ def test_precision_guard_escalates_a_net_with_inflated_activation_range(ctx):
     ctx.prof_enable(False)
     info = ctx.cnn_precision_info(3)
     print('inflated:', info, 'split-bf16 max |d log p| vs oracle', dlogp(p_x3), 'guarded', dlogp(p_g))
-    assert info['state'] == 'escalated' and info['mode'] == 'f32' and info['max_dlogp'] > 5e-4, info
+    # split bf16 fails the probe; fp16 halves (the same speed) pass it: that is the mode the network now runs in
+    assert info['state'] == 'escalated' and info['mode'] == 'f16x3' and info['max_dlogp'] > 5e-4, info
+    used = {e['kernel'] for e in ctx.prof_instances()}
+    assert any(k.endswith('f16>') for k in used), used
     assert np.array_equal(f_g, fin)
     assert dlogp(p_g) < 1e-3, dlogp(p_g)
-    assert dlogp(p_x3) > dlogp(p_g)
+    assert dlogp(p_x3) > 1e-3 and dlogp(p_x3) > 3 * dlogp(p_g) and info['max_dlogp_in_use'] < 5e-4
+    # a threshold neither split mode meets: exact f32
+    ctx.set_precision_guard(2e-6)
+    ctx.cnn_load(3, KM.compile_layers(hot, shp))
+    p_e, _ = ctx.cnn_probs(3, rows)
+    ctx.set_precision_guard(5e-4)
+    info_e = ctx.cnn_precision_info(3)
+    print('threshold 2e-6:', info_e, 'max |d log p| vs oracle', dlogp(p_e))
+    assert info_e['state'] == 'escalated' and info_e['mode'] == 'f32', info_e
+    assert dlogp(p_e) < 1e-3
+    ctx.cnn_load(3, KM.compile_layers(hot, shp))
+    p_g2, _ = ctx.cnn_probs(3, rows)
+    assert np.array_equal(p_g2, p_g)
     p_again, _ = ctx.cnn_probs(3, rows)                                  # decided once: no second probe, same arithmetic
     assert np.array_equal(p_again, p_g) and ctx.cnn_precision_info(3)['slots'] == info['slots']
     # the caller's own choice wins and is never probed
@@ -499,3 +514,41 @@ def test_precision_guard_escalates_a_net_with_inflated_activation_range(ctx):
     p_fix, _ = ctx.cnn_probs(3, rows)
     assert ctx.cnn_precision_info(3)['state'] == 'fixed' and np.array_equal(p_fix, p_x3)
     ctx.set_precision_guard(0)
+
+
+@pytest.mark.parametrize('net,nmel,ncls', [('smn', 21, 3), ('gender', 24, 2)])
+def test_f16x3_mode(ctx, net, nmel, ncls):
+    """ISS_PREC_F16X3 (round 6): fp16 instead of bf16 operand halves in the kernels that carry the arithmetic (conv2 with its CHL
+    output, conv3 / conv4 on it, the long-K dense layer), exact f32 for the small trailing layers.  On the calibrated stand-ins
+    over the bench generator's audio: the same windows, finite masks and arg-max as the oracle, and the log-probabilities several
+    times closer to it than the split-bf16 default's (tests/precision_emulation.py: 10-15 x less operand error)."""
+    import bench
+    pcm = bench.synth_recording(1, 60 * 16000, 'cpu').numpy()
+    ctx.set_signal(pcm)
+    T = ctx.sidekit()
+    mspec = ctx.get_mspec()
+    rows = S._window_rows(T)
+    layers, shp = KM.synthetic_ina_like(nmel, ncls, seed=1 if net == 'smn' else 2)
+    ctx.cnn_load(3, KM.compile_layers(layers, shp))
+    ref, rfin = _oracle_probs(layers, mspec, nmel, rows)
+    p_b, f_b = ctx.cnn_probs(3, rows)
+    ctx.set_precision(_native.PREC_F16X3)
+    try:
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        p_h, f_h = ctx.cnn_probs(3, rows)
+        used = sorted({e['kernel'] for e in ctx.prof_instances()})
+        ctx.prof_enable(False)
+    finally:
+        ctx.set_precision(_native.PREC_BF16X3)
+    assert np.array_equal(f_h, rfin) and np.array_equal(f_b, rfin)
+    ok = rfin[:, None] & (ref > 1e-30)
+
+    def dlogp(p):
+        with np.errstate(divide='ignore'):
+            return np.abs(np.log(p.astype(np.float64)) - np.log(ref.astype(np.float64)))[ok & (p > 1e-30)].max()
+    print(f'{net}: max |d log p| vs oracle: bf16x3 {dlogp(p_b):.2e}, f16x3 {dlogp(p_h):.2e}; kernels {used}')
+    assert sum(k.endswith('f16>') for k in used) >= 4, used                  # conv2, conv3, conv4, dense
+    assert any(k.startswith('conv_igemm_kernel') for k in used), used        # the small trailing layers: exact f32
+    assert np.abs(p_h - ref).max() < 1e-4 and np.array_equal(p_h.argmax(1)[rfin], ref.argmax(1)[rfin])
+    assert dlogp(p_h) < 1e-4 and dlogp(p_h) < 0.5 * dlogp(p_b)
