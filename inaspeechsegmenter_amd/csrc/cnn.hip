@@ -906,10 +906,12 @@ __global__ void pool_kernel(const float* __restrict__ in, float* __restrict__ ou
 }
 
 
-// Elementwise activations that are not fused into a producer's epilogue (ISS_OP_ACT): elu, leaky relu, selu, softplus.  One thread per
-// 4 elements (the tail scalar), grid-stride; in place when in == out.
-__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ in, float* __restrict__ out, long long total, int act, float alpha) {
+// Elementwise activations that are not fused into a producer's epilogue (ISS_OP_ACT): elu, leaky relu, selu, softplus, clipped relu.
+// One thread per 4 elements (the tail scalar), grid-stride; in place when in == out -- the op program's rows are, so the pointers are
+// NOT __restrict__ (iss_cnn_load refuses an ISS_OP_ACT row that reads the network input).
+__global__ __launch_bounds__(256) void act_kernel(const float* in, float* out, long long total, int act, float alpha) {
     auto f = [&](float v) {
+        if (act == 8) return fminf(fmaxf(v, 0.f), alpha);                                // keras.layers.ReLU(max_value = alpha)
         if (act == 4) return v > 0.f ? v : alpha * (expf(v) - 1.f);                       // keras.activations.elu
         if (act == 5) return v > 0.f ? v : alpha * v;                                    // keras.layers.LeakyReLU
         if (act == 6) return 1.05070098f * (v > 0.f ? v : 1.67326324f * (expf(v) - 1.f)); // selu
@@ -1077,7 +1079,8 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
                                "or the concatenated parameters lie outside the blob (include/iss.h)");
             }
         } else if (R[ISS_C_OP] == ISS_OP_ACT) {
-            if (R[ISS_C_ACT] < 4 || R[ISS_C_ACT] > 7) return bad("ISS_OP_ACT: activation code must be 4 (elu), 5 (leaky relu), 6 (selu) or 7 (softplus)");
+            if (R[ISS_C_ACT] < 4 || R[ISS_C_ACT] > 8) return bad("ISS_OP_ACT: activation code must be 4 (elu), 5 (leaky relu), 6 (selu), 7 (softplus) or 8 (relu with max_value)");
+            if (R[ISS_C_IN] == ISS_BUF_INPUT) return bad("ISS_OP_ACT: an elementwise activation cannot read the network input (it works in place)");
         } else if (R[ISS_C_OP] != ISS_OP_POOL && R[ISS_C_OP] != ISS_OP_SOFTMAX && R[ISS_C_OP] != ISS_OP_STATPOOL) {
             return bad("unknown op");
         }

@@ -25,7 +25,7 @@ import numpy as np
 from . import _native as N
 
 _ACT_CODE = {None: 0, 'linear': 0, 'relu': 1, 'sigmoid': 2, 'tanh': 3}                 # fused into a conv / dense epilogue
-_ACT_OP_CODE = {'elu': 4, 'leaky_relu': 5, 'selu': 6, 'softplus': 7}                   # their own elementwise op (ISS_OP_ACT)
+_ACT_OP_CODE = {'elu': 4, 'leaky_relu': 5, 'selu': 6, 'softplus': 7, 'relu_max': 8}    # their own elementwise op (ISS_OP_ACT)
 _ACT_DEFAULT_ALPHA = {'elu': 1.0, 'leaky_relu': 0.3}      # keras.activations.elu / keras.layers.LeakyReLU defaults
 
 
@@ -43,6 +43,12 @@ class CompiledNet:
 # ------------------------------------------------------------------------------ Keras parsing
 def _pair(v):
     return (int(v), int(v)) if np.isscalar(v) else (int(v[0]), int(v[1]))
+
+
+def _string_act_alpha(fn):
+    """The activation STRING 'leaky_relu' (`Activation('leaky_relu')`, `Conv2D(activation='leaky_relu')`) is
+    keras.activations.leaky_relu, whose negative_slope defaults to 0.2; only the LeakyReLU LAYER defaults to 0.3."""
+    return {'alpha': 0.2} if fn == 'leaky_relu' else {}
 
 
 def layers_from_keras_config(model_config, weights):
@@ -88,16 +94,32 @@ def layers_from_keras_config(model_config, weights):
         if cn in ('Conv2D', 'Convolution2D'):
             if c.get('data_format', 'channels_last') != 'channels_last':
                 raise NotImplementedError('channels_first Conv2D')
-            if _pair(c.get('dilation_rate', 1)) != (1, 1):
-                raise NotImplementedError('dilated Conv2D')
             layers.append(dict(type='conv2d', name=name, W=np.asarray(w['kernel'], np.float32),
                                b=np.asarray(w['bias'], np.float32) if c.get('use_bias', True) else None,
                                strides=_pair(c.get('strides', 1)), padding=c.get('padding', 'valid'),
-                               activation=c.get('activation', 'linear')))
+                               activation=c.get('activation', 'linear'), dilation=_pair(c.get('dilation_rate', 1)),
+                               **_string_act_alpha(c.get('activation'))))
+        elif cn in ('DepthwiseConv2D', 'SeparableConv2D'):
+            # no kernel of their own: lowered as ordinary convolutions on zero-filled kernels (expand_generic_layers) -- slow
+            # for wide layers, but a model_config that uses them loads and computes what Keras computes
+            if c.get('data_format', 'channels_last') != 'channels_last':
+                raise NotImplementedError(f'channels_first {cn}')
+            dk = np.asarray(w['depthwise_kernel'], np.float32)
+            sep = cn == 'SeparableConv2D'
+            layers.append(dict(type='depthwise', name=name + ('/depthwise' if sep else ''), W=dk,
+                               b=None if sep or not c.get('use_bias', True) else np.asarray(w['bias'], np.float32),
+                               strides=_pair(c.get('strides', 1)), padding=c.get('padding', 'valid'),
+                               activation='linear' if sep else c.get('activation', 'linear'), dilation=_pair(c.get('dilation_rate', 1)),
+                               **({} if sep else _string_act_alpha(c.get('activation')))))
+            if sep:
+                layers.append(dict(type='conv2d', name=name + '/pointwise', W=np.asarray(w['pointwise_kernel'], np.float32),
+                                   b=np.asarray(w['bias'], np.float32) if c.get('use_bias', True) else None,
+                                   strides=(1, 1), padding='valid', activation=c.get('activation', 'linear'), dilation=(1, 1),
+                                   **_string_act_alpha(c.get('activation'))))
         elif cn == 'Dense':
             layers.append(dict(type='dense', name=name, W=np.asarray(w['kernel'], np.float32),
                                b=np.asarray(w['bias'], np.float32) if c.get('use_bias', True) else None,
-                               activation=c.get('activation', 'linear')))
+                               activation=c.get('activation', 'linear'), **_string_act_alpha(c.get('activation'))))
         elif cn == 'BatchNormalization':
             axis = c.get('axis', -1)
             axis = axis[0] if isinstance(axis, (list, tuple)) else axis
@@ -110,13 +132,16 @@ def layers_from_keras_config(model_config, weights):
                                mean=np.asarray(w['moving_mean'], np.float32),
                                var=np.asarray(w['moving_variance'], np.float32), eps=float(c.get('epsilon', 1e-3))))
         elif cn == 'Activation':
-            layers.append(dict(type='activation', name=name, fn=c['activation']))
+            layers.append(dict(type='activation', name=name, fn=c['activation'], **_string_act_alpha(c['activation'])))
         elif cn == 'ReLU':
-            if c.get('max_value') is not None or float(c.get('threshold', 0.0) or 0.0) != 0.0:
-                raise NotImplementedError('ReLU with max_value / threshold')
             slope = float(c.get('negative_slope', 0.0) or 0.0)
-            layers.append(dict(type='activation', name=name, fn='relu') if slope == 0.0 else
-                          dict(type='activation', name=name, fn='leaky_relu', alpha=slope))
+            if float(c.get('threshold', 0.0) or 0.0) != 0.0 or (c.get('max_value') is not None and slope != 0.0):
+                raise NotImplementedError('ReLU with a threshold, or with max_value and negative_slope together')
+            if c.get('max_value') is not None:             # min(max(x, 0), max_value): its own elementwise op
+                layers.append(dict(type='activation', name=name, fn='relu_max', alpha=float(c['max_value'])))
+            else:
+                layers.append(dict(type='activation', name=name, fn='relu') if slope == 0.0 else
+                              dict(type='activation', name=name, fn='leaky_relu', alpha=slope))
         elif cn == 'LeakyReLU':
             layers.append(dict(type='activation', name=name, fn='leaky_relu',
                                alpha=float(c.get('alpha', c.get('negative_slope', 0.3)))))
@@ -371,6 +396,34 @@ def _can_fold_forward(layers, j, sc):
     return False
 
 
+def expand_generic_layers(layers):
+    """Layers the op program has no kernel for, re-expressed through the ones it has -- slower than a dedicated kernel would be,
+    but the same function (the reference's `keras.models.load_model`, segmenter.py:129-131, takes any model_config):
+      * dilated Conv2D: the kernel with dilation - 1 zeros between its taps, i.e. an ordinary ((kh-1) dy + 1) x ((kw-1) dx + 1) filter
+        (Keras pads 'same' for exactly that effective size);
+      * DepthwiseConv2D (and the depthwise half of SeparableConv2D): an ordinary convolution whose (cin, cin * multiplier) tap
+        matrices are zero except where output channel c * multiplier + m meets input channel c."""
+    out = []
+    for L in layers:
+        L = dict(L)
+        if L['type'] == 'depthwise':
+            kh, kw, cin, mult = L['W'].shape
+            W = np.zeros((kh, kw, cin, cin * mult), np.float32)
+            for c in range(cin):
+                W[:, :, c, c * mult:(c + 1) * mult] = L['W'][:, :, c, :]
+            L['type'], L['W'], L['alg_macs'] = 'conv2d', W, kh * kw * cin * mult
+        if L['type'] == 'conv2d' and tuple(L.get('dilation', (1, 1))) != (1, 1):
+            L.setdefault('alg_macs', int(np.prod(L['W'].shape)))
+            dy, dx = L['dilation']
+            kh, kw, cin, cout = L['W'].shape
+            W = np.zeros(((kh - 1) * dy + 1, (kw - 1) * dx + 1, cin, cout), np.float32)
+            W[::dy, ::dx] = L['W']
+            L['W'] = W
+        L.pop('dilation', None)
+        out.append(L)
+    return out
+
+
 def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_channels=True, fold_post_bn=True):
     """Lower a sequential layer list onto the op program.  Fusions: conv/dense + bias,
     + BatchNorm directly after (folded into W, b), + relu/sigmoid/tanh, + BatchNorm after the
@@ -387,6 +440,7 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
     that every conv / dense behind the first layer runs on the vectorised MFMA kernels (Cin % 32 == 0) instead of the
     scalar-gather path (only from 16 channels up: below that the padding would more than double the work); results are unchanged (the extra products are exact zeros) and `flops_per_sample` keeps counting
     the model's own MACs."""
+    layers = expand_generic_layers(layers)          # dilated / depthwise convolutions as ordinary ones on zero-filled kernels
     B = _Builder()
     shape = tuple(int(v) for v in in_shape)
     pmap = np.arange(shape[2])                      # physical channel -> logical channel of the current activation (-1 = padding)
@@ -477,7 +531,7 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
             # activation
             act_alpha = L.get('alpha') if ty in ('conv2d', 'dense') else None
             if act_name in (None, 'linear') and not softmax_after and j < n and layers[j]['type'] == 'activation' \
-                    and layers[j]['fn'] in ('relu', 'sigmoid', 'tanh', 'elu', 'leaky_relu', 'selu', 'softplus'):
+                    and layers[j]['fn'] in ('relu', 'sigmoid', 'tanh', 'elu', 'leaky_relu', 'selu', 'softplus', 'relu_max'):
                 act_name = layers[j]['fn']
                 act_alpha = layers[j].get('alpha')
                 j = peek(j + 1)
@@ -519,7 +573,7 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
                 raise ValueError(f"patch input must be (68, <=24, 1); got {shape}")
             # physical operand: input channels follow `pmap` (zero columns for padding channels); output channels are
             # padded when another conv / dense consumes them
-            alg_kc = Wm.shape[0] * Wm.shape[1]
+            alg_kc = L.get('alg_macs') or Wm.shape[0] * Wm.shape[1]      # (zero-filled generic kernels: the model's own MACs)
             cin_p = len(pmap)
             if cin_p != cin or np.any(pmap != np.arange(cin)):
                 W3 = Wm.reshape(cout, kh * kw, cin)

@@ -198,10 +198,10 @@ class _Worker:
             allrows = np.concatenate(rows)
             st['smooth_host'] += time.perf_counter() - t_; t_ = time.perf_counter()
             if dense:
-                probs, _fin = ctx.cnn_probs(net.net_id, allw)
+                probs, _fin = net.probs(ctx, allw)
                 probs = probs[np.concatenate(sel)]
             else:
-                probs, _fin = ctx.cnn_probs(net.net_id, allrows)
+                probs, _fin = net.probs(ctx, allrows)
             st['cnn_device'] += time.perf_counter() - t_; t_ = time.perf_counter()
             with np.errstate(divide='ignore'):
                 logp = np.log(probs)

@@ -18,6 +18,7 @@ import time
 import shutil
 import warnings
 
+import threading
 import numpy as np
 
 from . import _native
@@ -152,7 +153,38 @@ class DnnSegmenter:
 
     def predict_slots(self, win_rows):
         """(n,C) float32 probabilities (+ finite mask) for the given slots of the resident mspec."""
-        return self.ctx.cnn_probs(self.net_id, win_rows)
+        return self.probs(self.ctx, win_rows)
+
+    _MODES = {'bf16x3': _native.PREC_BF16X3, 'f32': _native.PREC_F32, 'f16x3': _native.PREC_F16X3}
+
+    def probs(self, ctx, win_rows, async_out=None):
+        """iss_cnn_probs (or, with async_out = (probs, finite) page-locked arrays, iss_cnn_probs_async) of this network on `ctx`.
+        The library's precision guard (include/iss.h) decides a network's arithmetic at its first call PER CONTEXT; the device
+        contexts of one Segmenter (its own and the pipeline workers') must not decide differently, so the first call anywhere
+        decides for all of them: it runs under a lock, and every other context is told the outcome before its first call."""
+        def run():
+            if async_out is None:
+                return ctx.cnn_probs(self.net_id, win_rows)
+            return ctx.cnn_probs_async(self.net_id, win_rows, *async_out)
+        st = self.__dict__.setdefault('_mode_state', {'lock': threading.Lock(), 'mode': None, 'told': set()})
+        if not hasattr(ctx, 'cnn_precision_info'):             # (a test double of the device context)
+            return run()
+        if st['mode'] is None:
+            with st['lock']:
+                if st['mode'] is None:
+                    out = run()
+                    info = ctx.cnn_precision_info(self.net_id)
+                    # 'pending' after a call = guard off: nothing to agree on
+                    st['mode'] = -1 if info['state'] == 'pending' else self._MODES[info['mode']]
+                    st['told'].add(id(ctx))
+                    return out
+        if st['mode'] >= 0 and id(ctx) not in st['told']:
+            with st['lock']:
+                if id(ctx) not in st['told']:
+                    if ctx.cnn_precision_info(self.net_id)['state'] == 'pending':
+                        ctx.cnn_set_net_precision(self.net_id, st['mode'])
+                    st['told'].add(id(ctx))
+        return run()
 
     def __call__(self, mspec, lseg, difflen=0, dense=False, ctx=None, allpred=None):
         """mspec: the RESIDENT mel spectrogram's frame count holder (`_Resident`) or a (T,24)
@@ -172,10 +204,10 @@ class DnnSegmenter:
             if allpred is not None:
                 rawpred = allpred[idx]
             elif dense:
-                allpred, _finite = ctx.cnn_probs(self.net_id, rows)
+                allpred, _finite = self.probs(ctx, rows)
                 rawpred = allpred[idx]
             else:
-                rawpred, _finite = ctx.cnn_probs(self.net_id, rows[idx])  # non-finite windows already at 0.5 (:175)
+                rawpred, _finite = self.probs(ctx, rows[idx])  # non-finite windows already at 0.5 (:175)
         ret = []
         trans = diag_trans_exp(self.viterbi_arg, len(self.outlabels))
         pos = 0
@@ -314,8 +346,8 @@ class Segmenter:
             # within one file its gender pass needs the VAD result)
             ctx = self.ctx
             rows = _window_rows(_ensure_resident(ctx, mspec), difflen)
-            t1, p1, _ = ctx.cnn_probs_async(self.vad.net_id, rows, *self._pinned_out(0, len(rows), len(self.vad.outlabels)))
-            t2, p2, _ = ctx.cnn_probs_async(self.gender.net_id, rows, *self._pinned_out(1, len(rows), len(self.gender.outlabels)))
+            t1, p1, _ = self.vad.probs(ctx, rows, async_out=self._pinned_out(0, len(rows), len(self.vad.outlabels)))
+            t2, p2, _ = self.gender.probs(ctx, rows, async_out=self._pinned_out(1, len(rows), len(self.gender.outlabels)))
             pending = (t1, p1, t2, p2)
         lseg = []
         for lab, start, stop in _binidx2seglist(_energy_activity(loge, self.energy_ratio)[::2]):

@@ -105,14 +105,15 @@ enum {
     ISS_OP_SOFTMAX  = 3,  /* softmax over the channel axis                               */
     ISS_OP_STATPOOL = 4,  /* mean || std over the time axis (resnet.py:123-127)          */
     ISS_OP_ACT      = 5,  /* elementwise activation beyond the fused ones: ISS_C_ACT 4 elu(alpha), 5 leaky relu(alpha),
-                             6 selu, 7 softplus; alpha = the float whose bits are in ISS_C_ACTPARAM; IN may equal OUT */
+                             6 selu, 7 softplus, 8 relu clipped at alpha (ReLU(max_value)); alpha = the float whose bits are in
+                             ISS_C_ACTPARAM; IN may equal OUT, and is never ISS_BUF_INPUT */
 };
 /* column meaning of a program row (unused columns = 0, absent offsets = -1) */
 enum {
     ISS_C_OP = 0, ISS_C_IN, ISS_C_OUT, ISS_C_RES,      /* buffer ids; RES = residual add   */
     ISS_C_H, ISS_C_W, ISS_C_CIN, ISS_C_HO, ISS_C_WO, ISS_C_COUT,
     ISS_C_KH, ISS_C_KW, ISS_C_SH, ISS_C_SW, ISS_C_PT, ISS_C_PL,
-    ISS_C_ACT,                                          /* CONV: 0 none 1 relu 2 sigmoid 3 tanh (fused); ISS_OP_ACT rows: 4..7 */
+    ISS_C_ACT,                                          /* CONV: 0 none 1 relu 2 sigmoid 3 tanh (fused); ISS_OP_ACT rows: 4..8 */
     ISS_C_WOFF, ISS_C_BOFF,                             /* blob offsets: W [Cout][roundup32(kh*kw*Cin)] (WOFF % 8 == 0), bias */
     ISS_C_PSOFF, ISS_C_PTOFF,                           /* post-activation scale / shift   */
     ISS_C_INMODE,                                       /* 0 NHWC buffer, 1 z-normed mspec patch,

@@ -37,6 +37,8 @@ def _act_np(x, fn, alpha=None):
         return x
     if fn == 'relu':
         return np.maximum(x, 0)
+    if fn == 'relu_max':                           # keras.layers.ReLU(max_value=alpha): min(max(x, 0), alpha)
+        return np.minimum(np.maximum(x, 0), np.float32(alpha))
     if fn == 'elu':                                # keras.activations.elu: x if x > 0 else alpha * (exp(x) - 1)
         return np.where(x > 0, x, np.float32(alpha) * (np.exp(np.minimum(x, 0)) - 1))
     if fn == 'leaky_relu':                         # keras.layers.LeakyReLU: x if x > 0 else alpha * x
@@ -68,6 +70,8 @@ def forward(layers, x, batch_size=1024, threads=None):
             return t
         if fn == 'relu':
             return torch.relu(t)
+        if fn == 'relu_max':
+            return torch.clamp(t, 0.0, float(alpha))
         if fn == 'elu':
             return F.elu(t, alpha=float(alpha))
         if fn == 'leaky_relu':
@@ -92,19 +96,29 @@ def forward(layers, x, batch_size=1024, threads=None):
             flat = False
             for L in layers:
                 ty = L['type']
-                if ty == 'conv2d':
-                    w = torch.from_numpy(np.ascontiguousarray(L['W'].transpose(3, 2, 0, 1)))
+                if ty in ('conv2d', 'depthwise'):
+                    # Conv2D: kernel (kh, kw, cin, cout).  DepthwiseConv2D: kernel (kh, kw, cin, depth_multiplier), output channel
+                    # c * multiplier + m = filter m of input channel c (torch groups = cin has the same channel order).
+                    # dilation_rate: taps (dy, dx) apart; 'same' pads for the EFFECTIVE kernel size (k - 1) * d + 1
+                    if ty == 'depthwise':
+                        kh, kw, cin, mult = L['W'].shape
+                        w = torch.from_numpy(np.ascontiguousarray(L['W'].transpose(2, 3, 0, 1).reshape(cin * mult, 1, kh, kw)))
+                        groups = cin
+                    else:
+                        w = torch.from_numpy(np.ascontiguousarray(L['W'].transpose(3, 2, 0, 1)))
+                        groups = 1
                     b = None if L.get('b') is None else torch.from_numpy(L['b'])
                     kh, kw = L['W'].shape[:2]
                     sh, sw = L.get('strides', (1, 1))
+                    dy, dx = L.get('dilation', (1, 1))
                     if L.get('pad'):                       # a ZeroPadding2D in front of the convolution: (top, bottom, left, right)
                         zt, zb, zl, zr = L['pad']
                         t = F.pad(t, (zl, zr, zt, zb))
                     if L.get('padding', 'valid') == 'same':
-                        pt, pb = same_pads(t.shape[2], kh, sh)
-                        pl, pr = same_pads(t.shape[3], kw, sw)
+                        pt, pb = same_pads(t.shape[2], (kh - 1) * dy + 1, sh)
+                        pl, pr = same_pads(t.shape[3], (kw - 1) * dx + 1, sw)
                         t = F.pad(t, (pl, pr, pt, pb))
-                    t = act_nchw(F.conv2d(t, w, b, stride=(sh, sw)), L.get('activation'), act, L.get('alpha'))
+                    t = act_nchw(F.conv2d(t, w, b, stride=(sh, sw), dilation=(dy, dx), groups=groups), L.get('activation'), act, L.get('alpha'))
                 elif ty == 'batchnorm':
                     sc = L['gamma'] / np.sqrt(L['var'] + np.float32(L['eps']))
                     sh_ = L['beta'] - L['mean'] * sc

@@ -61,7 +61,7 @@ def run(comp, x):
         elif op == N.OP_ACT:                         # elementwise elu / leaky relu / selu / softplus (in place in the program)
             alpha = float(np.array([int(R[N.C_ACTPARAM])], np.int32).view(np.float32)[0])
             out = {4: lambda: F.elu(src, alpha=alpha), 5: lambda: F.leaky_relu(src, negative_slope=alpha), 6: lambda: F.selu(src),
-                   7: lambda: F.softplus(src)}[int(R[N.C_ACT])]()
+                   7: lambda: F.softplus(src), 8: lambda: torch.clamp(src, 0.0, alpha)}[int(R[N.C_ACT])]()
         elif op == N.OP_STATPOOL:                    # mean || std over W (time) per (h, c), torch's (c, h) flatten order
             mean = src.mean(dim=2)                   # (N, H, C)
             std = torch.sqrt((src * src).mean(dim=2) - mean * mean + 1e-10)

@@ -89,6 +89,16 @@ TOPOLOGIES = {
                                             _rand_conv(r, 3, 3, 32, 32), _rand_bn(r, 32), dict(type='activation', fn='leaky_relu', alpha=0.2),
                                             _rand_conv(r, 3, 3, 32, 64, act='selu'), dict(type='globalavgpool'),
                                             _rand_dense(r, 64, 32, 'softplus'), _rand_dense(r, 32, 3, 'softmax')],
+    # layers without a kernel of their own, lowered as ordinary convolutions on zero-filled kernels (keras_model.expand_generic_layers):
+    # a dilated Conv2D, a DepthwiseConv2D (multiplier 2), the two halves of a SeparableConv2D, and ReLU(max_value) (ISS_OP_ACT code 8)
+    'dilated_depthwise_separable_relu6': lambda r, h: [
+        dict(_rand_conv(r, 3, 3, 1, 16, padding='same'), dilation=(2, 1)), dict(type='activation', fn='relu_max', alpha=1.5),
+        dict(type='depthwise', W=r.normal(0, 0.4, (3, 3, 16, 2)).astype(np.float32), b=r.normal(0, 0.05, 32).astype(np.float32),
+             strides=(1, 1), padding='valid', activation='relu', dilation=(1, 1)),
+        dict(type='maxpool', pool=(2, 2), strides=(2, 2), padding='valid'),
+        dict(type='depthwise', W=r.normal(0, 0.4, (3, 3, 32, 1)).astype(np.float32), b=None, strides=(1, 1), padding='same',
+             activation='linear', dilation=(1, 2)),
+        _rand_conv(r, 1, 1, 32, 32, act='relu'), dict(type='globalavgpool'), _rand_dense(r, 32, 3, 'softmax')],
     'standalone_bn_first': lambda r, h: [_rand_bn(r, 1), _rand_conv(r, 3, 3, 1, 4, act='relu'), dict(type='dropout'),
                                          dict(type='flatten'), _rand_dense(r, 66 * (h - 2) * 4, 64, 'relu'), _rand_bn(r, 64),
                                          _rand_dense(r, 64, 2, 'softmax')],

@@ -150,4 +150,53 @@ def test_more_activations_parse_lower_and_run():
     assert np.abs(prog_interp.run(comp, x) - want).max() < 2e-5 and np.abs(ocnn.forward_naive(layers, x[:1]) - want[:1]).max() < 2e-5
     with pytest.raises(NotImplementedError):
         KM.layers_from_keras_config({'class_name': 'Sequential', 'config': {'layers': [
-            {'class_name': 'ReLU', 'config': {'name': 'r', 'max_value': 6.0, 'batch_input_shape': [None, 68, 21, 1]}}]}}, {})
+            {'class_name': 'ReLU', 'config': {'name': 'r', 'threshold': 0.5, 'batch_input_shape': [None, 68, 21, 1]}}]}}, {})
+
+
+def test_layers_without_a_kernel_of_their_own_are_lowered_through_ordinary_convolutions():
+    """`keras.models.load_model` (segmenter.py:129-131) takes any model_config.  Dilated Conv2D, DepthwiseConv2D, SeparableConv2D and
+    ReLU(max_value=...) have no dedicated kernel: they are parsed from the Keras config and lowered as ordinary convolutions on
+    zero-filled kernels (keras_model.expand_generic_layers) / an ISS_OP_ACT row, and compute what the oracle's independent torch
+    semantics (dilation / groups arguments) compute.  The string activation 'leaky_relu' is keras.activations.leaky_relu (slope 0.2),
+    not the LeakyReLU layer (0.3)."""
+    rng = np.random.default_rng(12)
+    nrm = lambda *sh, s=0.3: rng.normal(0, s, sh).astype(np.float32)
+    cfg = {'class_name': 'Sequential', 'config': {'layers': [
+        {'class_name': 'Conv2D', 'config': {'name': 'c1', 'padding': 'same', 'activation': 'linear', 'dilation_rate': [2, 3],
+                                            'batch_input_shape': [None, 68, 21, 1]}},
+        {'class_name': 'ReLU', 'config': {'name': 'r6', 'max_value': 0.8}},
+        {'class_name': 'DepthwiseConv2D', 'config': {'name': 'dw', 'padding': 'valid', 'depth_multiplier': 2, 'activation': 'leaky_relu',
+                                                     'strides': [2, 1]}},
+        {'class_name': 'SeparableConv2D', 'config': {'name': 'sp', 'padding': 'same', 'activation': 'relu', 'dilation_rate': 2}},
+        {'class_name': 'GlobalAveragePooling2D', 'config': {'name': 'g'}},
+        {'class_name': 'Dense', 'config': {'name': 'd', 'activation': 'softmax'}}]}}
+    weights = {'c1': {'kernel': nrm(3, 2, 1, 8), 'bias': nrm(8, s=0.1)},
+               'dw': {'depthwise_kernel': nrm(3, 3, 8, 2), 'bias': nrm(16, s=0.1)},
+               'sp': {'depthwise_kernel': nrm(3, 3, 16, 1), 'pointwise_kernel': nrm(1, 1, 16, 24), 'bias': nrm(24, s=0.1)},
+               'd': {'kernel': nrm(24, 3), 'bias': np.zeros(3, np.float32)}}
+    layers, shp = KM.layers_from_keras_config(cfg, weights)
+    assert [L['type'] for L in layers] == ['conv2d', 'activation', 'depthwise', 'depthwise', 'conv2d', 'globalavgpool', 'dense']
+    assert layers[0]['dilation'] == (2, 3) and layers[1] == dict(type='activation', name='r6', fn='relu_max', alpha=0.8)
+    assert layers[2]['alpha'] == 0.2 and layers[2]['strides'] == (2, 1) and layers[3]['b'] is None and layers[3]['dilation'] == (2, 2)
+    ex = KM.expand_generic_layers(layers)
+    assert ex[0]['W'].shape == (5, 4, 1, 8) and np.count_nonzero(ex[0]['W']) <= 3 * 2 * 8                 # (kh - 1) dy + 1, (kw - 1) dx + 1
+    assert ex[2]['type'] == 'conv2d' and ex[2]['W'].shape == (3, 3, 8, 16) and ex[3]['W'].shape == (5, 5, 16, 16)
+    assert all(ex[2]['W'][:, :, c, o].any() == (o // 2 == c) for c in range(8) for o in range(16))         # output c * m + j <- input c
+    comp = KM.compile_layers(layers, shp)
+    assert any(int(R[N.C_OP]) == N.OP_ACT and int(R[N.C_ACT]) == 8 for R in comp.prog)
+    x = rng.normal(0, 1, (3,) + shp).astype(np.float32)
+    want = ocnn.forward(layers, x)
+    got = prog_interp.run(comp, x)
+    assert np.abs(got - want).max() < 2e-5, np.abs(got - want).max()
+    # the model's own MACs, not the zero-filled kernels': dilation and depthwise expansion do not inflate the count
+    dense_equiv = KM.compile_layers(ex, shp)
+    assert comp.flops_per_sample < 0.5 * sum(2.0 * np.prod(L['W'].shape) * 68 * 21 for L in ex if L['type'] == 'conv2d')
+    assert dense_equiv.flops_per_sample == comp.flops_per_sample
+    # a depthwise convolution by hand: channel c of the input through filter (c, m) only
+    one = [dict(type='depthwise', W=nrm(2, 2, 3, 2), b=None, strides=(1, 1), padding='valid', activation='linear', dilation=(1, 1))]
+    xi = rng.normal(0, 1, (1, 4, 4, 3)).astype(np.float32)
+    y = ocnn.forward(one + [dict(type='flatten')], xi).reshape(3, 3, 6)
+    for c in range(3):
+        for m in range(2):
+            ref = sum(xi[0, dy:dy + 3, dx:dx + 3, c] * one[0]['W'][dy, dx, c, m] for dy in range(2) for dx in range(2))
+            assert np.abs(y[:, :, c * 2 + m] - ref).max() < 1e-6
