@@ -200,6 +200,10 @@ class Context:
         env = os.environ.get('ISS_DIAG', '')
         if env:                     # A/B tooling only (tools/ab_env.sh): the library itself never reads the environment
             self.set_diag(diag_flags(env))
+        self.guard_threshold = None # last value given to set_precision_guard (None = library default, 5e-4)
+        env = os.environ.get('ISS_PREC_GUARD', '')
+        if env:                     # A/B tooling only: timing-only experiment builds compute wrong results on purpose
+            self.set_precision_guard(float(env))
 
     def close(self):
         if getattr(self, '_h', None):

@@ -303,12 +303,20 @@ __global__ __launch_bounds__(256, NTN <= 4 ? 2 : 1) void conv_x3_kernel(const Co
 // workgroups walk the XCD-aware tile order and the register prefetch runs ACROSS tiles (the next tile's first k-tile is
 // fetched during the current tile's last one, its stores drain behind the next tile's MFMAs); no row decomposition
 // (row m of the GEMM is pixel m).
+// Round 6: THREE workgroups per CU.  The segmenter nets' first dense layer (K = 4992 / 8320, 192 columns) has 660 tiles per launch;
+// on 512 resident workgroups that was two rounds for 1.29 rounds of work, and a timing-only build whose activation loads all hit L2
+// ran no faster (profiles/HISTORY.md, round 6: the layer is bound by its per-k-tile barrier structure, not by memory).  768 resident
+// workgroups hold every tile at once.  LDS: the 80-byte padded rows (61 KB per workgroup) became unpadded 64-byte rows with the
+// 16-byte chunk swizzle of conv_fp.h (chunk c of row r at c ^ ((r >> 2) & 3): the 16 lanes of a ds_read_b128 group hit 16
+// different bank groups) = 48 KB.
+constexpr int PWLD = XBK;                            // bf16 / fp16 elements per LDS row (64 bytes, swizzled)
 template <bool F16>                                // fp16 instead of bf16 operand halves (ISS_PREC_F16X3, conv_common.h)
-__global__ __launch_bounds__(256, 2) void conv_x3_pw_kernel(const ConvArgs p) {
-    __shared__ __attribute__((aligned(16))) uint16_t sAh[2][BM * XLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sAl[2][BM * XLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sBh[2][BN * XLD];
-    __shared__ __attribute__((aligned(16))) uint16_t sBl[2][BN * XLD];
+__global__ __launch_bounds__(256, 3) void conv_x3_pw_kernel(const ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) uint16_t sAh[2][BM * PWLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sAl[2][BM * PWLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBh[2][BN * PWLD];
+    __shared__ __attribute__((aligned(16))) uint16_t sBl[2][BN * PWLD];
+    auto lds_off = [](int row, int chunk) { return row * PWLD + ((chunk ^ ((row >> 2) & 3)) << 3); };     // in 16-bit elements
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const unsigned ntiles = p.nblk * p.nblk_n;
@@ -316,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pw_kernel(const ConvArgs p) {
     if (t >= ntiles) return;
     const int k8 = tid & 7, lr = tid >> 3;           // A staging: k columns [4 k8, 4 k8 + 4) of rows lr + 32 j
     const int br = tid >> 2, bseg = tid & 3;         // B staging: 8 bf16 of weight row br, hi and lo
+    const int awr = lds_off(lr, k8 >> 1) + (k8 & 1) * 4, bwr = lds_off(br, bseg);
     // A tile of the GEMM: uniform 64-bit base of its first row + 32-bit per-lane offsets (rows >= M re-read row M - 1:
     // their accumulator rows are never stored).  No masks and no branches around the loads: a select or a branch right
     // behind a load makes hipcc wait for it on the spot, in front of the MFMAs it is meant to overlap.
@@ -338,6 +347,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pw_kernel(const ConvArgs p) {
     // flight; with a one-iteration distance the launches ran at 2 TB/s and 10 % of the matrix peak.
     struct Regs { float4 a[4]; uint4 bh, bl; };
     auto gather = [&](Regs& r, const Tile& T, int kt) {
+#ifdef ISS_EXPERIMENTS                                           // timing-only (make EXPERIMENTS=1, ISS_DBG=4): every A load from one 64 KB region
+        if (p.dbg & 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.a[j] = *reinterpret_cast<const float4*>(p.in + ((T.ao[j] + (unsigned)(kt * XBK)) & 0x3FFCu));
+        } else
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) r.a[j] = *reinterpret_cast<const float4*>(T.abase + (T.ao[j] + (unsigned)(kt * XBK)));
         r.bh = *reinterpret_cast<const uint4*>(p.wh + (T.wo + (unsigned)(kt * XBK)));
@@ -353,17 +368,17 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pw_kernel(const ConvArgs p) {
             if constexpr (F16) {
                 uint2 h, l;
                 split4_pk<true>(r.a[j], h.x, h.y, l.x, l.y);
-                *reinterpret_cast<uint2*>(&sAh[buf][(lr + 32 * j) * XLD + k8 * 4]) = h;
-                *reinterpret_cast<uint2*>(&sAl[buf][(lr + 32 * j) * XLD + k8 * 4]) = l;
+                *reinterpret_cast<uint2*>(&sAh[buf][awr + 32 * j * PWLD]) = h;
+                *reinterpret_cast<uint2*>(&sAl[buf][awr + 32 * j * PWLD]) = l;
             } else {
             bf16x4 h, l;
             split4(r.a[j], h, l);
-            *reinterpret_cast<bf16x4*>(&sAh[buf][(lr + 32 * j) * XLD + k8 * 4]) = h;
-            *reinterpret_cast<bf16x4*>(&sAl[buf][(lr + 32 * j) * XLD + k8 * 4]) = l;
+            *reinterpret_cast<bf16x4*>(&sAh[buf][awr + 32 * j * PWLD]) = h;
+            *reinterpret_cast<bf16x4*>(&sAl[buf][awr + 32 * j * PWLD]) = l;
             }
         }
-        *reinterpret_cast<uint4*>(&sBh[buf][br * XLD + bseg * 8]) = r.bh;
-        *reinterpret_cast<uint4*>(&sBl[buf][br * XLD + bseg * 8]) = r.bl;
+        *reinterpret_cast<uint4*>(&sBh[buf][bwr]) = r.bh;
+        *reinterpret_cast<uint4*>(&sBl[buf][bwr]) = r.bl;
     };
 
     floatx16 acc0, acc1;
@@ -371,8 +386,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pw_kernel(const ConvArgs p) {
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     const int nk = p.Kpad / XBK;
     const int li = lane & 31, lh = lane >> 5;
-    const int aoff = (wv * 32 + li) * XLD + lh * 8;
-    const int boff_s = li * XLD + lh * 8;
+    // (rows lr + 32 j share (row >> 2) & 3, so one swizzled offset serves the four staging stores; the second k16 step of a row is
+    // its first one's chunk ^ 2 = 16 elements further or nearer)
+    const int aoff = lds_off(wv * 32 + li, lh);
+    const int boff_s = lds_off(li, lh);
 
     // load cursor (tile, k-tile), two iterations ahead of the compute cursor; past the last tile it re-reads that tile
     unsigned tl = t;
@@ -401,12 +418,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_pw_kernel(const ConvArgs p) {
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sAh[cur][aoff + ks * 16]);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sAl[cur][aoff + ks * 16]);
-            const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + ks * 16]);
-            const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + ks * 16]);
-            const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s + 32 * XLD + ks * 16]);
-            const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s + 32 * XLD + ks * 16]);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&sAh[cur][aoff ^ (ks * 16)]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&sAl[cur][aoff ^ (ks * 16)]);
+            const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(&sBh[cur][boff_s ^ (ks * 16)]);
+            const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(&sBl[cur][boff_s ^ (ks * 16)]);
+            const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(&sBh[cur][(boff_s ^ (ks * 16)) + 32 * PWLD]);
+            const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(&sBl[cur][(boff_s ^ (ks * 16)) + 32 * PWLD]);
             // C^T: rows = channels, columns = pixels (epilogue_tr); two independent accumulators alternate
             acc0 = mfma_x3<F16>(b0h, al, acc0);
             acc1 = mfma_x3<F16>(b1h, al, acc1);
@@ -1788,7 +1805,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                     if (hl_f16.count(R[ISS_C_IN])) { a.f16 = 1; a.wh = n.d_wh16 + R[ISS_C_WOFF]; a.wl = n.d_wl16 + R[ISS_C_WOFF]; }
                     if (wq3_kind == 0 && want_hl_out(r, a.M)) { a.out_hl = 1; a.out_np = issk::chl_npad(a.M); hl_out_row = r; hl_out_np = a.out_np; }
                     if (a.out_hl && a.f16) hl_out_f16 = true;
-                    iss_prof_inst(c, a.f16 ? "conv_x3_wq3h_kernel<%d,%s,f16>" : "conv_x3_wq3h_kernel<%d,%s>", wq3_kind, a.out_hl ? "true" : "false");
+                    iss_prof_inst(c, "conv_x3_wq3h_kernel<%d,%s,%s>", wq3_kind, a.out_hl ? "true" : "false", a.f16 ? "true" : "false");     // <KIND,OUT_HL,F16>
                     issk::iss_wq3h_launch(a, qgrid, c->stream, wq3_kind);
                     in_hl_taken = true;
                 } else {
@@ -1861,8 +1878,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 const dim3 qgrid(std::min<unsigned>((qtiles + 1) / 2, 256u), grid.y);     // persistent: one 256-thread workgroup per CU
                 if (a.Cout % BN == 0 && want_hl_out(r, a.M / 4)) { a.out_hl = 1; a.out_np = issk::chl_npad(a.M / 4); hl_out_row = r; hl_out_np = a.out_np; }
                 if (row_f16) { a.f16 = 1; a.wh = n.d_wh16 + R[ISS_C_WOFF]; a.wl = n.d_wl16 + R[ISS_C_WOFF]; if (a.out_hl) hl_out_f16 = true; }
-                iss_prof_inst(c, a.f16 ? (a.out_hl ? "conv_x3_wq_kernel<%d,%d,hl,f16>" : "conv_x3_wq_kernel<%d,%d,f16>")
-                                       : (a.out_hl ? "conv_x3_wq_kernel<%d,%d,hl>" : "conv_x3_wq_kernel<%d,%d>"), a.H_k, a.kw);
+                iss_prof_inst(c, "conv_x3_wq_kernel<%d,%d,%s,%s>", a.H_k, a.kw, a.out_hl ? "true" : "false", a.f16 ? "true" : "false");   // <KH,KW,OUT_HL,F16>
                 issk::iss_wq_launch_5x3(a, qgrid, c->stream);
             } else {
             {
@@ -1939,11 +1955,11 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             } else if (pointwise) {
                 if (row_f16) {
                     a.f16 = 1; a.wh = n.d_wh16 + R[ISS_C_WOFF]; a.wl = n.d_wl16 + R[ISS_C_WOFF];
-                    iss_prof_inst(c, "conv_x3_pw_kernel<f16>");
-                    hipLaunchKernelGGL(conv_x3_pw_kernel<true>, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), dim3(256), 0, c->stream, a);
+                    iss_prof_inst(c, "conv_x3_pw_kernel<true>");                                  // <F16>
+                    hipLaunchKernelGGL(conv_x3_pw_kernel<true>, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 768u)), dim3(256), 0, c->stream, a);
                 } else {
-                iss_prof_inst(c, "conv_x3_pw_kernel");
-                hipLaunchKernelGGL(conv_x3_pw_kernel<false>, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 512u)), dim3(256), 0, c->stream, a);
+                iss_prof_inst(c, "conv_x3_pw_kernel<false>");
+                hipLaunchKernelGGL(conv_x3_pw_kernel<false>, dim3(std::min<unsigned>(a.nblk * a.nblk_n, 768u)), dim3(256), 0, c->stream, a);
                 }
             } else {
             iss_prof_inst(c, "conv_x3_kernel<%d,%s,2>", a.mode, (a.mode != 2 && tr) ? "true" : "false");

@@ -168,14 +168,21 @@ class VoiceFemininityScoring:
             resnet, mlp = models['resnet'], models['mlp']
         else:
             try:                                          # the file `get_remote` fetches by default (remote_utils.py:13, backend='onnx')
-                resnet = _load_resnet_params(locate_model('final.onnx'))
-            except (FileNotFoundError, ValueError, NotImplementedError) as exc:
-                # no final.onnx, or one this package's reader does not recognise as resnet.py's graph: the torch checkpoint
-                # of the same network (remote_utils.py:14) if it is there, else the first error
+                onnx_path = locate_model('final.onnx')
+            except FileNotFoundError as exc:
+                # no final.onnx: the torch checkpoint of the same network (remote_utils.py:14) if it is there, else that error
                 try:
                     resnet = _load_resnet_params(locate_model('raw_81.pth'))
                 except FileNotFoundError:
                     raise exc
+            else:
+                # a final.onnx the reader does not recognise as resnet.py's graph is an error of its own: no silent second try
+                # (a torch ImportError from the .pth path would hide the real cause)
+                try:
+                    resnet = _load_resnet_params(onnx_path)
+                except (ValueError, NotImplementedError) as exc:
+                    raise type(exc)(f"{exc} -- {onnx_path} was found but could not be read as the ResNet-101 of resnet.py; remove it to "
+                                    "fall back to raw_81.pth, or export it with `torch.onnx.export` from resnet.py") from exc
             mlp = keras_model.load_model_file(locate_model(gd_model))
         self.features = FeatureExtractor(self.ctx)
         self.xvector_model = VBxExtractor(self.ctx, resnet)
