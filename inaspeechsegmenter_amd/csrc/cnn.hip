@@ -1743,6 +1743,14 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         ws = ws && fused;
         if (gfused) a.mode = fs1 ? 4 : 3;
+        // CHL output through the shared pooled epilogue (conv_common.h epilogue_impl / chl_store): every kernel family that ends in it --
+        // the weight-stationary forms, conv_x3_fp_kernel, the generic gather kernel -- can hand its pooled relu output to a
+        // conv_x3_wq3h_kernel the way conv_x3_wq_kernel does (the two launch sites with an epilogue of their own take it back below)
+        if (x3 && !patch && issk::epi_is_pool_relu(a) && a.Cout % 16 == 0 && want_hl_out(r, a.M / a.pp)) {
+            a.out_hl = 1; a.out_np = issk::chl_npad(a.M / a.pp); a.out_f16 = f16mode ? 1 : 0;
+            hl_out_row = r; hl_out_np = a.out_np; hl_out_f16 = f16mode;
+        }
+        auto no_chl_out = [&]() { a.out_hl = 0; a.out_np = 0; a.out_f16 = 0; if (hl_out_row == r) hl_out_row = -1; hl_out_f16 = false; };
         iss_prof_begin(c, 0, fl);
         iss_prof_tag(c, ws || ws_plain || ws_plain_u || ws_nh2 ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
         iss_prof_row(c, r);
@@ -1800,6 +1808,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             if (wq3_kind >= 0) {
                 const unsigned qtiles = (unsigned)((a.M + a.tmr - 1) / a.tmr);
                 const dim3 qgrid(std::min<unsigned>((qtiles + 1) / 2, std::max(1u, 256u / ny)), ny);
+                no_chl_out();                                    // (these kernels have epilogues of their own: kind 0 decides below, kind 1 writes f32)
                 if (in_is_hl) {                                  // the producer wrote the CHL layout for this launch (want_hl_out)
                     a.in_hl = 1; a.in_np = hl_np[R[ISS_C_IN]];
                     if (hl_f16.count(R[ISS_C_IN])) { a.f16 = 1; a.wh = n.d_wh16 + R[ISS_C_WOFF]; a.wl = n.d_wl16 + R[ISS_C_WOFF]; }
@@ -1876,6 +1885,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             if (wq) {
                 const unsigned qtiles = (unsigned)((a.M + a.tmr - 1) / a.tmr);
                 const dim3 qgrid(std::min<unsigned>((qtiles + 1) / 2, 256u), grid.y);     // persistent: one 256-thread workgroup per CU
+                no_chl_out();                                    // (its own CHL epilogue; the halves follow the launch's operand type)
                 if (a.Cout % BN == 0 && want_hl_out(r, a.M / 4)) { a.out_hl = 1; a.out_np = issk::chl_npad(a.M / 4); hl_out_row = r; hl_out_np = a.out_np; }
                 if (row_f16) { a.f16 = 1; a.wh = n.d_wh16 + R[ISS_C_WOFF]; a.wl = n.d_wl16 + R[ISS_C_WOFF]; if (a.out_hl) hl_out_f16 = true; }
                 iss_prof_inst(c, "conv_x3_wq_kernel<%d,%d,%s,%s>", a.H_k, a.kw, a.out_hl ? "true" : "false", a.f16 ? "true" : "false");   // <KH,KW,OUT_HL,F16>

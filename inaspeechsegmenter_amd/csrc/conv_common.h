@@ -90,6 +90,8 @@ struct ConvArgs {
     unsigned in_np, out_np;
     int f16;                 // operand halves are fp16, not bf16 (ISS_PREC_F16X3): wh / wl point at the fp16 split of the weights, a CHL
                              // input / output holds fp16 planes; only the kernels with an F16 instantiation are launched with it
+    int out_f16;             // the shared pooled epilogue (epilogue_impl) writes a CHL output with fp16 (1) or bf16 (0) halves, whatever
+                             // the launch's own operand type is
 };
 
 // ------------------------------------------------------------------------------------------
@@ -183,6 +185,23 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // HAS_PS: post-activation scale/shift; HAS_RES: residual add.  The common combinations are compiled without any
 // per-element branch (the fully generic form, inlined 32 times per tile, was ~6000 ISA lines of mostly skipped code).
 // P: ConvArgs, or the EpiArgs subset the weight-stationary kernel loads at the end of a tile group (conv_ws.h)
+// One pooled value of channel n at pooled pixel `pix` into a CHL tensor (planes of `np` pixels; see chl_npad below): the operand split
+// the consumer would do on an f32 input, two 2-byte stores.  The weight-stationary kernels' pooled epilogue (conv_ws.h) writes it
+// for a conv_x3_wq3h_kernel that reads it by LDS-DMA, like conv_x3_wq_kernel's own epilogue does.
+__device__ __forceinline__ void chl_store(float* out, unsigned np, int f16, long long pix, int n, float x) {
+    uint16_t* o = reinterpret_cast<uint16_t*>(out) + (((size_t)((n >> 4) * 4 + ((n >> 3) & 1) * 2) * np + (size_t)pix) * 8 + (size_t)(n & 7));
+    uint16_t h, l;
+    if (f16) {
+        const _Float16 hh = (_Float16)x, ll = (_Float16)(x - (float)hh);
+        h = __builtin_bit_cast(uint16_t, hh); l = __builtin_bit_cast(uint16_t, ll);
+    } else {
+        const __bf16 hh = (__bf16)x, ll = (__bf16)(x - (float)hh);
+        h = __builtin_bit_cast(uint16_t, hh); l = __builtin_bit_cast(uint16_t, ll);
+    }
+    o[0] = h;
+    o[(size_t)np * 8] = l;                          // the lo plane follows the hi plane
+}
+
 template <int ACT, int PP, bool HAS_PS, bool HAS_RES, class P>
 __device__ __forceinline__ void epilogue_impl(const P& p, const floatx16& acc, long long mrow0, int n, int lh) {
     if (n >= p.Cout) return;
@@ -200,7 +219,8 @@ __device__ __forceinline__ void epilogue_impl(const P& p, const floatx16& acc, l
                     if (mb < p.M) {
                         float x = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bias;
                         if (ACT == 1) x = fmaxf(x, 0.f);
-                        p.out[(size_t)(mb >> 2) * p.Cout + n] = x;
+                        if (p.out_np) chl_store(p.out, p.out_np, p.out_f16, mb >> 2, n, x);
+                        else p.out[(size_t)(mb >> 2) * p.Cout + n] = x;
                     }
                 } else {
 #pragma unroll
@@ -208,7 +228,8 @@ __device__ __forceinline__ void epilogue_impl(const P& p, const floatx16& acc, l
                         if (mb + i < p.M) {
                             float x = fmaxf(acc[4 * g + i], acc[4 * g + i + 1]) + bias;
                             if (ACT == 1) x = fmaxf(x, 0.f);
-                            p.out[(size_t)((mb + i) >> 1) * p.Cout + n] = x;
+                            if (p.out_np) chl_store(p.out, p.out_np, p.out_f16, (mb + i) >> 1, n, x);
+                            else p.out[(size_t)((mb + i) >> 1) * p.Cout + n] = x;
                         }
                 }
             }

@@ -59,6 +59,7 @@ typedef const ConvArgs __attribute__((address_space(4)))* KArg;
 struct EpiArgs {
     const float* bias; const float* ps; const float* pt; const float* res; float* out;
     long long M; int Cout, act, pp, poolkind;
+    unsigned out_np; int out_f16;                  // CHL output of the pooled epilogue (conv_common.h chl_store), 0 = f32 NHWC
 };
 
 
@@ -635,6 +636,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
             EpiArgs e;
             e.bias = q->bias; e.ps = q->ps; e.pt = q->pt; e.res = q->res; e.out = q->out;
             e.M = q->M; e.Cout = q->Cout; e.act = q->act; e.pp = q->pp; e.poolkind = q->poolkind;
+            e.out_np = q->out_hl ? q->out_np : 0u; e.out_f16 = q->out_f16;
             // t: NH = 1: tile of the group; NH = 2: column half of the group's one tile
             auto finish = [&](const int t, const int rb, floatx16& c0acc, floatx16& c1acc) __attribute__((always_inline)) {
                 const int tile = NH == 2 ? grp : grp * G + t;
