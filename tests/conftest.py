@@ -38,7 +38,7 @@ def ctx():
     # ... and in the split-bf16 arithmetic every GEMM kernel has (the tests that switch kernel families with iss_set_diag expect
     # bit-identical results; the library default, fp16 halves, exists in the kernels of the segmenter nets only:
     # test_f16x3_mode / test_precision_guard_* and every Segmenter of the other tests run it)
-    c.set_precision(_native.PREC_BF16X3)
+    c.set_precision({'f16x3': _native.PREC_F16X3, 'f32': _native.PREC_F32}.get(os.environ.get('ISS_TEST_PREC', ''), _native.PREC_BF16X3))
     yield c
     c.close()
 

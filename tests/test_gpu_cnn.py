@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 PROB_TOL = 1e-3
 
 
-@pytest.fixture(params=['bf16x3', 'f32'])
+@pytest.fixture(params=['bf16x3', 'f16x3', 'f32'])
 def prec(request, ctx):
-    ctx.set_precision(_native.PREC_F32 if request.param == 'f32' else _native.PREC_BF16X3)
+    ctx.set_precision({'f32': _native.PREC_F32, 'f16x3': _native.PREC_F16X3}.get(request.param, _native.PREC_BF16X3))
     yield request.param
     ctx.set_precision(_native.PREC_BF16X3)
 

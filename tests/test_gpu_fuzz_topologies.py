@@ -95,6 +95,13 @@ def test_random_topology(ctx, k):
     finally:
         ctx.set_precision(_native.PREC_BF16X3)
     err3 = np.abs(p3 - ref).max()
-    print(f'net {k}: {spec}\n   kernels {sorted(set(insts))}\n   overlapping {err:.2e}, scattered {err2:.2e}, exact-f32 {err3:.2e}')
-    assert np.array_equal(fin, rfin) and np.array_equal(f2, rf2) and np.array_equal(f3, rfin)
-    assert err < 1e-4 and err2 < 1e-4 and err3 < 1e-4, (k, spec, err, err2, err3)
+    ctx.set_precision(_native.PREC_F16X3)                                # the library default: fp16 halves / exact f32 / bf16 halves per layer
+    try:
+        p4, f4 = ctx.cnn_probs(5, rows)
+        p5, f5 = ctx.cnn_probs(5, scat)
+    finally:
+        ctx.set_precision(_native.PREC_BF16X3)
+    err4, err5 = np.abs(p4 - ref).max(), np.abs(p5 - r2).max()
+    print(f'net {k}: {spec}\n   kernels {sorted(set(insts))}\n   overlapping {err:.2e}, scattered {err2:.2e}, exact-f32 {err3:.2e}, fp16 halves {err4:.2e} / {err5:.2e}')
+    assert np.array_equal(fin, rfin) and np.array_equal(f2, rf2) and np.array_equal(f3, rfin) and np.array_equal(f4, rfin) and np.array_equal(f5, rf2)
+    assert err < 1e-4 and err2 < 1e-4 and err3 < 1e-4 and err4 < 1e-4 and err5 < 1e-4, (k, spec, err, err2, err3, err4, err5)

@@ -6,7 +6,7 @@ through the asynchronous entry.  Plus the BASELINE config-size check: one hour o
 import numpy as np
 import pytest
 
-from inaspeechsegmenter_amd import keras_model as KM, segmenter as S
+from inaspeechsegmenter_amd import keras_model as KM, segmenter as S, _native
 from oracle import keras_cnn as ocnn
 import topologies as TP
 
@@ -88,8 +88,18 @@ def test_topology_parity(ctx, name):
         p2, f2 = ctx.cnn_probs(5, scat)
         r2, rf2 = _oracle_probs(layers, mspec, nmel, scat)
         err2 = np.abs(p2 - r2).max()
-        print(f'{name}/{net}: overlapping {err:.2e}, scattered {err2:.2e}')
+        # the library's default arithmetic (round 6): fp16 operand halves where a kernel has them, exact f32 for small layers without,
+        # bf16 halves elsewhere -- per layer, so every topology mixes them its own way; same finite mask, same tolerance
+        ctx.set_precision(_native.PREC_F16X3)
+        try:
+            p16, f16 = ctx.cnn_probs(5, rows)
+            p16s, f16s = ctx.cnn_probs(5, scat)
+        finally:
+            ctx.set_precision(_native.PREC_BF16X3)
+        err16, err16s = np.abs(p16 - ref).max(), np.abs(p16s - r2).max()
+        print(f'{name}/{net}: overlapping {err:.2e}, scattered {err2:.2e}; fp16 halves {err16:.2e} / {err16s:.2e}')
         assert err < 1e-4 and err2 < 1e-4 and np.array_equal(f2, rf2), (name, net, err, err2)
+        assert err16 < 1e-4 and err16s < 1e-4 and np.array_equal(f16, rfin) and np.array_equal(f16s, rf2), (name, net, err16, err16s)
         # asynchronous entry: same bits, result arrays in page-locked memory
         pp = ctx.pinned_empty((len(rows), probs.shape[1]), np.float32)
         pf = ctx.pinned_empty((len(rows),), np.uint8)

@@ -778,3 +778,39 @@ def test_every_diag_switch_of_the_abi_has_its_python_name():
     assert _native.diag_flags('no_ring,no_fsame+no_gfused') == 0x2000 | 0x4000 | 0x40000
     with pytest.raises(KeyError):
         _native.diag_flags('no_such_switch')
+
+
+def test_one_arithmetic_decision_per_network_across_device_contexts():
+    """The precision guard (include/iss.h) decides a network's arithmetic at its first call PER CONTEXT; `DnnSegmenter.probs`
+    makes the first call anywhere decide for every device context of the Segmenter (its own and the pipeline workers'): later
+    contexts are told the outcome before their first call and are never probed; with the guard off nothing is touched."""
+    from inaspeechsegmenter_amd import segmenter as S
+
+    class Ctx:
+        def __init__(self, outcome):
+            self.outcome, self.state, self.mode, self.calls, self.told = outcome, 'pending', 'f16x3', 0, []
+
+        def cnn_probs(self, net_id, rows):
+            self.calls += 1
+            if self.state == 'pending' and self.outcome is not None:
+                self.state, self.mode = self.outcome
+            return np.zeros((len(rows), 2), np.float32), np.ones(len(rows), np.uint8)
+
+        def cnn_precision_info(self, net_id):
+            return {'state': self.state, 'mode': self.mode, 'max_dlogp': None, 'max_dlogp_in_use': None, 'slots': 0}
+
+        def cnn_set_net_precision(self, net_id, mode):
+            self.told.append(mode); self.state = 'fixed'
+            self.mode = {_native.PREC_BF16X3: 'bf16x3', _native.PREC_F32: 'f32', _native.PREC_F16X3: 'f16x3'}[mode]
+
+    net = S.DnnSegmenter.__new__(S.Gender)
+    a, b, c = Ctx(('escalated', 'bf16x3')), Ctx(('passed', 'f16x3')), Ctx(('escalated', 'f32'))
+    rows = np.arange(4, dtype=np.int32)
+    net.probs(a, rows)                                   # the first call anywhere: the library probes and decides
+    net.probs(b, rows); net.probs(c, rows); net.probs(b, rows); net.probs(a, rows)
+    assert a.told == [] and b.told == [_native.PREC_BF16X3] and c.told == [_native.PREC_BF16X3]
+    assert (a.mode, b.mode, c.mode) == ('bf16x3', 'bf16x3', 'bf16x3') and (a.calls, b.calls, c.calls) == (2, 2, 1)
+    off = S.DnnSegmenter.__new__(S.Gender)               # guard off: the state stays 'pending', nobody is told anything
+    d, e = Ctx(None), Ctx(None)
+    off.probs(d, rows); off.probs(e, rows); off.probs(d, rows)
+    assert d.told == [] and e.told == [] and d.calls == 2 and e.calls == 1
