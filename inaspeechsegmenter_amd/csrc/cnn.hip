@@ -27,6 +27,7 @@
 #include "conv_wq.h"
 #include "conv_wq3.h"
 #include "conv_wq3h.h"
+#include "conv_dhl.h"
 #include "conv_pwc.h"
 #include "conv_pw.h"
 
@@ -1012,6 +1013,7 @@ int iss_cnn_free(iss_ctx* c, int id) {
     if (n.d_blob) (void)hipFree(n.d_blob);
     if (n.d_wh) (void)hipFree(n.d_wh);
     if (n.d_wl) (void)hipFree(n.d_wl);
+    for (auto& kv : n.dhl_wp) if (kv.second) (void)hipFree(kv.second);
     if (n.d_wh16) (void)hipFree(n.d_wh16);
     if (n.d_wl16) (void)hipFree(n.d_wl16);
     if (n.d_wsum) (void)hipFree(n.d_wsum);
@@ -1375,6 +1377,8 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
     // only reader and runs on conv_x3_wq3h_kernel (wq3_plan: the conditions conv_row launches conv_x3_wq3_kernel under).
     std::map<int, unsigned> hl_np;
     std::map<int, bool> hl_f16;                                  // ... and holds fp16 (not bf16) planes
+    std::map<int, bool> hl_dense;                                // ... and is the flattened-feature CHL tensor of a dense layer (conv_dhl.h)
+    bool hl_out_dense = false;
     bool hl_out_f16 = false;
     int hl_out_row = -1;                                         // the row conv_row has just launched with a CHL output ...
     unsigned hl_out_np = 0;                                      // ... and its plane size
@@ -1439,6 +1443,30 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         return true;
     };
+    // row r is a pooled conv launch (conv_x3_wq3h_kernel<1, ..>) whose output, flattened, is read by the dense layer of row r + 1 and by
+    // nobody else: it may write the CHL tensor conv_dhl_kernel fetches by LDS-DMA (window = "pixel", feature = "channel")
+    auto want_dhl_out = [&](int r, int hq, int wq) -> bool {
+        if (no_hl || r + 1 >= n.nrows || !x3mode) return false;
+        const int32_t* R = &n.prog[(size_t)r * ISS_PROG_COLS];
+        const int32_t* Q = &n.prog[(size_t)(r + 1) * ISS_PROG_COLS];
+        const int ob = R[ISS_C_OUT];
+        const long long K = (long long)hq * wq * R[ISS_C_COUT];
+        int qph, qpw;
+        fused_pool_of(Q, qph, qpw);
+        if (Q[ISS_C_OP] != ISS_OP_CONV || Q[ISS_C_IN] != ob || Q[ISS_C_OUT] == ob || Q[ISS_C_INMODE] != 0 || Q[ISS_C_RES] >= 0 || Q[ISS_C_DUALW] != 0) return false;
+        if (Q[ISS_C_KH] != 1 || Q[ISS_C_KW] != 1 || Q[ISS_C_H] != 1 || Q[ISS_C_W] != 1 || Q[ISS_C_HO] != 1 || Q[ISS_C_WO] != 1 || qph * qpw != 1) return false;
+        if (Q[ISS_C_CIN] != K || n.kpad[r + 1] != K || hq * wq < 2 || R[ISS_C_COUT] % 8 != 0) return false;
+        if (!issk::dhl_supported((int)K, Q[ISS_C_COUT], Q[ISS_C_ACT], Q[ISS_C_PSOFF] >= 0, false)) return false;
+        const size_t bytes = (size_t)issk::dhl_npad(bc) * (size_t)K * 4;
+        if (bytes > (size_t)bc * K * 4 + issk::ISS_ACT_SLACK || bytes >= 0xFFF00000ull || (long long)bc * hq * wq * (hq * wq) >= (1ll << 32)) return false;
+        if ((long long)bc * Q[ISS_C_COUT] * 4 >= (1ll << 32)) return false;
+        for (int t = r + 2; t < n.nrows; ++t) {
+            const int32_t* T = &n.prog[(size_t)t * ISS_PROG_COLS];
+            if (T[ISS_C_IN] == ob || T[ISS_C_RES] == ob) return false;
+            if (T[ISS_C_OUT] == ob) break;
+        }
+        return true;
+    };
     constexpr int kDualDeclined = -12345;                        // conv_row(r, -1, r - 1): the two-source launch is not possible for this call
     std::function<int(int, int, int, int)> conv_row = [&](int r, int pend, int dual, int chain) -> int {
         const int32_t* R = &n.prog[(size_t)r * ISS_PROG_COLS];
@@ -1474,6 +1502,26 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         bool row_f16 = f16mode;                                  // cleared below where the launch has no fp16 form
         const bool in_is_hl = R[ISS_C_IN] != ISS_BUF_INPUT && hl_np.count(R[ISS_C_IN]) != 0;     // (only conv_x3_wq3h_kernel reads that layout)
         bool in_hl_taken = false;
+        if (in_is_hl && hl_dense.count(R[ISS_C_IN])) {
+            // the first dense layer on the flattened-feature CHL tensor conv4 wrote for it (want_dhl_out): both operands by LDS-DMA
+            const bool f16 = hl_f16.count(R[ISS_C_IN]) != 0;
+            const int K = R[ISS_C_CIN];
+            uint16_t*& wp = n.dhl_wp[{r, f16 ? 1 : 0}];
+            if (!wp) {
+                ISS_HIP(c, hipMalloc((void**)&wp, issk::dhl_packed_elems(K) * 2));
+                issk::iss_dhl_pack((f16 ? n.d_wh16 : n.d_wh) + R[ISS_C_WOFF], (f16 ? n.d_wl16 : n.d_wl) + R[ISS_C_WOFF], wp, R[ISS_C_COUT], n.kpad[r], K, c->stream);
+            }
+            issk::DhlArgs d;
+            d.a = reinterpret_cast<const uint16_t*>(in); d.wp = wp; d.bias = a.bias; d.out = out;
+            d.np = hl_np[R[ISS_C_IN]]; d.M = bc; d.K = K; d.Cout = R[ISS_C_COUT]; d.act = R[ISS_C_ACT];
+            iss_prof_begin(c, 0, 2.0 * K * (double)R[ISS_C_COUT] * (double)bc);
+            iss_prof_tag(c, ISS_PROF_PW);
+            iss_prof_row(c, r);
+            iss_prof_inst(c, "conv_dhl_kernel<%s>", f16 ? "true" : "false");
+            issk::iss_dhl_launch(d, c->stream, f16);
+            iss_prof_end(c);
+            return ISS_OK;
+        }
         a.mode = patch ? 2 : ((a.Cin % (x3 ? XBK : 4) == 0) ? 0 : 1);
         const bool window = R[ISS_C_INMODE] == 2;
         if (patch) {
@@ -1750,7 +1798,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             a.out_hl = 1; a.out_np = issk::chl_npad(a.M / a.pp); a.out_f16 = f16mode ? 1 : 0;
             hl_out_row = r; hl_out_np = a.out_np; hl_out_f16 = f16mode;
         }
-        auto no_chl_out = [&]() { a.out_hl = 0; a.out_np = 0; a.out_f16 = 0; if (hl_out_row == r) hl_out_row = -1; hl_out_f16 = false; };
+        auto no_chl_out = [&]() { a.out_hl = 0; a.out_np = 0; a.out_f16 = 0; if (hl_out_row == r) hl_out_row = -1; hl_out_f16 = false; hl_out_dense = false; };
         iss_prof_begin(c, 0, fl);
         iss_prof_tag(c, ws || ws_plain || ws_plain_u || ws_nh2 ? ISS_PROF_WS : fp ? ISS_PROF_FP : !x3 ? ISS_PROF_F32 : ISS_PROF_GATHER);
         iss_prof_row(c, r);
@@ -1813,6 +1861,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                     a.in_hl = 1; a.in_np = hl_np[R[ISS_C_IN]];
                     if (hl_f16.count(R[ISS_C_IN])) { a.f16 = 1; a.wh = n.d_wh16 + R[ISS_C_WOFF]; a.wl = n.d_wl16 + R[ISS_C_WOFF]; }
                     if (wq3_kind == 0 && want_hl_out(r, a.M)) { a.out_hl = 1; a.out_np = issk::chl_npad(a.M); hl_out_row = r; hl_out_np = a.out_np; }
+                    if (wq3_kind == 1 && want_dhl_out(r, a.Hq, a.Wq)) { a.out_hl = 1; a.out_np = issk::dhl_npad(bc); hl_out_row = r; hl_out_np = a.out_np; hl_out_dense = true; }
                     if (a.out_hl && a.f16) hl_out_f16 = true;
                     iss_prof_inst(c, "conv_x3_wq3h_kernel<%d,%s,%s>", wq3_kind, a.out_hl ? "true" : "false", a.f16 ? "true" : "false");     // <KIND,OUT_HL,F16>
                     issk::iss_wq3h_launch(a, qgrid, c->stream, wq3_kind);
@@ -2061,9 +2110,12 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         }
         ISS_HIP(c, hipGetLastError());
         *result = out;
-        if (hl_out_row == r) { hl_np[R[ISS_C_OUT]] = hl_out_np; if (hl_out_f16) hl_f16[R[ISS_C_OUT]] = true; else hl_f16.erase(R[ISS_C_OUT]); }
-        else { hl_np.erase(R[ISS_C_OUT]); hl_f16.erase(R[ISS_C_OUT]); }
-        hl_out_f16 = false;
+        if (hl_out_row == r) {
+            hl_np[R[ISS_C_OUT]] = hl_out_np;
+            if (hl_out_f16) hl_f16[R[ISS_C_OUT]] = true; else hl_f16.erase(R[ISS_C_OUT]);
+            if (hl_out_dense) hl_dense[R[ISS_C_OUT]] = true; else hl_dense.erase(R[ISS_C_OUT]);
+        } else { hl_np.erase(R[ISS_C_OUT]); hl_f16.erase(R[ISS_C_OUT]); hl_dense.erase(R[ISS_C_OUT]); }
+        hl_out_f16 = false; hl_out_dense = false;
         if (op != ISS_OP_CONV && R[ISS_C_IN] != ISS_BUF_INPUT && hl_np.count(R[ISS_C_IN]))
             return iss_fail(c, ISS_EINVAL, "internal: row %d reads a CHL tensor", r);
     }

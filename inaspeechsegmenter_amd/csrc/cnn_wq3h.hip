@@ -9,6 +9,7 @@ void iss_wq3h_launch(const ConvArgs& a, dim3 grid, hipStream_t st, int kind) {
     if (a.f16) return iss_wq3h_launch_f16(a, grid, st, kind);
     if (kind == 0 && a.out_hl) hipLaunchKernelGGL((conv_x3_wq3h_kernel<0, true>), grid, dim3(256), 0, st, a);
     else if (kind == 0) hipLaunchKernelGGL((conv_x3_wq3h_kernel<0, false>), grid, dim3(256), 0, st, a);
+    else if (a.out_hl) hipLaunchKernelGGL((conv_x3_wq3h_kernel<1, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_x3_wq3h_kernel<1, false>), grid, dim3(256), 0, st, a);
 }
 }  // namespace issk

@@ -109,7 +109,7 @@ struct ConvArgs {
 // npad = pixel count rounded up to 64 + one footprint (512): a footprint DMA that starts at any valid pixel stays inside its plane.
 inline unsigned chl_npad(long long npix) { return (unsigned)((npix + 63) / 64 * 64 + 512); }
 inline size_t chl_bytes(long long npix, int C) { return (size_t)chl_npad(npix) * 16u * 4u * (size_t)(C / 16); }
-constexpr size_t ISS_ACT_SLACK = 1u << 20;           // bytes every activation buffer has beyond bc * elems * 4 (the padding of a CHL tensor)
+constexpr size_t ISS_ACT_SLACK = 8u << 20;           // bytes every activation buffer has beyond bc * elems * 4 (the padding of a CHL tensor)
 inline bool chl_fits(long long npix, int C) { return C % 16 == 0 && chl_bytes(npix, C) <= (size_t)npix * C * 4 + ISS_ACT_SLACK && chl_bytes(npix, C) < 0xFFF00000ull; }
 
 // Host: magic constants of ConvArgs::dv_* for divisor d >= 1 (mul == 0 means d == 1).

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
     constexpr bool X_NOEPI = ISS_WQH_EXP & 4, X_NODMA = ISS_WQH_EXP & 128, X_NOADMA = ISS_WQH_EXP & 1, X_NOBAR = ISS_WQH_EXP & 2, X_NOFLAG = ISS_WQH_EXP & 16;      // timing-only experiment builds
     constexpr int KH = 3, KW = 3, NT = 9, G = 2;
     constexpr bool TR = KIND == 0;
-    static_assert(!OUT_HL || TR, "the CHL epilogue is written for the transposed (kind 0) accumulators");
+    // OUT_HL: kind 0 writes CHL for the next 3x3 layer; kind 1 writes the pixel-major split layout of a DENSE layer behind the flatten
+    // (conv_dhl.h)
     static_assert(wqh_lds_bytes() <= 160 * 1024, "");
     __shared__ __attribute__((aligned(4096))) unsigned char smem[wqh_lds_bytes()];     // [11 tap slots][footprint 0][footprint 1][bias][progress]
     const unsigned sB_base = (unsigned)(size_t)smem;
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
         ep.bias = q->bias; ep.out = q->out; ep.cout = q->Cout;
     }
     const unsigned out_np16 = OUT_HL ? p.out_np * 16u : 0u;
-    const unsigned out_bytes = OUT_HL ? p.out_np * (unsigned)ep.cout * 4u
-                                      : (TR ? (unsigned)M * (unsigned)ep.cout * 4u : (unsigned)(M >> 1) * (unsigned)ep.cout * 4u);
+    const unsigned out_bytes = OUT_HL && TR ? p.out_np * (unsigned)ep.cout * 4u
+                                            : (TR ? (unsigned)M * (unsigned)ep.cout * 4u : (unsigned)(M >> 1) * (unsigned)ep.cout * 4u);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(ep.out, 0, (int)out_bytes, 0x00020000);
     constexpr unsigned E_INVALID = 0xFFFF0000u;      // (the host keeps the output below 0xFFF00000 bytes)
     int rowb = ep.cout * 4;                          // bytes per output row
@@ -237,7 +238,31 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e_p1), orsrc, (int)off, (rb * 16 + 4 * g + 1) * rowb + cb * 128, 0);
         }
     };
+    // ---- kind 1, OUT_HL: the pooled output in the pixel-major split layout conv_dhl_kernel reads ("PHL"): pooled pixel P (NHWC order, so
+    // that a window's pixels x channels ARE its flattened features) = Cout / 8 groups of [hi 8 x 16 bit | lo 8 x 16 bit] = the same
+    // 4 bytes per element as f32.  Channel c of pixel P: byte P * Cout * 4 + (c >> 3) * 32 + (c & 7) * 2, lo part 16 bytes further.  The 32
+    // lanes of a unit (32 channels of one pixel) fill one 128-byte line with their hi and lo stores.
+    unsigned d_h0 = 0, d_l0 = 0, d_h1 = 0, d_l1 = 0;
+    auto epi1_split = [&]() {
+        d_h0 = cvt_pk16<F16>(e_p0, e_p0); d_h1 = cvt_pk16<F16>(e_p1, e_p1);
+        const float r0 = e_p0 - unpk16_lo<F16>(d_h0), r1 = e_p1 - unpk16_lo<F16>(d_h1);
+        d_l0 = cvt_pk16<F16>(r0, r0); d_l1 = cvt_pk16<F16>(r1, r1);
+    };
+    // vb: byte offset of (pooled row (tile * tmr + wv * 64) / 2 + 2 lh, channel n0 + li) -- hi part
+    auto epi1_c = [&](int rb, int cb, int g, unsigned vb, int tile_rows) {
+        int wr = wrow;
+        asm volatile("" : "+v"(wr), "+s"(rowb));
+        const bool ok = wr < tile_rows - (rb * 32 + 8 * g);
+        const unsigned off = ok ? vb : E_INVALID;
+        if (X_NOEPI) return;
+        // unit (rb, g): pooled rows + rb * 16 + 4 g (+ 1); channel 32 cb + li: 4 cb groups of 32 bytes further on
+        __builtin_amdgcn_raw_buffer_store_b16((short)d_h0, orsrc, (int)off, (rb * 16 + 4 * g) * rowb + cb * 128, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((short)d_l0, orsrc, (int)off, (rb * 16 + 4 * g) * rowb + cb * 128 + 16, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((short)d_h1, orsrc, (int)off, (rb * 16 + 4 * g + 1) * rowb + cb * 128, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((short)d_l1, orsrc, (int)off, (rb * 16 + 4 * g + 1) * rowb + cb * 128 + 16, 0);
+    };
     auto epi_base = [&](int tile) {
+        if (OUT_HL && !TR) return (unsigned)((tile * (TMR >> 1) + wv * 32 + 2 * lh) * ep.cout * 4 + ((n0 + li) >> 3) * 32 + ((n0 + li) & 7) * 2);
         if (OUT_HL) return ((unsigned)((n0 >> 4) * 4) * p.out_np + (unsigned)(tile * TMR + wv * 64 + li)) * 16u + (unsigned)(8 * lh);
         if (TR) return (unsigned)(((tile * TMR + wv * 64 + li) * ep.cout + n0 + 4 * lh) * 4);
         return (unsigned)(((tile * (TMR >> 1) + wv * 32 + 2 * lh) * ep.cout + n0 + li) * 4);
@@ -313,7 +338,8 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
             const unsigned sw_next = (pass & 1u) ? 0u : (unsigned)(2 * WQH_SLOT);    // taps 7, 8 of pass + 1
             unsigned vb = E_INVALID;
             int erows = 0;
-            if (EP) { vb = epi_base(etile); erows = tile_rows_of(etile); if (OUT_HL) { e_lim = erows - wrow; e_inv = E_INVALID; asm volatile("" : "+v"(e_inv)); } }
+            if (EP) { vb = epi_base(etile); erows = tile_rows_of(etile); if (OUT_HL) { e_lim = erows - wrow; e_inv = E_INVALID; asm volatile("" : "+v"(e_inv)); }
+                    }
 #pragma unroll
             for (int v = 0; v < NT; ++v) {
                 const int cs = (v + t) & 1, ns = cs ^ 1;
@@ -395,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
                             else epi0_c(erb, ecb, eg, vb, erows);
                         }
                     }
-                    if (EP && TR && OUT_HL && v <= 5) {                      // four pieces per unit, six units per step
+                    if (EP && TR && OUT_HL && v <= 5) {                      // three pieces per unit in four slots, six units per step
                         const int unit = v * 6 + s / 4;
                         if (unit < 32) {
                             const int erb = unit >> 4, ecb = (unit >> 2) & 3, eg = unit & 3;
@@ -406,7 +432,17 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
                             else epi0_c(erb, ecb, eg, vb, erows);
                         }
                     }
-                    if (EP && !TR && v <= 3 && s < 16) {                     // two pieces per unit, eight units per step
+                    if (EP && !TR && OUT_HL && v <= 5) {                     // three pieces per unit in four slots, six units per step
+                        const int unit = v * 6 + s / 4;
+                        if (unit < 32) {
+                            const int erb = unit >> 4, ecb = (unit >> 2) & 3, eg = unit & 3;
+                            const floatx16& oa = erb == 0 ? (ecb == 0 ? o00 : ecb == 1 ? o01 : ecb == 2 ? o02 : o03) : (ecb == 0 ? o10 : ecb == 1 ? o11 : ecb == 2 ? o12 : o13);
+                            if (s % 4 == 0) epi1_a(oa, ecb, eg);
+                            else if (s % 4 == 1) epi1_split();
+                            else if (s % 4 == 2) epi1_c(erb, ecb, eg, vb, erows);
+                        }
+                    }
+                    if (EP && !TR && !OUT_HL && v <= 3 && s < 16) {          // two pieces per unit, eight units per step
                         const int unit = v * 8 + s / 2;
                         const int erb = unit >> 4, ecb = (unit >> 2) & 3, eg = unit & 3;
                         const floatx16& oa = erb == 0 ? (ecb == 0 ? o00 : ecb == 1 ? o01 : ecb == 2 ? o02 : o03) : (ecb == 0 ? o10 : ecb == 1 ? o11 : ecb == 2 ? o12 : o13);
@@ -458,6 +494,7 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
             const int erb = unit >> 4, ecb = (unit >> 2) & 3, eg = unit & 3;
             const floatx16& oa = erb == 0 ? (ecb == 0 ? c100 : ecb == 1 ? c101 : ecb == 2 ? c102 : c103) : (ecb == 0 ? c110 : ecb == 1 ? c111 : ecb == 2 ? c112 : c113);
             if (TR) { epi0_a(unit); epi0_b(oa, unit); if (OUT_HL) { epi0_h(); epi0_l(); } epi0_c(erb, ecb, eg, vb, erows); }
+            else if (OUT_HL) { epi1_a(oa, ecb, eg); epi1_split(); epi1_c(erb, ecb, eg, vb, erows); }
             else { epi1_a(oa, ecb, eg); epi1_b(erb, ecb, eg, vb, erows); }
         }
     }
@@ -466,7 +503,8 @@ __global__ __launch_bounds__(256, 1) void conv_x3_wq3h_kernel(const ConvArgs p) 
 #undef ISS_WQH_SET1
 }
 
-// kind 0 = bias + relu (f32 NHWC or, a.out_hl, CHL output), kind 1 = relu + 2 x 1 max-pool (f32 output); a.in_hl is implied
+// kind 0 = bias + relu (f32 NHWC or, a.out_hl, CHL output), kind 1 = relu + 2 x 1 max-pool (f32 output or, a.out_hl, the CHL input of a
+// dense layer: conv_dhl.h); a.in_hl is implied
 void iss_wq3h_launch(const ConvArgs& a, dim3 grid, hipStream_t st, int kind);
 
 }  // namespace issk

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <unordered_map>
+#include <map>
 #include "../../include/iss.h"
 
 struct DevBuf {
@@ -26,6 +27,7 @@ struct IssNet {
     uint16_t* d_wh16 = nullptr;           // fp16 hi / lo parts (ISS_PREC_F16X3)
     uint16_t* d_wl16 = nullptr;
     bool f16_ok = false;                  // every parameter is inside fp16's range
+    std::map<std::pair<int, int>, uint16_t*> dhl_wp;   // (row, fp16?) -> the dense layer's weights packed for conv_dhl_kernel (built at first use)
     float* d_wsum = nullptr;              // patch-mode first layers: sum_k w[c][k] per output channel (shared first layer)
     std::vector<int64_t> wsum_off;        // per row: offset into d_wsum, -1 = none
     std::vector<int64_t> wsumx_off;       // per row: offset of S[W][Cout] (zero-padded first layers: per-column weight sums), -1 = none
