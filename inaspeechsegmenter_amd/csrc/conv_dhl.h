@@ -1,5 +1,5 @@
-// conv_dhl_kernel: the segmenter nets' first dense layer (K = 4992 / 8320 -> 192) as a GEMM whose BOTH operands arrive by LDS-DMA
-// -- round 6.
+// conv_dhl_kernel: the segmenter nets' first dense layer (K = 4992 / 8320 -> 192) as a GEMM whose BOTH operands arrive pre-split, in the
+// order the LDS tiles want them -- round 6.
 //
 // conv_x3_pw_kernel runs that layer at 0.075 of the roofline: a timing-only build whose activation loads all hit L2 is no faster
 // (profiles/HISTORY.md, round 6), so it is not memory -- it is the structure: per 32-wide k-tile every thread converts four
@@ -7,14 +7,13 @@
 // staged through registers:
 //   * A: conv_x3_wq3h_kernel<1, true, ..> (conv4) writes its pooled output pixel-major but already split ("PHL": per pixel Cout / 8
 //     groups of [hi 8 x 16 bit | lo 8 x 16 bit]; pixels in NHWC order, so a window's pixels x channels are its flattened features and a
-//     32-feature k-tile of a window is ONE 128-byte line; the producer's 32 lanes fill such a line with their hi and lo stores).  One
-//     global_load_lds_dwordx4 fetches the k-tile of EIGHT windows (8 lanes per line); in LDS a window's line keeps its eight 16-byte
-//     pieces at slot = piece ^ (window & 7) (swizzle on the SOURCE side: lane (row, slot) asks for piece slot ^ (row & 7)), so that
-//     the 16 lanes of a fragment read spread over the bank groups;
+//     32-feature k-tile of a window is ONE 128-byte line; the producer's 32 lanes fill such a line with their hi and lo stores).  Eight
+//     threads fetch a window's line; in LDS it keeps its eight 16-byte pieces at slot = piece ^ (window & 7) (the thread of
+//     (row, slot) loads piece slot ^ (row & 7)), so that the 16 lanes of a fragment read spread over the bank groups;
 //   * B: the layer's weights, split into 16-bit halves and packed ONCE per network (dhl_pack_kernel) in the order a k-tile's LDS image
 //     wants them -- [k-tile of 32][k-group of 8][hi | lo][column][8 x 16 bit] -- so a k-tile is 24 KB of contiguous memory;
-//   * a three-stage LDS ring of 40 KB k-tiles (16 KB of A + 24 KB of B), two k-tiles in flight, counted vmcnt, one barrier per
-//     k-tile = per 36 MFMAs of a wave; 128 rows x 192 columns per workgroup (one per CU; a launch of ~30 k windows = 235 tiles),
+//   * 40 KB k-tiles (16 KB of A + 24 KB of B) in a double buffer, loaded two k-tiles ahead, one barrier per k-tile = per 36 MFMAs of a
+//     wave (the first version moved them by LDS-DMA and ran at a CU's DMA fill rate, ~31 GB/s: see the kernel); 128 rows x 192 columns per workgroup (one per CU; a launch of ~30 k windows = 235 tiles),
 //     four waves as 2 x 2 (64 rows x 96 columns each: 6 accumulators, 10 fragment reads per 18 MFMAs).
 // Term and k order per output = conv_x3_pw_kernel's (lo.hi, hi.lo, hi.hi per k16 step, k ascending): bit-identical results.
 #pragma once
@@ -26,7 +25,6 @@ constexpr int DHL_BM = 128, DHL_BN = 192, DHL_BK = 32;
 constexpr int DHL_A = DHL_BM * DHL_BK * 4;         // 16 KB: 128 rows x 128 B (8 pieces (k-group, part) of 16 B, swizzled by row & 7)
 constexpr int DHL_B = DHL_BN * DHL_BK * 4;         // 24 KB: 8 planes x 192 columns x 16 B
 constexpr int DHL_STAGE = DHL_A + DHL_B;           // 40 KB
-constexpr int DHL_NSTAGE = 3;
 
 struct DhlArgs {
     const uint16_t* a;       // PHL tensor: [window][K / 8 groups][hi 8 | lo 8] x 16 bit (K * 4 bytes per window)
@@ -39,7 +37,11 @@ struct DhlArgs {
 
 template <bool F16>
 __global__ __launch_bounds__(256, 1) void conv_dhl_kernel(const DhlArgs p) {
-    __shared__ __attribute__((aligned(4096))) unsigned char smem[DHL_NSTAGE * DHL_STAGE];
+    // v2: the first version fetched both operands by LDS-DMA into a three-stage ring and ran at the LDS-DMA fill rate of a CU
+    // (40 KB per k-tile at ~31 GB/s = 1.3 us against 0.6 us of MFMAs: MI355X_MICROARCH.md "ldsdma-fill").  The operands are pre-split, so
+    // the register path costs no conversion either: ten 16-byte global loads per thread and k-tile, two k-tiles ahead, ten
+    // ds_write_b128 into a double buffer -- the load / store path is several times wider than the DMA path.
+    __shared__ __attribute__((aligned(4096))) unsigned char smem[2 * DHL_STAGE];
     const unsigned s0 = (unsigned)(size_t)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -49,26 +51,40 @@ __global__ __launch_bounds__(256, 1) void conv_dhl_kernel(const DhlArgs p) {
     const int nk = p.K / DHL_BK;
     const unsigned rowbytes = (unsigned)p.K * 4u;                       // bytes per window
 
-    // ---- one k-tile into ring slot `slot`: wave w issues A pieces w, w + 4, .. (16 of 1 KB = 8 windows x 128 B each) and B pieces
-    // w, w + 4, .. (24 of 1 KB, contiguous in the packed weights).  A lane of an A piece: window 8 piece + (lane >> 3), LDS slot lane & 7
-    // <- source piece (lane & 7) ^ (window & 7)
-    const unsigned a_lane = (unsigned)(m0 + (lane >> 3)) * rowbytes + (unsigned)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
-    auto load_tile = [&](int kt, int slot) {
-        const unsigned dst = s0 + (unsigned)(slot * DHL_STAGE);
+    // ---- staging: thread t moves A pieces t, t + 256, .. (4 of the tile's 1024: window i >> 3, LDS slot i & 7 <- source piece
+    // (i & 7) ^ (window & 7): the swizzle of the fragment reads below) and B pieces t, t + 256, .. (6 of 1536, a straight copy)
+    unsigned a_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + 256 * j, row = i >> 3, slot = i & 7;
+        a_src[j] = (unsigned)(m0 + row) * rowbytes + (unsigned)((slot ^ (row & 7)) * 16);
+#if defined(ISS_DHL_EXP) && (ISS_DHL_EXP & 1)                            // timing-only: every A load from the tile's first 16 KB (cache hits)
+        a_src[j] = (unsigned)(blockIdx.x & 63) * 16384u + (unsigned)(i * 16);
+#endif
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 __attribute__((address_space(3)))* LdsW16;
+    struct Regs { u32x4 a[4], b[6]; };
+    auto gather = [&](Regs& r, int kt) {
         const unsigned char* ab = reinterpret_cast<const unsigned char*>(p.a) + (size_t)kt * 128;               // 128 B per window and k-tile
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int piece = wv + 4 * j;                               // 0..15: windows 8 piece .. 8 piece + 7 of the tile
-            glds16_m0(ab, a_lane + (unsigned)(piece * 8) * rowbytes,
-                      (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)(piece * 1024))));
-        }
         const unsigned char* bb = reinterpret_cast<const unsigned char*>(p.wp) + (size_t)kt * DHL_B;
+#if defined(ISS_DHL_EXP) && (ISS_DHL_EXP & 1)
+        ab = reinterpret_cast<const unsigned char*>(p.a);
+#endif
+#if defined(ISS_DHL_EXP) && (ISS_DHL_EXP & 2)                            // timing-only: every B load from the first k-tile
+        bb = reinterpret_cast<const unsigned char*>(p.wp);
+#endif
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int piece = wv + 4 * j;                               // 0..23
-            glds16_m0(bb, (unsigned)(piece * 1024 + lane * 16),
-                      (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)(DHL_A + piece * 1024))));
-        }
+        for (int j = 0; j < 4; ++j) r.a[j] = *reinterpret_cast<const u32x4*>(ab + a_src[j]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) r.b[j] = *reinterpret_cast<const u32x4*>(bb + (unsigned)((tid + 256 * j) * 16));
+    };
+    auto stage = [&](Regs& r, int buf) {
+        const unsigned dst = s0 + (unsigned)(buf * DHL_STAGE) + (unsigned)(tid * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(LdsW16)(dst + (unsigned)(j * 4096)) = r.a[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *(LdsW16)(dst + (unsigned)(DHL_A + j * 4096)) = r.b[j];
     };
 
     floatx16 acc[2][3];
@@ -85,40 +101,63 @@ __global__ __launch_bounds__(256, 1) void conv_dhl_kernel(const DhlArgs p) {
     const unsigned a_rd = (unsigned)((wr * 64 + li) * 128 + (((2 * lh) ^ (li & 7)) * 16));
     const unsigned b_rd = (unsigned)(DHL_A + (wc * 96 + li) * 16 + lh * 2 * 3072);
 
-    load_tile(0, 0);
-    if (nk > 1) load_tile(1, 1);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int slot = kt % DHL_NSTAGE;
-        // this wave's 10 pieces of k-tile kt have landed (the 10 of kt + 1 may still fly); then every wave's have, and nobody reads
-        // the slot k-tile kt + 2 goes into (it held kt - 1) any more
-        if (kt + 1 < nk) wait_vmcnt<10>(); else wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) load_tile(kt + 2, (kt + 2) % DHL_NSTAGE);
-        const unsigned st = s0 + (unsigned)(slot * DHL_STAGE);
+    // One wave per SIMD: nobody else hides an LDS round trip, so the fragments of BOTH k16 steps are requested up front (the second
+    // set lands behind the first set's 18 MFMAs) instead of read - wait - use three registers at a time (hipcc's own order for this
+    // loop: the matrix pipe 20 % busy).  The staging stores of the next k-tile ride between the two MFMA blocks.
+    struct Frag { bf16x8 ah[2], al[2], bh[3], bl[3]; };
+    auto read_frags = [&](Frag& f, unsigned st, int ks) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 ah[2], al[2], bh[3], bl[3];
+        for (int r = 0; r < 2; ++r) {
+            f.ah[r] = *(LdsR16)(st + ((a_rd + (unsigned)(r * 32 * 128)) ^ (unsigned)(ks * 4 * 16)));
+            f.al[r] = *(LdsR16)(st + ((a_rd + (unsigned)(r * 32 * 128)) ^ (unsigned)(ks * 4 * 16 + 16)));
+        }
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                ah[r] = *(LdsR16)(st + ((a_rd + (unsigned)(r * 32 * 128)) ^ (unsigned)(ks * 4 * 16)));
-                al[r] = *(LdsR16)(st + ((a_rd + (unsigned)(r * 32 * 128)) ^ (unsigned)(ks * 4 * 16 + 16)));
-            }
+        for (int c = 0; c < 3; ++c) {
+            f.bh[c] = *(LdsR16)(st + b_rd + (unsigned)(ks * 4 * 3072 + c * 32 * 16));
+            f.bl[c] = *(LdsR16)(st + b_rd + (unsigned)(ks * 4 * 3072 + 3072 + c * 32 * 16));
+        }
+    };
+    // C^T as conv_x3_pw_kernel computes it (rows = columns of the layer, columns = windows): the same products in the same order per
+    // accumulator (lo.hi, hi.lo, hi.hi per k16 step); term outermost, so that an accumulator's MFMAs are six issues apart
+    auto mfmas = [&](const Frag& f) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                bh[c] = *(LdsR16)(st + b_rd + (unsigned)(ks * 4 * 3072 + c * 32 * 16));
-                bl[c] = *(LdsR16)(st + b_rd + (unsigned)(ks * 4 * 3072 + 3072 + c * 32 * 16));
-            }
-            // C^T as conv_x3_pw_kernel computes it (rows = columns of the layer, columns = windows): the same products in the same order
+        for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    acc[r][c] = mfma_x3<F16>(bh[c], al[r], acc[r][c]);
-                    acc[r][c] = mfma_x3<F16>(bl[c], ah[r], acc[r][c]);
-                    acc[r][c] = mfma_x3<F16>(bh[c], ah[r], acc[r][c]);
-                }
-        }
+                for (int c = 0; c < 3; ++c)
+                    acc[r][c] = mfma_x3<F16>(term == 1 ? f.bl[c] : f.bh[c], term == 0 ? f.al[r] : f.ah[r], acc[r][c]);
+    };
+
+    // two register sets: a k-tile's loads are issued two steps before they are written to LDS (past the last k-tile: re-reads it)
+    Regs r0, r1;
+    gather(r0, 0);
+    gather(r1, nk > 1 ? 1 : 0);
+    stage(r0, 0);
+    __syncthreads();
+    int kt = 0;
+    auto step = [&](Regs& rload, Regs& rstage, int cur) {               // loads for kt + 2, MFMAs on kt, k-tile kt + 1 into the other buffer
+        const unsigned st = s0 + (unsigned)(cur * DHL_STAGE);
+        Frag f0, f1;
+        read_frags(f0, st, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        gather(rload, kt + 2 < nk ? kt + 2 : nk - 1);
+        read_frags(f1, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(rstage, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        ++kt;
+    };
+    while (true) {
+        step(r0, r1, 0);
+        if (kt >= nk) break;
+        step(r1, r0, 1);
+        if (kt >= nk) break;
     }
     // ---- epilogue.  Transposed accumulators: lane li = window (row of the GEMM) m0 + wr * 64 + r * 32 + li; register 4 g + i of
     // accumulator c = column wc * 96 + c * 32 + 8 g + 4 lh + i: bias, relu, one float4 per (c, g)
