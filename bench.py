@@ -1192,11 +1192,12 @@ def main():
             line["cpu_baseline"] = cpu
             line["parity_check"] = par
         # precision guard (include/iss.h iss_set_precision_guard): what the library measured on the weights in use at their first call
-        line["precision_guard"] = {"threshold_dlogp": getattr(seg.ctx, 'guard_threshold', 5e-4),
+        line["precision_guard"] = {"threshold_dlogp": getattr(seg.ctx, 'guard_threshold', None) or 5e-4,
                                    "vad": seg.ctx.cnn_precision_info(seg.vad.net_id),
                                    "gender": seg.ctx.cnn_precision_info(seg.gender.net_id) if seg.detect_gender else None,
-                                   "what": "max |log p(split bf16) - log p(exact f32)| over up to 256 windows of each network's first "
-                                           "call; above the threshold the library switches that network to exact f32 (north star: within 1e-3)"}
+                                   "what": "max |log p(split 16-bit operands) - log p(exact f32)| over up to 256 windows of each network's "
+                                           "first call, measured by the library; above the threshold it switches that network to the other "
+                                           "split mode or, failing that, to exact f32 (north star: within 1e-3)"}
         if companions:
             line["companions"] = companions
         print(json.dumps(line))

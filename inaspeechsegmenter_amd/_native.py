@@ -388,8 +388,8 @@ class Context:
         self.precision = int(mode)
 
     def set_precision_guard(self, threshold):
-        """Precision guard (include/iss.h): max |d log p| between the split-bf16 and the exact-f32 arithmetic above which a
-        patch network's first call switches it to exact f32; <= 0 turns the probe off.  Default 5e-4."""
+        """Precision guard (include/iss.h): max |d log p| between the split-operand and the exact-f32 arithmetic above which a
+        patch network's first call switches it to the other split mode or to exact f32; <= 0 turns the probe off.  Default 5e-4."""
         self._ck(self._L.iss_set_precision_guard(self._h, float(threshold)), 'iss_set_precision_guard')
         self.guard_threshold = float(threshold)
 
