@@ -41,6 +41,35 @@ def split(x, kind):
     return h, l
 
 
+_MX = {'e4m3': (3, -6, 448.0), 'e5m2': (2, -14, 57344.0), 'e2m3': (3, 0, 7.5), 'e3m2': (2, -2, 28.0)}
+
+
+def mxq(x, dim, fmt, block=32, scaled=True):
+    """x (float64 tensor) rounded to an OCP 8- / 6-bit float `fmt` with one power-of-two scale per `block` consecutive elements
+    along `dim` (v_mfma_scale_f32_32x32x64_f8f6f4's E8M0 scale per lane = per row and 32-wide K block); the scale is the smallest
+    power of two that keeps the block's largest magnitude representable (no saturation).  scaled=False: scale 1 everywhere."""
+    import torch
+    m, emin, vmax = _MX[fmt]
+    x = x.movedim(dim, -1)
+    n = x.shape[-1]
+    pad = (-n) % block
+    if pad:
+        x = torch.nn.functional.pad(x, (0, pad))
+    xb = x.reshape(x.shape[:-1] + (-1, block))
+    if scaled:
+        amax = xb.abs().amax(-1, keepdim=True)
+        sc = torch.exp2(torch.ceil(torch.log2(torch.clamp(amax, min=1e-300) / vmax)))
+        sc = torch.where(amax > 0, sc, torch.ones_like(sc))
+    else:
+        sc = torch.ones_like(xb[..., :1])
+    y = xb / sc
+    e = torch.floor(torch.log2(torch.clamp(y.abs(), min=1e-300)))
+    ulp = torch.exp2(torch.clamp(e, min=emin) - m)
+    q = torch.clamp(torch.round(y / ulp) * ulp, -vmax, vmax) * sc      # round half to even like the cvt instructions
+    q = q.reshape(x.shape)[..., :n]
+    return q.movedim(-1, dim)
+
+
 def _same_pad(size, k, s):
     """Keras 'same': total = max((ceil(size / s) - 1) * s + k - size, 0), the smaller half in front."""
     total = max((-(-size // s) - 1) * s + k - size, 0)
@@ -115,7 +144,17 @@ def forward_mode(folded, x, mode, batch=256):
                     else:
                         ah, al = split(a32, kind)
                         wh, wl = split(w, kind)
-                        if mode.endswith('x3') or mode.startswith('f16x3_tail') or '_last' in mode:
+                        if mode.startswith('f16mx'):
+                            # hi.hi in fp16; the two cross terms with BOTH operands in a block-scaled 8- / 6-bit float
+                            fmt = {'f16mx8': 'e4m3', 'f16mx8u': 'e5m2', 'f16mx6': 'e2m3', 'f16mx6b': 'e3m2'}[mode]
+                            sc_ = mode != 'f16mx8u'
+                            cd = 1 if ty == 'conv2d' else a32.dim() - 1
+                            wd = 2 if ty == 'conv2d' else 0
+                            if ty == 'dense' and a32.shape[-1] % 32:
+                                raise ValueError('K % 32')
+                            y = op(ah, wh) + op(mxq(al, cd, fmt, scaled=sc_), mxq(wh, wd, fmt, scaled=sc_)) \
+                                + op(mxq(ah, cd, fmt, scaled=sc_), mxq(wl, wd, fmt, scaled=sc_))
+                        elif mode.endswith('x3') or mode.startswith('f16x3_tail') or '_last' in mode:
                             y = op(ah, wh) + op(al, wh) + op(ah, wl)
                         elif mode.endswith('x2_w'):
                             y = op(ah + al, wh)
