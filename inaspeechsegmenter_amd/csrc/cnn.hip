@@ -919,8 +919,9 @@ __global__ void pool_kernel(const float* __restrict__ in, float* __restrict__ ou
             ++cnt;
         }
     }
-    out[idx] = kind == 0 ? acc : acc / (float)(kh * kw);
-    (void)cnt;
+    // average: over the window's elements INSIDE the input -- kh * kw unless the pool is zero-padded (Keras / TF 'same' average
+    // pooling leaves the padding out of the mean)
+    out[idx] = kind == 0 ? acc : acc / (float)(cnt > 0 ? cnt : 1);
 }
 
 
@@ -942,6 +943,32 @@ __global__ __launch_bounds__(256) void act_kernel(const float* in, float* out, l
         reinterpret_cast<float4*>(out)[i] = v;
     }
     for (long long i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) out[i] = f(in[i]);
+}
+
+// Merge / data-movement rows of graph-shaped models (ISS_OP_ELT, include/iss.h): one thread per output element, grid-stride.  `in`,
+// `res` and `out` may alias for the binary kinds (each element is read before it is written, by the same thread).
+__global__ __launch_bounds__(256) void elt_kernel(const float* in, const float* res, float* out, long long total, int kind,
+                                                  int cin, int cout, int nch, int soff, int doff, int d0, int d1, int d2,
+                                                  int s0, int s1, int s2) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        if (kind >= ISS_ELT_ADD && kind <= ISS_ELT_AVG) {
+            const float a = in[i], b = res[i];
+            out[i] = kind == ISS_ELT_ADD ? a + b : kind == ISS_ELT_SUB ? a - b : kind == ISS_ELT_MUL ? a * b :
+                     kind == ISS_ELT_MAX ? fmaxf(a, b) : kind == ISS_ELT_MIN ? fminf(a, b) : (a + b) * 0.5f;
+        } else if (kind == ISS_ELT_COPY || kind == ISS_ELT_ZERO) {       // total = pixels * nch
+            const long long p = i / nch;
+            const int ch = (int)(i - p * nch);
+            out[p * cout + doff + ch] = kind == ISS_ELT_ZERO ? 0.f : in[p * cin + soff + ch];
+        } else {                                                         // PERMUTE: output (d0, d1, d2) row-major per sample, input strides s0..s2
+            const long long per = (long long)d0 * d1 * d2;
+            const long long smp = i / per;
+            long long r = i - smp * per;
+            const int i2 = (int)(r % d2); r /= d2;
+            const int i1 = (int)(r % d1);
+            const int i0 = (int)(r / d1);
+            out[i] = in[smp * per + (long long)i0 * s0 + (long long)i1 * s1 + (long long)i2 * s2];
+        }
+    }
 }
 
 __global__ void softmax_kernel(const float* __restrict__ in, float* __restrict__ out, long long rows, int C) {
@@ -1100,6 +1127,31 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
         } else if (R[ISS_C_OP] == ISS_OP_ACT) {
             if (R[ISS_C_ACT] < 4 || R[ISS_C_ACT] > 8) return bad("ISS_OP_ACT: activation code must be 4 (elu), 5 (leaky relu), 6 (selu), 7 (softplus) or 8 (relu with max_value)");
             if (R[ISS_C_IN] == ISS_BUF_INPUT) return bad("ISS_OP_ACT: an elementwise activation cannot read the network input (it works in place)");
+        } else if (R[ISS_C_OP] == ISS_OP_ELT) {
+            const int k = R[ISS_C_ACT];
+            const long long hw = (long long)R[ISS_C_H] * R[ISS_C_W];
+            if (k < ISS_ELT_COPY || k > ISS_ELT_PERMUTE) return bad("ISS_OP_ELT: unknown kind");
+            if (R[ISS_C_HO] < 1 || R[ISS_C_WO] < 1 || R[ISS_C_COUT] < 1 || R[ISS_C_CIN] < 1 || hw < 1) return bad("ISS_OP_ELT: shape");
+            if ((long long)R[ISS_C_HO] * R[ISS_C_WO] * R[ISS_C_COUT] > buf_elems[R[ISS_C_OUT]]) return bad("ISS_OP_ELT: output larger than its buffer");
+            if (R[ISS_C_IN] != ISS_BUF_INPUT && k != ISS_ELT_ZERO && hw * R[ISS_C_CIN] > buf_elems[R[ISS_C_IN]]) return bad("ISS_OP_ELT: input larger than its buffer");
+            if (R[ISS_C_IN] == ISS_BUF_INPUT && k != ISS_ELT_ZERO) return bad("ISS_OP_ELT: a merge row cannot read the network input");
+            if (k >= ISS_ELT_ADD && k <= ISS_ELT_AVG) {
+                if (R[ISS_C_RES] < 0 || R[ISS_C_RES] >= nbuf) return bad("ISS_OP_ELT: a binary row needs its second operand in ISS_C_RES");
+                if (R[ISS_C_HO] != R[ISS_C_H] || R[ISS_C_WO] != R[ISS_C_W] || R[ISS_C_COUT] != R[ISS_C_CIN]) return bad("ISS_OP_ELT: binary rows keep the shape");
+                if (hw * R[ISS_C_CIN] > buf_elems[R[ISS_C_RES]]) return bad("ISS_OP_ELT: second operand larger than its buffer");
+            } else if (k == ISS_ELT_COPY || k == ISS_ELT_ZERO) {
+                if (R[ISS_C_HO] != R[ISS_C_H] || R[ISS_C_WO] != R[ISS_C_W]) return bad("ISS_OP_ELT: COPY / ZERO keep the pixel grid");
+                if (R[ISS_C_KH] < 1 || R[ISS_C_PL] < 0 || R[ISS_C_PL] + R[ISS_C_KH] > R[ISS_C_COUT]) return bad("ISS_OP_ELT: destination channel range outside COUT");
+                if (k == ISS_ELT_COPY && (R[ISS_C_PT] < 0 || R[ISS_C_PT] + R[ISS_C_KH] > R[ISS_C_CIN] || R[ISS_C_IN] == R[ISS_C_OUT]))
+                    return bad("ISS_OP_ELT: COPY source channel range outside CIN, or IN == OUT");
+            } else {
+                const int pm[3] = {R[ISS_C_KH], R[ISS_C_KW], R[ISS_C_SH]};
+                const int dims[3] = {R[ISS_C_H], R[ISS_C_W], R[ISS_C_CIN]};
+                if (pm[0] < 0 || pm[0] > 2 || pm[1] < 0 || pm[1] > 2 || pm[2] < 0 || pm[2] > 2 || pm[0] == pm[1] || pm[0] == pm[2] || pm[1] == pm[2])
+                    return bad("ISS_OP_ELT: PERMUTE needs a permutation of (0, 1, 2) in KH, KW, SH");
+                if (R[ISS_C_HO] != dims[pm[0]] || R[ISS_C_WO] != dims[pm[1]] || R[ISS_C_COUT] != dims[pm[2]] || R[ISS_C_IN] == R[ISS_C_OUT])
+                    return bad("ISS_OP_ELT: PERMUTE output shape is not the permuted input shape, or IN == OUT");
+            }
         } else if (R[ISS_C_OP] != ISS_OP_POOL && R[ISS_C_OP] != ISS_OP_SOFTMAX && R[ISS_C_OP] != ISS_OP_STATPOOL) {
             return bad("unknown op");
         }
@@ -2100,6 +2152,23 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             iss_prof_begin(c, 2, 0);
             hipLaunchKernelGGL(act_kernel, dim3((unsigned)std::min<long long>((total + 1023) / 1024, 1 << 20)), dim3(256), 0, c->stream, in, out, total,
                                R[ISS_C_ACT], alpha);
+            iss_prof_end(c);
+        } else if (op == ISS_OP_ELT) {
+            const int k = R[ISS_C_ACT];
+            const long long hw = (long long)R[ISS_C_H] * R[ISS_C_W];
+            const bool chan = k == ISS_ELT_COPY || k == ISS_ELT_ZERO;
+            const long long total = (long long)bc * hw * (chan ? R[ISS_C_KH] : R[ISS_C_CIN]);
+            const float* res = R[ISS_C_RES] >= 0 ? (const float*)c->act[R[ISS_C_RES]].p : nullptr;
+            if (res && hl_np.count(R[ISS_C_RES])) return iss_fail(c, ISS_EINVAL, "internal: row %d reads a CHL tensor", r);
+            int st[3] = {0, 0, 0};
+            if (k == ISS_ELT_PERMUTE) {
+                const int sin[3] = {R[ISS_C_W] * R[ISS_C_CIN], R[ISS_C_CIN], 1};
+                st[0] = sin[R[ISS_C_KH]]; st[1] = sin[R[ISS_C_KW]]; st[2] = sin[R[ISS_C_SH]];
+            }
+            iss_prof_begin(c, 2, 0);
+            hipLaunchKernelGGL(elt_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 1 << 20)), dim3(256), 0, c->stream, in, res, out,
+                               total, k, R[ISS_C_CIN], R[ISS_C_COUT], R[ISS_C_KH], R[ISS_C_PT], R[ISS_C_PL],
+                               R[ISS_C_HO], R[ISS_C_WO], R[ISS_C_COUT], st[0], st[1], st[2]);
             iss_prof_end(c);
         } else if (op == ISS_OP_STATPOOL) {
             const long long total = (long long)bc * R[ISS_C_H] * R[ISS_C_CIN];

@@ -61,17 +61,20 @@ def layers_from_keras_config(model_config, weights):
     klayers = cfg['layers'] if isinstance(cfg, dict) else cfg
     if cls not in ('Sequential', 'Model', 'Functional'):
         raise NotImplementedError(f"Keras model class {cls!r}")
-    if cls != 'Sequential':
-        # accept functional models that are a plain chain
-        for i, kl in enumerate(klayers[1:], 1):
-            inb = kl.get('inbound_nodes', [])
-            names = json.dumps(inb)
-            if names.count(klayers[i - 1]['config']['name']) < 1:
-                raise NotImplementedError("only linear-chain functional models are supported")
+    functional = cls != 'Sequential'
+    inbound = {}                                    # Keras layer name -> names of the layers it reads (functional models)
+    if functional:
+        for kl in klayers:
+            inbound[kl['config'].get('name', kl.get('name'))] = _inbound_names(kl)
+        if isinstance(cfg, dict) and (len(cfg.get('input_layers', [0])) != 1 or len(_flat_refs(cfg.get('output_layers', [0]))) > 1):
+            raise NotImplementedError("models with several inputs or outputs: the segmenter networks have one of each")
     layers, in_shape = [], None
+    produced = {}                                   # Keras layer name -> (first, last) index into `layers` (None: an InputLayer)
     for kl in klayers:
         cn, c = kl['class_name'], kl['config']
         name = c.get('name')
+        n_before = len(layers)
+        produced[name] = None
         if in_shape is None and c.get('batch_input_shape') is not None:
             in_shape = tuple(int(v) for v in c['batch_input_shape'][1:])
         if in_shape is None and c.get('batch_shape') is not None:
@@ -90,6 +93,7 @@ def layers_from_keras_config(model_config, weights):
             if c.get('data_format', 'channels_last') != 'channels_last':
                 raise NotImplementedError('channels_first ZeroPadding2D')
             layers.append(dict(type='zeropad', name=name, pad=zp))
+            produced[name] = (n_before, n_before)
             continue
         if cn in ('Conv2D', 'Convolution2D'):
             if c.get('data_format', 'channels_last') != 'channels_last':
@@ -160,21 +164,59 @@ def layers_from_keras_config(model_config, weights):
             layers.append(dict(type='globalmaxpool', name=name))
         elif cn == 'Flatten':
             layers.append(dict(type='flatten', name=name))
-        elif cn in ('Dropout', 'SpatialDropout2D', 'GaussianNoise', 'GaussianDropout', 'AlphaDropout'):
+        elif cn in ('Dropout', 'SpatialDropout2D', 'GaussianNoise', 'GaussianDropout', 'AlphaDropout', 'ActivityRegularization'):
             layers.append(dict(type='dropout', name=name))
+        elif cn == 'Reshape':
+            layers.append(dict(type='reshape', name=name, target=tuple(int(v) for v in c['target_shape'])))
+        elif cn == 'Permute':                       # dims are 1-based over the non-batch axes; stored activations are (H, W, C)
+            dims = tuple(int(v) for v in c['dims'])
+            if sorted(dims) == [1]:
+                layers.append(dict(type='dropout', name=name))
+            elif sorted(dims) == [1, 2, 3]:
+                layers.append(dict(type='permute', name=name, perm=tuple(d - 1 for d in dims)))
+            else:
+                raise NotImplementedError(f"Permute{dims}: the op program stores (H, W, C) activations")
+        elif cn in ('Add', 'Subtract', 'Multiply', 'Average', 'Maximum', 'Minimum', 'Concatenate'):
+            if not functional:
+                raise ValueError(f"{cn} in a Sequential model")
+            layers.append(dict(type=cn.lower(), name=name, **({'axis': int(c.get('axis', -1))} if cn == 'Concatenate' else {})))
         else:
             raise NotImplementedError(f"Keras layer {cn!r} ({name}) is not supported by the op program")
+        if len(layers) > n_before:
+            produced[name] = (n_before, len(layers) - 1)
+    if functional and not _wire_graph(layers, klayers, inbound, produced):
+        functional = False                          # a plain chain in list order: the sequential lowering takes it
     # ZeroPadding2D -> explicit padding of the Conv2D right behind it (the only place the op program can express it)
     merged = []
-    for L in layers:
+    if functional:                                  # graph: the padding layer's one reader must be that convolution
+        byname = {L['name']: L for L in layers}
+        nread = {}
+        for L in layers:
+            for nm in L['inputs']:
+                nread[nm] = nread.get(nm, 0) + 1
+        for L in layers:
+            if L['type'] == 'zeropad':
+                continue
+            src = byname.get(L['inputs'][0]) if len(L['inputs']) == 1 else None
+            if src is not None and src['type'] == 'zeropad':
+                if L['type'] != 'conv2d' or L.get('padding', 'valid') != 'valid' or nread[src['name']] != 1:
+                    raise NotImplementedError(f"ZeroPadding2D ({src['name']}) must be read by one Conv2D(padding='valid') only")
+                L = dict(L, pad=src['pad'], inputs=list(src['inputs']))
+            if any(byname.get(nm, {}).get('type') == 'zeropad' for nm in L['inputs']):
+                raise NotImplementedError(f"ZeroPadding2D in front of {L['name']} ({L['type']})")
+            merged.append(L)
+        if any(L['type'] == 'zeropad' and not nread.get(L['name']) for L in layers):
+            raise NotImplementedError('ZeroPadding2D at the end of the model')
+    else:
+        for L in layers:
+            if merged and merged[-1]['type'] == 'zeropad':
+                z = merged.pop()
+                if L['type'] != 'conv2d' or L.get('padding', 'valid') != 'valid':
+                    raise NotImplementedError(f"ZeroPadding2D ({z['name']}) must be followed by a Conv2D(padding='valid')")
+                L = dict(L, pad=z['pad'])
+            merged.append(L)
         if merged and merged[-1]['type'] == 'zeropad':
-            z = merged.pop()
-            if L['type'] != 'conv2d' or L.get('padding', 'valid') != 'valid':
-                raise NotImplementedError(f"ZeroPadding2D ({z['name']}) must be followed by a Conv2D(padding='valid')")
-            L = dict(L, pad=z['pad'])
-        merged.append(L)
-    if merged and merged[-1]['type'] == 'zeropad':
-        raise NotImplementedError('ZeroPadding2D at the end of the model')
+            raise NotImplementedError('ZeroPadding2D at the end of the model')
     layers = merged
     if in_shape is None:
         raise ValueError("model_config carries no batch_input_shape")
@@ -183,6 +225,71 @@ def layers_from_keras_config(model_config, weights):
     if len(in_shape) != 3:
         raise NotImplementedError(f"input shape {in_shape}: need (H, W, C) or (C,)")
     return layers, in_shape
+
+
+def _flat_refs(o):
+    """[name, node, tensor] references in a Keras config value (`input_layers` / `output_layers`: one reference or a list of them)."""
+    if isinstance(o, (list, tuple)):
+        if len(o) >= 3 and isinstance(o[0], str) and isinstance(o[1], int) and isinstance(o[2], int):
+            return [o[0]]
+        return [r for v in o for r in _flat_refs(v)]
+    return []
+
+
+def _inbound_names(kl):
+    """Names of the layers whose outputs a functional-model layer reads.  Keras 2 writes `inbound_nodes` as
+    [[[name, node, tensor, kwargs], ...]], Keras 3 as [{'args': [<__keras_tensor__ with keras_history [name, node, tensor]> | list
+    of them], 'kwargs': {...}}]; a layer called more than once (a shared layer) has several nodes."""
+    inb = kl.get('inbound_nodes', [])
+    if not inb:
+        return []
+    if len(inb) > 1:
+        raise NotImplementedError(f"layer {kl['config'].get('name')!r} is called {len(inb)} times (shared layers are not lowered)")
+    names = []
+
+    def walk(o):
+        if isinstance(o, dict):
+            if o.get('class_name') == '__keras_tensor__':
+                names.append(o['config']['keras_history'][0])
+                return
+            for v in o.values():
+                walk(v)
+        elif isinstance(o, (list, tuple)):
+            if len(o) >= 3 and isinstance(o[0], str) and isinstance(o[1], int) and isinstance(o[2], int):
+                names.append(o[0])
+                return
+            for v in o:
+                walk(v)
+    walk(inb[0])
+    return names
+
+
+def _wire_graph(layers, klayers, inbound, produced):
+    """Give every parsed layer of a functional model its 'inputs' (names of parsed layers, GRAPH_INPUT for the InputLayer).  Returns
+    False -- and leaves the list untouched -- when the model is a plain chain in list order."""
+    def out_name(kname):                            # parsed layer that carries a Keras layer's output
+        if kname not in produced:
+            raise ValueError(f"inbound layer {kname!r} is not in the model")
+        pr = produced[kname]
+        return GRAPH_INPUT if pr is None else layers[pr[1]]['name']
+    wired, chain, prev = [], True, GRAPH_INPUT
+    for kl in klayers:
+        kname = kl['config'].get('name')
+        pr = produced[kname]
+        if pr is None:
+            continue
+        src = [out_name(nm) for nm in inbound.get(kname, [])]
+        if not src:
+            raise ValueError(f"layer {kname!r} of a functional model has no inbound node")
+        for q in range(pr[0], pr[1] + 1):
+            wired.append(src if q == pr[0] else [layers[q - 1]['name']])
+            chain = chain and wired[-1] == [prev]
+            prev = layers[q]['name']
+    if chain:
+        return False
+    for L, src in zip(layers, wired):
+        L['inputs'] = src
+    return True
 
 
 def _short(wname):
@@ -330,6 +437,27 @@ class _Builder:
         self.rows.append(r)
         return shape_in
 
+    def elt(self, kind, src, dst, shape_in, shape_out, res=-1, nch=0, soff=0, doff=0, perm=(0, 0, 0)):
+        """Merge / data-movement row (ISS_OP_ELT, include/iss.h): binary kinds on (src, res) -> dst; COPY / ZERO of `nch` channels
+        from channel soff of src to channel doff of dst; PERMUTE of the (H, W, C) axes."""
+        h, w, c = shape_in
+        ho, wo, co = shape_out
+        r = [0] * N.PROG_COLS
+        r[N.C_OP] = N.OP_ELT
+        r[N.C_IN], r[N.C_OUT], r[N.C_RES] = src, dst, res
+        r[N.C_H], r[N.C_W], r[N.C_CIN] = h, w, c
+        r[N.C_HO], r[N.C_WO], r[N.C_COUT] = ho, wo, co
+        r[N.C_ACT] = kind
+        if kind in (N.ELT_COPY, N.ELT_ZERO):
+            r[N.C_KH], r[N.C_PT], r[N.C_PL] = nch, soff, doff
+        elif kind == N.ELT_PERMUTE:
+            r[N.C_KH], r[N.C_KW], r[N.C_SH] = perm
+        for col in (N.C_WOFF, N.C_BOFF, N.C_PSOFF, N.C_PTOFF):
+            r[col] = -1
+        self.rows.append(r)
+        self.use_buf(dst, ho * wo * co)
+        return shape_out
+
     def softmax(self, src, dst, shape_in):
         h, w, c = shape_in
         r = [0] * N.PROG_COLS
@@ -424,6 +552,34 @@ def expand_generic_layers(layers):
     return out
 
 
+class _Bufs:
+    """Activation-buffer ids of a program under construction: the lowest id that holds no live tensor and is not the one being
+    read.  A chain model ping-pongs between 0 and 1; a graph pins the tensors that still have readers."""
+
+    def __init__(self):
+        self.pinned = {}                            # buffer id -> readers left
+
+    def alloc(self, cur):
+        b = 0
+        while b == cur or b in self.pinned:
+            b += 1
+        return b
+
+    def pin(self, b, readers):
+        if b >= 0 and readers > 0:
+            self.pinned[b] = self.pinned.get(b, 0) + readers
+
+    def release(self, b):
+        if b in self.pinned:
+            self.pinned[b] -= 1
+            if self.pinned[b] <= 0:
+                del self.pinned[b]
+
+
+def _is_graph(layers):
+    return any('inputs' in L for L in layers)
+
+
 def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_channels=True, fold_post_bn=True):
     """Lower a sequential layer list onto the op program.  Fusions: conv/dense + bias,
     + BatchNorm directly after (folded into W, b), + relu/sigmoid/tanh, + BatchNorm after the
@@ -440,17 +596,47 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
     that every conv / dense behind the first layer runs on the vectorised MFMA kernels (Cin % 32 == 0) instead of the
     scalar-gather path (only from 16 channels up: below that the padding would more than double the work); results are unchanged (the extra products are exact zeros) and `flops_per_sample` keeps counting
     the model's own MACs."""
+
     layers = expand_generic_layers(layers)          # dilated / depthwise convolutions as ordinary ones on zero-filled kernels
     B = _Builder()
+    opts = dict(patch_input=patch_input, fuse_pool=fuse_pool, pad_channels=pad_channels, fold_post_bn=fold_post_bn)
     shape = tuple(int(v) for v in in_shape)
-    pmap = np.arange(shape[2])                      # physical channel -> logical channel of the current activation (-1 = padding)
-    cur = N.BUF_INPUT
-    first = True
+    if _is_graph(layers):
+        cur, shape, pmap = _compile_graph(B, layers, shape, opts)
+    else:
+        cur, shape, pmap = _compile_chain(B, _Bufs(), layers, N.BUF_INPUT, shape, np.arange(shape[2]), True, False, opts)
+    if cur == N.BUF_INPUT:
+        raise ValueError("empty network")
+    if len(pmap) != shape[2]:
+        raise NotImplementedError("network output is channel-padded")
+    out_dim = shape[0] * shape[1] * shape[2]
+    return B.finish(in_shape, out_dim, patch_input)
+
+
+def _absorbs_padding(layers, j, at_end):
+    """Whether the tensor produced in front of layers[j] may carry zero padding channels: the next layer that is not transparent to
+    them (pools, flatten, dropout are) rebuilds the channel axis from its weights (conv / dense, or the identity carrier of a
+    stand-alone BatchNorm / activation).  Softmax, Reshape, Permute and the merge layers need the model's own channels."""
+    for L in layers[j:]:
+        ty = L['type']
+        if ty in ('dropout', 'flatten', 'maxpool', 'avgpool', 'globalavgpool', 'globalmaxpool'):
+            continue
+        return ty in ('conv2d', 'dense', 'batchnorm') or (ty == 'activation' and L['fn'] != 'softmax')
+    return at_end
+
+
+def _compile_chain(B, bufs, layers, cur, shape, pmap, first, padded_end, opts):
+    """Lower a single-input single-output run of layers reading buffer `cur` (logical `shape`, physical channel map `pmap`); returns
+    (buffer, shape, pmap) of its result.  `first`: the run starts at the network input.  `padded_end`: whoever reads the result
+    accepts padding channels (_absorbs_padding)."""
+    patch_input, fuse_pool, pad_channels, fold_post_bn = (opts[k] for k in ('patch_input', 'fuse_pool', 'pad_channels', 'fold_post_bn'))
+    # pmap: physical channel -> logical channel of the current activation (-1 = padding)
     i, n = 0, len(layers)
     carry = None                                    # (sc, sft) float64 per LOGICAL input feature of the next linear layer (fold_post_bn)
+    src0 = cur                                      # the run's own input: never overwritten, released by the caller
 
     def nxt_buf():
-        return 0 if cur in (N.BUF_INPUT, 1) else 1
+        return bufs.alloc(cur)
 
     def peek(j):
         while j < n and layers[j]['type'] == 'dropout':
@@ -580,8 +766,7 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
                 Wp3 = np.zeros((cout, kh * kw, cin_p))
                 Wp3[:, :, pmap >= 0] = W3[:, :, pmap[pmap >= 0]]
                 Wm = Wp3.reshape(cout, kh * kw * cin_p)
-            later = any(l['type'] in ('conv2d', 'dense', 'batchnorm') or (l['type'] == 'activation' and l['fn'] != 'softmax')
-                        for l in layers[j:])
+            later = _absorbs_padding(layers, j, padded_end)
             cout_p = cout
             if pad_channels and later and not softmax_after and cout % CH_ALIGN and cout >= CH_ALIGN // 2:   # at most 2x the work
                 cout_p = -(-cout // CH_ALIGN) * CH_ALIGN
@@ -622,9 +807,7 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
             h, w, c = shape
             ph, pw = L['pool']
             sh, sw = L.get('strides') or L['pool']
-            if L.get('padding', 'valid') == 'same':
-                if ty == 'avgpool':
-                    raise NotImplementedError("AveragePooling2D(padding='same')")
+            if L.get('padding', 'valid') == 'same':     # (average: the mean leaves the padding out, as Keras / TF do)
                 ho, pt = _same_pads(h, ph, sh)
                 wo, pl = _same_pads(w, pw, sw)
             else:
@@ -639,17 +822,187 @@ def compile_layers(layers, in_shape, patch_input=True, fuse_pool=True, pad_chann
             B.pool(cur, dst, pshape, h, w, h, w, 0, 0, 1, 1, 1 if ty == 'globalavgpool' else 0)
             shape = (1, 1, c)
             cur = dst
+        elif ty == 'reshape':                       # row-major on (H, W, C) storage: a new shape for the same floats, no row
+            if len(pmap) != shape[2]:
+                raise NotImplementedError("internal: Reshape of a channel-padded activation")
+            shape = _reshape_target(L['target'], shape)
+            pmap = np.arange(shape[2])
+        elif ty == 'permute':
+            if len(pmap) != shape[2]:
+                raise NotImplementedError("internal: Permute of a channel-padded activation")
+            perm = tuple(int(v) for v in L['perm'])
+            if perm != (0, 1, 2):
+                oshape = tuple(shape[k] for k in perm)
+                dst = nxt_buf()
+                B.elt(N.ELT_PERMUTE, cur, dst, shape, oshape, perm=perm)
+                shape, cur = oshape, dst
+                pmap = np.arange(shape[2])
         else:
             raise NotImplementedError(ty)
         first = False
         i += 1
-    if cur == N.BUF_INPUT:
-        raise ValueError("empty network")
     assert carry is None, "a deferred BatchNorm was never consumed"
-    if len(pmap) != shape[2]:
-        raise NotImplementedError("network output is channel-padded")
-    out_dim = shape[0] * shape[1] * shape[2]
-    return B.finish(in_shape, out_dim, patch_input)
+    return cur, shape, pmap
+
+
+def _reshape_target(target, shape):
+    """keras.layers.Reshape(target_shape) on a stored (H, W, C) activation: (n,) -> (1, 1, n); (a, b, c) as it is; one -1 is inferred."""
+    total = int(shape[0]) * int(shape[1]) * int(shape[2])
+    t = [int(v) for v in target]
+    if t.count(-1) > 1 or len(t) not in (1, 3):
+        raise NotImplementedError(f"Reshape to {tuple(target)}: the op program stores (H, W, C) or flat activations")
+    if -1 in t:
+        known = int(np.prod([v for v in t if v != -1])) if len(t) > 1 else 1
+        t[t.index(-1)] = total // max(known, 1)
+    if int(np.prod(t)) != total:
+        raise ValueError(f"Reshape {tuple(shape)} -> {tuple(target)}: element counts differ")
+    return (1, 1, t[0]) if len(t) == 1 else tuple(t)
+
+
+_MERGE_KIND = {'add': N.ELT_ADD, 'subtract': N.ELT_SUB, 'multiply': N.ELT_MUL, 'maximum': N.ELT_MAX, 'minimum': N.ELT_MIN,
+               'average': N.ELT_AVG}
+_MERGES = tuple(_MERGE_KIND) + ('concatenate',)
+GRAPH_INPUT = '__input__'
+
+
+def _compile_graph(B, layers, in_shape, opts):
+    """Lower a layer list whose entries name their producers ('inputs': [layer names], GRAPH_INPUT = the network input) -- what a
+    functional Keras model that is not a chain parses to.  Runs of single-input layers between branch and merge points go through
+    `_compile_chain` (with all its fusions); Add / Subtract / Multiply / Average / Maximum / Minimum / Concatenate become ISS_OP_ELT
+    rows (one-thread-per-element kernels: a graph costs speed, not the run).  Buffers are handed out by liveness (`_Bufs`)."""
+    names = [L.get('name') for L in layers]
+    if None in names or len(set(names)) != len(names) or GRAPH_INPUT in names:
+        raise ValueError("a graph-shaped layer list needs unique layer names")
+    idx_of = {nm: k for k, nm in enumerate(names)}
+    ins = []
+    for k, L in enumerate(layers):
+        src = L.get('inputs')
+        if src is None:
+            src = [names[k - 1] if k else GRAPH_INPUT]
+        for nm in src:
+            if nm != GRAPH_INPUT and nm not in idx_of:
+                raise ValueError(f"layer {L['name']!r} reads {nm!r}, which is not a layer of the model")
+        if L['type'] not in _MERGES and len(src) != 1:
+            raise ValueError(f"layer {L['name']!r} ({L['type']}) takes one input, got {len(src)}")
+        ins.append(list(src))
+    readers = {nm: [] for nm in names + [GRAPH_INPUT]}
+    for k, src in enumerate(ins):
+        for nm in src:
+            readers[nm].append(k)
+    sinks = [nm for nm in names if not readers[nm]]
+    if len(sinks) != 1:
+        raise NotImplementedError(f"a model with {len(sinks)} outputs ({sinks}): the segmenter networks have one")
+    # topological order that keeps the list's own order where it can
+    order, placed, left = [], {GRAPH_INPUT}, list(range(len(layers)))
+    while left:
+        ready = [k for k in left if all(nm in placed for nm in ins[k])]
+        if not ready:
+            raise ValueError("the layer graph has a cycle")
+        order.append(ready[0]); placed.add(names[ready[0]]); left.remove(ready[0])
+
+    def run_from(k):
+        """The run of single-input layers that starts at layer k and can be lowered as one chain."""
+        run = [k]
+        while True:
+            rd = readers[names[run[-1]]]
+            if len(rd) != 1 or layers[rd[0]]['type'] in _MERGES or len(ins[rd[0]]) != 1:
+                return run
+            run.append(rd[0])
+
+    def accepts_padding(nm):
+        rd = readers[nm]
+        return bool(rd) and all(layers[k]['type'] not in _MERGES and _absorbs_padding([layers[q] for q in run_from(k)], 0, False) for k in rd)
+
+    bufs = _Bufs()
+    tensors = {GRAPH_INPUT: (N.BUF_INPUT, tuple(in_shape), np.arange(in_shape[2]))}
+    at_input = True                                  # the network input has not been copied into an activation buffer
+    rd0 = readers[GRAPH_INPUT]
+    if not rd0:
+        raise ValueError("no layer reads the network input")
+    if len(rd0) > 1 or layers[rd0[0]]['type'] in _MERGES or not opts['patch_input']:
+        if opts['patch_input']:                      # several readers (or a merge): one identity carrier materialises the patch
+            b = bufs.alloc(N.BUF_INPUT)
+            shp = B.conv(N.BUF_INPUT, b, tuple(in_shape), np.eye(1, dtype=np.float32), 1, 1, 1, 1, 0, 0, in_shape[0], in_shape[1], inmode=1)
+            tensors[GRAPH_INPUT] = (b, shp, np.arange(shp[2]))
+            bufs.pin(b, len(rd0))
+            at_input = False
+        elif any(layers[k]['type'] in _MERGES for k in rd0):
+            raise NotImplementedError("a merge layer directly on the network input of a feature-vector model")
+    done = set()
+    for k in order:
+        if k in done:
+            continue
+        L = layers[k]
+        if L['type'] in _MERGES:
+            ts = [tensors[nm] for nm in ins[k]]
+            for nm, (b, shp, pm) in zip(ins[k], ts):
+                if len(pm) != shp[2]:
+                    raise NotImplementedError(f"internal: merge input {nm!r} is channel-padded")
+            out_nm, nrd = names[k], len(readers[names[k]])
+            if L['type'] == 'concatenate':
+                nd = 3 if any(t[1][0] * t[1][1] > 1 for t in ts) else 1          # stored rank: (H, W, C) or flat
+                ax = int(L.get('axis', -1))
+                ax = ax + nd + 1 if ax < 0 else ax                                # Keras counts the batch axis
+                if not 1 <= ax <= nd:
+                    raise ValueError(f"Concatenate axis {L.get('axis')} on rank-{nd} activations")
+                ax = ax - 1 + (3 - nd)                                            # 0 = H, 1 = W, 2 = C of the stored shape
+                base = ts[0][1]
+                for t in ts:
+                    if any(t[1][d] != base[d] for d in range(3) if d != ax):
+                        raise ValueError(f"Concatenate ({out_nm}): input shapes {[t_[1] for t_ in ts]} differ off axis {ax}")
+                tot = sum(t[1][ax] for t in ts)
+                oshape = tuple(tot if d == ax else base[d] for d in range(3))
+                # COPY rows on a re-read grid: the axis in front of `ax` are pixels, everything from `ax` on is one "channel" run
+                grid = int(np.prod(base[:ax])) if ax else 1
+                inner = int(np.prod(base[ax + 1:])) if ax < 2 else 1
+                ctot = tot * inner
+                cp = ctot
+                if ax == 2 and opts['pad_channels'] and accepts_padding(out_nm) and ctot % CH_ALIGN and ctot >= CH_ALIGN // 2:
+                    cp = -(-ctot // CH_ALIGN) * CH_ALIGN
+                dst = bufs.alloc(-1)
+                off = 0
+                for (b, shp, pm) in ts:
+                    nch = shp[ax] * inner
+                    B.elt(N.ELT_COPY, b, dst, (grid, 1, nch), (grid, 1, cp), nch=nch, soff=0, doff=off)
+                    off += nch
+                if cp > ctot:
+                    B.elt(N.ELT_ZERO, dst, dst, (grid, 1, cp), (grid, 1, cp), nch=cp - ctot, doff=ctot)
+                res = (dst, oshape, np.concatenate((np.arange(ctot), np.full(cp - ctot, -1))) if ax == 2 else np.arange(oshape[2]))
+            else:
+                base = ts[0][1]
+                if any(t[1] != base for t in ts) or len(ts) < 2:
+                    raise ValueError(f"{L['type']} ({out_nm}): needs two or more inputs of one shape, got {[t_[1] for t_ in ts]}")
+                if L['type'] == 'subtract' and len(ts) != 2:
+                    raise ValueError("Subtract takes exactly two inputs")
+                kind = _MERGE_KIND[L['type']]
+                many_avg = L['type'] == 'average' and len(ts) > 2
+                dst = bufs.alloc(-1)
+                B.elt(N.ELT_ADD if many_avg else kind, ts[0][0], dst, base, base, res=ts[1][0])
+                for t in ts[2:]:
+                    B.elt(N.ELT_ADD if many_avg else kind, dst, dst, base, base, res=t[0])
+                if many_avg:                          # mean of n > 2 tensors: the sum through an identity 1x1 conv scaled by 1 / n
+                    bufs.pin(dst, 1)
+                    d2 = bufs.alloc(dst)
+                    B.conv(dst, d2, base, np.eye(base[2], dtype=np.float64) / len(ts), 1, 1, 1, 1, 0, 0, base[0], base[1], alg_kc=base[2])
+                    bufs.release(dst)
+                    dst = d2
+                res = (dst, base, np.arange(base[2]))
+            for (b, shp, pm) in ts:
+                bufs.release(b)
+            tensors[out_nm] = res
+            bufs.pin(res[0], nrd)
+            continue
+        run = run_from(k)
+        done.update(run)
+        src_nm = ins[k][0]
+        b, shp, pm = tensors[src_nm]
+        bufs.release(b)
+        first = at_input and src_nm == GRAPH_INPUT
+        last_nm = names[run[-1]]
+        res = _compile_chain(B, bufs, [layers[q] for q in run], b, shp, pm, first, accepts_padding(last_nm), opts)
+        tensors[last_nm] = res
+        bufs.pin(res[0], len(readers[last_nm]))
+    return tensors[sinks[0]]
 
 
 # ------------------------------------------------------------------------------ ResNet-101

@@ -101,13 +101,25 @@ int iss_set_mspec(iss_ctx* ctx, const float* mspec, int32_t T);
 
 enum {
     ISS_OP_CONV     = 1,  /* conv2d / dense as implicit GEMM (MFMA) + fused epilogue (+ fused pool) */
-    ISS_OP_POOL     = 2,  /* max / average pooling, NHWC                                 */
+    ISS_OP_POOL     = 2,  /* max / average pooling, NHWC; a padded (PT / PL, 'same') average leaves the padding out of the mean */
     ISS_OP_SOFTMAX  = 3,  /* softmax over the channel axis                               */
     ISS_OP_STATPOOL = 4,  /* mean || std over the time axis (resnet.py:123-127)          */
     ISS_OP_ACT      = 5,  /* elementwise activation beyond the fused ones: ISS_C_ACT 4 elu(alpha), 5 leaky relu(alpha),
                              6 selu, 7 softplus, 8 relu clipped at alpha (ReLU(max_value)); alpha = the float whose bits are in
                              ISS_C_ACTPARAM; IN may equal OUT, and is never ISS_BUF_INPUT */
+    ISS_OP_ELT      = 6,  /* merge / data-movement rows of graph-shaped models (keras.layers.Add, Concatenate, Permute ...; what
+                             `keras.models.load_model`, segmenter.py:129-131, accepts beyond a chain).  Plain one-thread-per-element
+                             kernels: correct, not fast.  ISS_C_ACT = kind (ISS_ELT_*); IN is never ISS_BUF_INPUT.
+                             kinds ADD .. AVG: OUT[i] = IN[i] (op) RES[i] over H * W * CIN floats per sample (HO, WO, COUT = H, W, CIN;
+                                               OUT may be IN or RES);
+                             COPY:    OUT[p][PL + c] = IN[p][PT + c] for c < KH, p over the H * W pixels; IN holds CIN and OUT COUT
+                                      channels per pixel (HO, WO = H, W); OUT != IN.  Concatenate = one COPY per input;
+                             ZERO:    OUT[p][PL + c] = 0 for c < KH (channel padding behind a COPY);
+                             PERMUTE: OUT = IN with its (H, W, CIN) axes permuted, output axis i = input axis perm[i],
+                                      perm = (KH, KW, SH); (HO, WO, COUT) = the permuted shape; OUT != IN */
 };
+enum { ISS_ELT_COPY = 0, ISS_ELT_ADD = 1, ISS_ELT_SUB = 2, ISS_ELT_MUL = 3, ISS_ELT_MAX = 4, ISS_ELT_MIN = 5, ISS_ELT_AVG = 6,
+       ISS_ELT_ZERO = 7, ISS_ELT_PERMUTE = 8 };
 /* column meaning of a program row (unused columns = 0, absent offsets = -1) */
 enum {
     ISS_C_OP = 0, ISS_C_IN, ISS_C_OUT, ISS_C_RES,      /* buffer ids; RES = residual add   */

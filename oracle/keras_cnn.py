@@ -18,6 +18,11 @@ inaspeechsegmenter_amd/keras_model.py produces, but this file does not import it
   batchnorm: gamma, beta, mean, var, eps
   activation: fn ; maxpool/avgpool: pool, strides, padding ; flatten ; dropout
   globalavgpool / globalmaxpool
+  reshape  : target (keras.layers.Reshape target_shape: (n,) or (a, b, c)) ; permute: perm (0-based over (H, W, C))
+Graph-shaped models (functional Keras models that are not a chain): every dict carries 'name' and 'inputs' (names of the layers it
+reads, '__input__' = the network input), in any topological order, plus the merge layers
+  add / subtract / multiply / average / maximum / minimum (keras.layers.Add ...: elementwise over inputs of one shape)
+  concatenate : axis (Keras numbering, batch axis included; default -1)
 """
 import numpy as np
 
@@ -88,76 +93,140 @@ def forward(layers, x, batch_size=1024, threads=None):
             return torch.softmax(t, dim=-1)
         raise ValueError(fn)
 
+    def step(L, t, flat):
+        ty = L['type']
+        if ty in ('conv2d', 'depthwise'):
+            # Conv2D: kernel (kh, kw, cin, cout).  DepthwiseConv2D: kernel (kh, kw, cin, depth_multiplier), output channel
+            # c * multiplier + m = filter m of input channel c (torch groups = cin has the same channel order).
+            # dilation_rate: taps (dy, dx) apart; 'same' pads for the EFFECTIVE kernel size (k - 1) * d + 1
+            if ty == 'depthwise':
+                kh, kw, cin, mult = L['W'].shape
+                w = torch.from_numpy(np.ascontiguousarray(L['W'].transpose(2, 3, 0, 1).reshape(cin * mult, 1, kh, kw)))
+                groups = cin
+            else:
+                w = torch.from_numpy(np.ascontiguousarray(L['W'].transpose(3, 2, 0, 1)))
+                groups = 1
+            b = None if L.get('b') is None else torch.from_numpy(L['b'])
+            kh, kw = L['W'].shape[:2]
+            sh, sw = L.get('strides', (1, 1))
+            dy, dx = L.get('dilation', (1, 1))
+            if L.get('pad'):                       # a ZeroPadding2D in front of the convolution: (top, bottom, left, right)
+                zt, zb, zl, zr = L['pad']
+                t = F.pad(t, (zl, zr, zt, zb))
+            if L.get('padding', 'valid') == 'same':
+                pt, pb = same_pads(t.shape[2], (kh - 1) * dy + 1, sh)
+                pl, pr = same_pads(t.shape[3], (kw - 1) * dx + 1, sw)
+                t = F.pad(t, (pl, pr, pt, pb))
+            t = act_nchw(F.conv2d(t, w, b, stride=(sh, sw), dilation=(dy, dx), groups=groups), L.get('activation'), act, L.get('alpha'))
+        elif ty == 'batchnorm':
+            sc = L['gamma'] / np.sqrt(L['var'] + np.float32(L['eps']))
+            sh_ = L['beta'] - L['mean'] * sc
+            sc_t = torch.from_numpy(sc.astype(np.float32))
+            sh_t = torch.from_numpy(sh_.astype(np.float32))
+            if flat:
+                t = t * sc_t + sh_t
+            else:
+                t = t * sc_t[None, :, None, None] + sh_t[None, :, None, None]
+        elif ty == 'activation':
+            t = act(t, L['fn'], L.get('alpha')) if flat else act_nchw(t, L['fn'], act, L.get('alpha'))
+        elif ty in ('maxpool', 'avgpool'):
+            ph, pw = L['pool']
+            sh, sw = L.get('strides') or L['pool']
+            if L.get('padding', 'valid') == 'same':
+                pt, pb = same_pads(t.shape[2], ph, sh)
+                pl, pr = same_pads(t.shape[3], pw, sw)
+                fill = float('-inf') if ty == 'maxpool' else 0.0
+                if ty == 'avgpool' and (pt + pb + pl + pr):    # Keras / TF: the mean is over the elements inside the input
+                    ones = F.pad(torch.ones_like(t[:1, :1]), (pl, pr, pt, pb))
+                    cnt = F.avg_pool2d(ones, (ph, pw), (sh, sw)) * (ph * pw)
+                    t = F.avg_pool2d(F.pad(t, (pl, pr, pt, pb)), (ph, pw), (sh, sw)) * (ph * pw) / cnt
+                    return t, flat
+                t = F.pad(t, (pl, pr, pt, pb), value=fill)
+            t = F.max_pool2d(t, (ph, pw), (sh, sw)) if ty == 'maxpool' else F.avg_pool2d(t, (ph, pw), (sh, sw))
+        elif ty == 'globalavgpool':
+            t = t.mean(dim=(2, 3)); flat = True
+        elif ty == 'globalmaxpool':
+            t = t.amax(dim=(2, 3)); flat = True
+        elif ty == 'flatten':
+            t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1); flat = True
+        elif ty == 'dense':
+            assert flat, "dense on un-flattened input"
+            t = t @ torch.from_numpy(L['W'])
+            if L.get('b') is not None:
+                t = t + torch.from_numpy(L['b'])
+            t = act(t, L.get('activation'), L.get('alpha'))
+        elif ty == 'dropout':
+            pass
+        elif ty == 'reshape':                      # row-major on the channels-last tensor
+            u = (t if flat else t.permute(0, 2, 3, 1)).reshape((t.shape[0],) + tuple(int(v) for v in L['target']))
+            if u.dim() == 2:
+                t, flat = u, True
+            elif u.dim() == 4:
+                t, flat = u.permute(0, 3, 1, 2), False
+            else:
+                raise ValueError(f"reshape target {L['target']}")
+        elif ty == 'permute':                      # output axis i = input axis perm[i] of (H, W, C)
+            assert not flat
+            pm = [int(v) + 1 for v in L['perm']]
+            t = t.permute(0, 2, 3, 1).permute(0, *pm).permute(0, 3, 1, 2)
+        else:
+            raise ValueError(ty)
+        return t, flat
+
+    def merge(L, ins):
+        ty = L['type']
+        ts = [a for a, _ in ins]
+        flat = ins[0][1]
+        assert all(f == flat for _, f in ins), "merge of flat and (H, W, C) tensors"
+        if ty == 'concatenate':
+            nd = 1 if flat else 3
+            ax = int(L.get('axis', -1))
+            ax = ax + nd + 1 if ax < 0 else ax             # Keras axis, batch included: 1..nd
+            dim = 1 if flat else {1: 2, 2: 3, 3: 1}[ax]    # NHWC axis -> the NCHW dim used here
+            return torch.cat(ts, dim=dim), flat
+        r = ts[0]
+        for u in ts[1:]:
+            r = {'add': torch.add, 'average': torch.add, 'subtract': torch.sub, 'multiply': torch.mul,
+                 'maximum': torch.maximum, 'minimum': torch.minimum}[ty](r, u)
+        return (r / np.float32(len(ts)) if ty == 'average' else r), flat
+
+    graph = any('inputs' in L for L in layers)
     outs = []
     with torch.no_grad():
         for s in range(0, len(x), batch_size):
             t = torch.from_numpy(np.ascontiguousarray(x[s:s + batch_size], dtype=np.float32))
             t = t.permute(0, 3, 1, 2)                      # NCHW internally
             flat = False
-            for L in layers:
-                ty = L['type']
-                if ty in ('conv2d', 'depthwise'):
-                    # Conv2D: kernel (kh, kw, cin, cout).  DepthwiseConv2D: kernel (kh, kw, cin, depth_multiplier), output channel
-                    # c * multiplier + m = filter m of input channel c (torch groups = cin has the same channel order).
-                    # dilation_rate: taps (dy, dx) apart; 'same' pads for the EFFECTIVE kernel size (k - 1) * d + 1
-                    if ty == 'depthwise':
-                        kh, kw, cin, mult = L['W'].shape
-                        w = torch.from_numpy(np.ascontiguousarray(L['W'].transpose(2, 3, 0, 1).reshape(cin * mult, 1, kh, kw)))
-                        groups = cin
-                    else:
-                        w = torch.from_numpy(np.ascontiguousarray(L['W'].transpose(3, 2, 0, 1)))
-                        groups = 1
-                    b = None if L.get('b') is None else torch.from_numpy(L['b'])
-                    kh, kw = L['W'].shape[:2]
-                    sh, sw = L.get('strides', (1, 1))
-                    dy, dx = L.get('dilation', (1, 1))
-                    if L.get('pad'):                       # a ZeroPadding2D in front of the convolution: (top, bottom, left, right)
-                        zt, zb, zl, zr = L['pad']
-                        t = F.pad(t, (zl, zr, zt, zb))
-                    if L.get('padding', 'valid') == 'same':
-                        pt, pb = same_pads(t.shape[2], (kh - 1) * dy + 1, sh)
-                        pl, pr = same_pads(t.shape[3], (kw - 1) * dx + 1, sw)
-                        t = F.pad(t, (pl, pr, pt, pb))
-                    t = act_nchw(F.conv2d(t, w, b, stride=(sh, sw), dilation=(dy, dx), groups=groups), L.get('activation'), act, L.get('alpha'))
-                elif ty == 'batchnorm':
-                    sc = L['gamma'] / np.sqrt(L['var'] + np.float32(L['eps']))
-                    sh_ = L['beta'] - L['mean'] * sc
-                    sc_t = torch.from_numpy(sc.astype(np.float32))
-                    sh_t = torch.from_numpy(sh_.astype(np.float32))
-                    if flat:
-                        t = t * sc_t + sh_t
-                    else:
-                        t = t * sc_t[None, :, None, None] + sh_t[None, :, None, None]
-                elif ty == 'activation':
-                    t = act(t, L['fn'], L.get('alpha')) if flat else act_nchw(t, L['fn'], act, L.get('alpha'))
-                elif ty in ('maxpool', 'avgpool'):
-                    ph, pw = L['pool']
-                    sh, sw = L.get('strides') or L['pool']
-                    if L.get('padding', 'valid') == 'same':
-                        pt, pb = same_pads(t.shape[2], ph, sh)
-                        pl, pr = same_pads(t.shape[3], pw, sw)
-                        fill = float('-inf') if ty == 'maxpool' else 0.0
-                        assert ty == 'maxpool' or (pt + pb + pl + pr) == 0, "avgpool same-pad unsupported"
-                        t = F.pad(t, (pl, pr, pt, pb), value=fill)
-                    t = F.max_pool2d(t, (ph, pw), (sh, sw)) if ty == 'maxpool' else F.avg_pool2d(t, (ph, pw), (sh, sw))
-                elif ty == 'globalavgpool':
-                    t = t.mean(dim=(2, 3)); flat = True
-                elif ty == 'globalmaxpool':
-                    t = t.amax(dim=(2, 3)); flat = True
-                elif ty == 'flatten':
-                    t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1); flat = True
-                elif ty == 'dense':
-                    assert flat, "dense on un-flattened input"
-                    t = t @ torch.from_numpy(L['W'])
-                    if L.get('b') is not None:
-                        t = t + torch.from_numpy(L['b'])
-                    t = act(t, L.get('activation'), L.get('alpha'))
-                elif ty == 'dropout':
-                    pass
-                else:
-                    raise ValueError(ty)
+            if not graph:
+                for L in layers:
+                    t, flat = step(L, t, flat)
+            else:
+                t, flat = _run_graph(layers, (t, flat), lambda L, v: step(L, v[0], v[1]), merge)
             outs.append(t.numpy())
     return np.concatenate(outs) if outs else np.zeros((0, 0), np.float32)
+
+
+_MERGE_TYPES = ('add', 'subtract', 'multiply', 'average', 'maximum', 'minimum', 'concatenate')
+
+
+def _run_graph(layers, x, step, merge):
+    """Evaluate a graph-shaped layer list: every layer once all of its inputs exist; the value of the one layer nobody reads is
+    the model's output."""
+    vals = {'__input__': x}
+    names = [L['name'] for L in layers]
+    srcs = [L.get('inputs') or [names[k - 1] if k else '__input__'] for k, L in enumerate(layers)]
+    read = {nm for src in srcs for nm in src}
+    sinks = [nm for nm in names if nm not in read]
+    assert len(sinks) == 1, sinks
+    left = list(range(len(layers)))
+    while left:
+        k = next((k for k in left if all(nm in vals for nm in srcs[k])), None)
+        if k is None:
+            raise ValueError('cycle or missing input in the layer graph')
+        L = layers[k]
+        vals[L['name']] = merge(L, [vals[nm] for nm in srcs[k]]) if L['type'] in _MERGE_TYPES else step(L, vals[srcs[k][0]])
+        left.remove(k)
+    return vals[sinks[0]]
 
 
 def act_nchw(t, fn, act, alpha=None):
@@ -169,9 +238,29 @@ def act_nchw(t, fn, act, alpha=None):
 def forward_naive(layers, x):
     """Pure-numpy NHWC loops, float32, for tiny shapes: independent check of `forward`."""
     t = np.asarray(x, dtype=np.float32)
+    if any('inputs' in L for L in layers):
+        def merge(L, ts):
+            if L['type'] == 'concatenate':
+                ax = int(L.get('axis', -1))
+                return np.concatenate(ts, axis=ax if ax >= 0 else ts[0].ndim + ax)      # NHWC / (N, n): Keras' own axis numbering
+            f = {'add': np.add, 'average': np.add, 'subtract': np.subtract, 'multiply': np.multiply, 'maximum': np.maximum,
+                 'minimum': np.minimum}[L['type']]
+            r = ts[0]
+            for u in ts[1:]:
+                r = f(r, u)
+            return (r / np.float32(len(ts)) if L['type'] == 'average' else r).astype(np.float32)
+        return _run_graph(layers, t, lambda L, v: _naive_chain([L], v), merge)
+    return _naive_chain(layers, t)
+
+
+def _naive_chain(layers, t):
     for L in layers:
         ty = L['type']
-        if ty == 'conv2d':
+        if ty == 'reshape':
+            t = t.reshape((t.shape[0],) + tuple(int(v) for v in L['target']))
+        elif ty == 'permute':
+            t = t.transpose((0,) + tuple(int(v) + 1 for v in L['perm']))
+        elif ty == 'conv2d':
             W = L['W']; kh, kw, cin, cout = W.shape
             sh, sw = L.get('strides', (1, 1))
             if L.get('pad'):
@@ -199,14 +288,14 @@ def forward_naive(layers, x):
             ph, pw = L['pool']; sh, sw = L.get('strides') or L['pool']
             if L.get('padding', 'valid') == 'same':
                 pt, pb = same_pads(t.shape[1], ph, sh); pl, pr = same_pads(t.shape[2], pw, sw)
-                t = np.pad(t, ((0, 0), (pt, pb), (pl, pr), (0, 0)), constant_values=-np.inf)
+                t = np.pad(t, ((0, 0), (pt, pb), (pl, pr), (0, 0)), constant_values=-np.inf if ty == 'maxpool' else np.nan)
             n, H, Wd, c = t.shape
             ho, wo = (H - ph) // sh + 1, (Wd - pw) // sw + 1
             o = np.zeros((n, ho, wo, c), np.float32)
             for y in range(ho):
                 for xx in range(wo):
                     win = t[:, y * sh:y * sh + ph, xx * sw:xx * sw + pw, :]
-                    o[:, y, xx, :] = win.max(axis=(1, 2)) if ty == 'maxpool' else win.mean(axis=(1, 2))
+                    o[:, y, xx, :] = win.max(axis=(1, 2)) if ty == 'maxpool' else np.nanmean(win, axis=(1, 2))   # (NaN = padding)
             t = o
         elif ty == 'globalavgpool':
             t = t.mean(axis=(1, 2))

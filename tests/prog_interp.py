@@ -52,9 +52,9 @@ def run(comp, x):
             if R[N.C_POOLKIND] == 0:
                 t = F.pad(t, (pl, pr, pt, pb), value=float('-inf'))
                 y = F.max_pool2d(t, (kh, kw), (sh, sw))
-            else:
-                assert pt == pl == pb == pr == 0
-                y = F.avg_pool2d(t, (kh, kw), (sh, sw))
+            else:                                        # mean over the elements inside the input (padded 'same' average pools)
+                ones = F.pad(torch.ones_like(t[:1, :1]), (pl, pr, pt, pb))
+                y = F.avg_pool2d(F.pad(t, (pl, pr, pt, pb)), (kh, kw), (sh, sw)) / F.avg_pool2d(ones, (kh, kw), (sh, sw))
             out = y[:, :, :ho, :wo].permute(0, 2, 3, 1)
         elif op == N.OP_SOFTMAX:
             out = torch.softmax(src, dim=-1)
@@ -62,6 +62,28 @@ def run(comp, x):
             alpha = float(np.array([int(R[N.C_ACTPARAM])], np.int32).view(np.float32)[0])
             out = {4: lambda: F.elu(src, alpha=alpha), 5: lambda: F.leaky_relu(src, negative_slope=alpha), 6: lambda: F.selu(src),
                    7: lambda: F.softplus(src), 8: lambda: torch.clamp(src, 0.0, alpha)}[int(R[N.C_ACT])]()
+        elif op == N.OP_ELT:                         # merge / data-movement rows of graph-shaped models
+            kind = int(R[N.C_ACT])
+            if N.ELT_ADD <= kind <= N.ELT_AVG:
+                b = bufs[int(R[N.C_RES])].reshape(src.shape)
+                out = {N.ELT_ADD: lambda: src + b, N.ELT_SUB: lambda: src - b, N.ELT_MUL: lambda: src * b,
+                       N.ELT_MAX: lambda: torch.maximum(src, b), N.ELT_MIN: lambda: torch.minimum(src, b),
+                       N.ELT_AVG: lambda: (src + b) * 0.5}[kind]()
+            elif kind in (N.ELT_COPY, N.ELT_ZERO):
+                nch, soff, doff = int(R[N.C_KH]), int(R[N.C_PT]), int(R[N.C_PL])
+                old = bufs.get(int(R[N.C_OUT]))
+                if kind == N.ELT_ZERO:
+                    out = src.reshape(-1, h, w, cout).clone()
+                    out[..., doff:doff + nch] = 0
+                else:
+                    out = old.reshape(-1, h, w, cout).clone() if old is not None and old.numel() == len(src) * h * w * cout \
+                        else torch.full((len(src), h, w, cout), float('nan'), dtype=torch.float64)   # NaN: channels nobody wrote show up
+                    out[..., doff:doff + nch] = src[..., soff:soff + nch]
+            elif kind == N.ELT_PERMUTE:
+                out = src.permute(0, 1 + int(R[N.C_KH]), 1 + int(R[N.C_KW]), 1 + int(R[N.C_SH]))
+                assert tuple(out.shape[1:]) == (ho, wo, cout)
+            else:
+                raise NotImplementedError(kind)
         elif op == N.OP_STATPOOL:                    # mean || std over W (time) per (h, c), torch's (c, h) flatten order
             mean = src.mean(dim=2)                   # (N, H, C)
             std = torch.sqrt((src * src).mean(dim=2) - mean * mean + 1e-10)

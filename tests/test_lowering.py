@@ -200,3 +200,99 @@ def test_layers_without_a_kernel_of_their_own_are_lowered_through_ordinary_convo
         for m in range(2):
             ref = sum(xi[0, dy:dy + 3, dx:dx + 3, c] * one[0]['W'][dy, dx, c, m] for dy in range(2) for dx in range(2))
             assert np.abs(y[:, :, c * 2 + m] - ref).max() < 1e-6
+
+
+# ------------------------------------------------------------------------------ graph-shaped models (ISS_OP_ELT rows)
+import graph_nets as GN
+
+
+@pytest.mark.parametrize('name', sorted(GN.NETS))
+def test_graph_shaped_models_lower_and_run(name):
+    """Functional models that are not a chain (residual adds, concatenations, permutes / reshapes, several readers of a tensor):
+    the lowered program -- chains through the usual fusions, merges as ISS_OP_ELT rows, buffers handed out by liveness -- computes
+    what the Keras-semantics oracle computes, and the two oracle implementations agree with each other."""
+    rng = np.random.default_rng(11)
+    for nmel, ncls in ((21, 3), (24, 2)):
+        layers, shp = GN.NETS[name](nmel, ncls, 5)
+        x = rng.normal(0, 1, (3,) + shp).astype(np.float32)
+        comp = KM.compile_layers(layers, shp)
+        got = prog_interp.run(comp, x)
+        want = ocnn.forward(layers, x)
+        assert got.shape == want.shape == (3, ncls) and np.isfinite(got).all()
+        assert np.abs(got - want).max() < 2e-5, (name, nmel, np.abs(got - want).max())
+        assert any(R[N.C_OP] == N.OP_ELT for R in comp.prog) or name == 'permute_reshape' and any(R[N.C_ACT] == N.ELT_PERMUTE for R in comp.prog)
+        # no row overwrites a buffer somebody still has to read (the interpreter would have computed garbage), and the count of
+        # buffers stays small
+        assert len(comp.buf_elems) <= 6, len(comp.buf_elems)
+        comp2 = KM.compile_layers(layers, shp, pad_channels=False, fuse_pool=False, fold_post_bn=False)
+        assert np.abs(prog_interp.run(comp2, x) - want).max() < 2e-5
+    small, shp = GN.NETS[name](21, 3, 9)
+    xs = rng.normal(0, 1, (1,) + shp).astype(np.float32)
+    assert np.abs(ocnn.forward(small, xs) - ocnn.forward_naive(small, xs)).max() < 2e-5
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_graphs_lower_and_run(seed):
+    rng = np.random.default_rng(seed)
+    layers, shp = GN.random_graph(seed, 21 if seed % 2 else 24, 3 if seed % 2 else 2)
+    x = rng.normal(0, 1, (2,) + shp).astype(np.float32)
+    got = prog_interp.run(KM.compile_layers(layers, shp), x)
+    want = ocnn.forward(layers, x)
+    assert np.isfinite(got).all() and np.abs(got - want).max() < 2e-5, (seed, np.abs(got - want).max())
+
+
+def _keras_functional_config(fmt):
+    """A small residual + concatenate model as `model.to_json()` writes it: Keras 2 ('inbound_nodes': [[[name, 0, 0, {}], ...]]) or
+    Keras 3 ('inbound_nodes': [{'args': [...__keras_tensor__...], 'kwargs': {}}])."""
+    def inb(*names):
+        if fmt == 2:
+            return [[[nm, 0, 0, {}] for nm in names]]
+        kt = [{'class_name': '__keras_tensor__', 'config': {'shape': [None, 1], 'dtype': 'float32', 'keras_history': [nm, 0, 0]}} for nm in names]
+        return [{'args': [kt[0]] if len(kt) == 1 else [kt], 'kwargs': {}}]
+    L = [
+        {'class_name': 'InputLayer', 'config': {'name': 'in', **({'batch_input_shape': [None, 68, 21, 1]} if fmt == 2 else {'batch_shape': [None, 68, 21, 1]})}, 'inbound_nodes': []},
+        {'class_name': 'Conv2D', 'config': {'name': 'c1', 'filters': 8, 'kernel_size': [3, 3], 'padding': 'same', 'activation': 'relu'}, 'inbound_nodes': inb('in')},
+        {'class_name': 'ZeroPadding2D', 'config': {'name': 'zp', 'padding': [[1, 1], [1, 1]]}, 'inbound_nodes': inb('c1')},
+        {'class_name': 'Conv2D', 'config': {'name': 'c2', 'filters': 8, 'kernel_size': [3, 3], 'padding': 'valid', 'activation': 'linear'}, 'inbound_nodes': inb('zp')},
+        {'class_name': 'BatchNormalization', 'config': {'name': 'bn', 'axis': 3, 'epsilon': 1e-3}, 'inbound_nodes': inb('c2')},
+        {'class_name': 'Add', 'config': {'name': 'add'}, 'inbound_nodes': inb('c1', 'bn')},
+        {'class_name': 'SeparableConv2D', 'config': {'name': 'sep', 'filters': 8, 'kernel_size': [3, 3], 'padding': 'same', 'activation': 'relu'}, 'inbound_nodes': inb('add')},
+        {'class_name': 'Concatenate', 'config': {'name': 'cat', 'axis': -1}, 'inbound_nodes': inb('add', 'sep')},
+        {'class_name': 'MaxPooling2D', 'config': {'name': 'mp', 'pool_size': [4, 4]}, 'inbound_nodes': inb('cat')},
+        {'class_name': 'Permute', 'config': {'name': 'pm', 'dims': [2, 1, 3]}, 'inbound_nodes': inb('mp')},
+        {'class_name': 'Flatten', 'config': {'name': 'fl'}, 'inbound_nodes': inb('pm')},
+        {'class_name': 'Dense', 'config': {'name': 'out', 'units': 3, 'activation': 'softmax'}, 'inbound_nodes': inb('fl')},
+    ]
+    return {'class_name': 'Functional' if fmt == 3 else 'Model',
+            'config': {'name': 'm', 'layers': L, 'input_layers': [['in', 0, 0]], 'output_layers': [['out', 0, 0]]}}
+
+
+@pytest.mark.parametrize('fmt', (2, 3))
+def test_functional_model_config_with_branches_parses_and_lowers(fmt):
+    rng = np.random.default_rng(2)
+    r = lambda *s: rng.normal(0, 0.3, s).astype(np.float32)
+    w = {'c1': {'kernel': r(3, 3, 1, 8), 'bias': r(8)}, 'c2': {'kernel': r(3, 3, 8, 8), 'bias': r(8)},
+         'bn': {'gamma': 1 + r(8), 'beta': r(8), 'moving_mean': r(8), 'moving_variance': 1 + np.abs(r(8))},
+         'sep': {'depthwise_kernel': r(3, 3, 8, 1), 'pointwise_kernel': r(1, 1, 8, 8), 'bias': r(8)},
+         'out': {'kernel': r(17 * 5 * 16, 3), 'bias': r(3)}}
+    layers, shp = KM.layers_from_keras_config(_keras_functional_config(fmt), w)
+    assert shp == (68, 21, 1) and all('inputs' in L for L in layers)
+    byname = {L['name']: L for L in layers}
+    assert byname['add']['inputs'] == ['c1', 'bn'] and byname['cat']['inputs'] == ['add', 'sep/pointwise']
+    assert byname['c2']['inputs'] == ['c1'] and byname['c2']['pad'] == (1, 1, 1, 1) and 'zp' not in byname
+    x = rng.normal(0, 1, (2,) + shp).astype(np.float32)
+    got = prog_interp.run(KM.compile_layers(layers, shp), x)
+    assert np.abs(got - ocnn.forward(layers, x)).max() < 2e-5
+    # a functional model that IS a chain still takes the sequential lowering (no 'inputs', the same program as before)
+    cfg = _keras_functional_config(fmt)
+    cfg['config']['layers'] = [cfg['config']['layers'][k] for k in (0, 1, 8, 10)] + [dict(cfg['config']['layers'][11])]
+    for a, b in ((1, 'in'), (2, 'c1'), (3, 'mp'), (4, 'fl')):
+        cfg['config']['layers'][a] = dict(cfg['config']['layers'][a], inbound_nodes=[[[b, 0, 0, {}]]])
+    w['out'] = {'kernel': r(17 * 5 * 8, 3), 'bias': r(3)}
+    chain, _ = KM.layers_from_keras_config(cfg, w)
+    assert not any('inputs' in L for L in chain)
+    # shared layers and several outputs are refused with a message, not mis-computed
+    bad = _keras_functional_config(fmt)
+    bad['config']['layers'][1]['inbound_nodes'] = bad['config']['layers'][1]['inbound_nodes'] * 2
+    with pytest.raises(NotImplementedError, match='called 2 times'):
+        KM.layers_from_keras_config(bad, w)
