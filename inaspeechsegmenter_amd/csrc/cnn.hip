@@ -1945,13 +1945,13 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         } else if (ws && ws_ring) {
             const unsigned ngroups = (unsigned)((a.M + a.tmr - 1) / a.tmr);      // one tile of tmr rows per group
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);
-            iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,false,true,1,%d,ring>", a.H_k, a.kw, padded ? "true" : "false", (int)issk::epi_is_pool_relu(a));
+            iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,false,true,1,%d,ring>", a.H_k, a.kw, padded ? "true" : "false", (int)issk::epi_is_pool_relu_any(a));
             issk::iss_ws_launch_ring(a, wgrid, c->stream, padded);
         } else if (ws && ws_fs) {
-            const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM * WS_G - 1) / ((long long)WS_TM * WS_G));
+            const unsigned ngroups = (unsigned)((a.M + (long long)WS_TM - 1) / (long long)WS_TM);      // FS: one tile per group (conv_ws.h G)
             const dim3 wgrid(std::min<unsigned>(ngroups, 256u), grid.y);
             iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,%s,true,1,%d,fs>", a.H_k, a.kw, padded ? "true" : "false", fs_tr_ok ? "true" : "false",
-                          fs_tr_ok ? 1 : (int)issk::epi_is_pool_relu(a));
+                          fs_tr_ok ? 1 : (int)issk::epi_is_pool_relu_any(a));
             if (fs_tr_ok) issk::iss_ws_launch_fs_5x3_tr(a, wgrid, c->stream);
             else if (a.H_k == 5) issk::iss_ws_launch_fs_5x3(a, wgrid, c->stream, padded);
             else issk::iss_ws_launch_fs_3x3(a, wgrid, c->stream, padded);
@@ -1993,7 +1993,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
                 issk::iss_wq_launch_5x3(a, qgrid, c->stream);
             } else {
             {
-                const int epi = tr ? issk::epi_is_simple_tr(a) : issk::epi_is_pool_relu(a);
+                const int epi = tr ? issk::epi_is_simple_tr(a) : issk::epi_is_pool_relu_any(a);
                 iss_prof_inst(c, "conv_x3_ws_kernel<%d,%d,%s,%s,true,1,%d>", a.H_k, a.kw, padded ? "true" : "false", tr ? "true" : "false", epi);
             }
 #define ISS_WS_CASE(KH_, KW_) if (a.H_k == KH_ && a.kw == KW_) iss_ws_launch_##KH_##x##KW_(a, wgrid, c->stream, padded, tr, fused); else

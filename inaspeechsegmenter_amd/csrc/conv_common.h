@@ -307,6 +307,12 @@ __device__ __forceinline__ void epilogue_pool_relu(const P& p, const floatx16& a
 inline bool epi_is_pool_relu(const ConvArgs& a) {
     return a.act == 1 && (a.pp == 2 || a.pp == 4) && a.poolkind == 0 && !a.ps && !a.res;
 }
+// ... and what the weight-stationary kernel's EPI = 1 forms take: epilogue_pool_relu's own code also carries relu + AVERAGE pool
+// (epilogue_impl<1, PP, false, false> falls through to its generic loop when poolkind != 0).  Only the max form may write CHL, and only
+// the max form is what the one-wave-per-SIMD kernels' hand-written epilogues compute: they keep asking epi_is_pool_relu.
+inline bool epi_is_pool_relu_any(const ConvArgs& a) {
+    return a.act == 1 && (a.pp == 2 || a.pp == 4) && (a.poolkind == 0 || a.poolkind == 1) && !a.ps && !a.res;
+}
 inline bool epi_is_simple_tr(const ConvArgs& a) { return a.act <= 1 && !a.ps && !a.res; }
 
 // Epilogue of TRANSPOSED accumulators (the MFMAs were issued as W-fragment x A-fragment, i.e. C^T): lane = GEMM row

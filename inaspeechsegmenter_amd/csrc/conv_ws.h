@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     constexpr int TG = RING ? ws_tg(NT) : NV;        // steps per tap group
     constexpr int NG = RING ? (NV + TG - 1) / TG : 1;
     constexpr int NRES = ws_resident(NT, NH);        // resident 4 KB weight tiles
-    constexpr int G = (NH == 2 || RING) ? 1 : WS_G;  // tiles per group
+    constexpr int G = (NH == 2 || RING || FS) ? 1 : WS_G;  // tiles per group (FS: one -- its 64 fewer accumulator registers are what the S-table arithmetic needs)
     constexpr int PIX = ws_pix(NH, NT);
     constexpr int WS_ZERO = PIX * F2_ROW;            // byte offset of the all-zero pixel behind the footprint
     constexpr int WS_NFV = PIX / 128;                // 128-pixel slices per footprint: 512 threads x 4 channels each
@@ -674,7 +674,7 @@ void launch_ws_shape(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded, 
         // instantiated for the shared-first-layer convolution (the dominant launch of the segmenter nets) -- every
         // instantiation costs minutes of compile time; the other footprint layers stay on conv_x3_fp_kernel
         if (!fused) return;
-        const bool fast = tr ? epi_is_simple_tr(a) : epi_is_pool_relu(a);
+        const bool fast = tr ? epi_is_simple_tr(a) : epi_is_pool_relu_any(a);
         if (padded) {
             if (tr) { if (fast) ISS_WS_LAUNCH(true, true, true, 1, 1); else ISS_WS_LAUNCH(true, true, true); }
             else { if (fast) ISS_WS_LAUNCH(true, false, true, 1, 1); else ISS_WS_LAUNCH(true, false, true); }
@@ -703,7 +703,7 @@ void iss_ws_launch_fs_3x3(const ConvArgs& a, dim3 grid, hipStream_t st, bool pad
 void iss_ws_launch_fs_5x3_tr(const ConvArgs& a, dim3 grid, hipStream_t st);   // unpadded, no fused pool: transposed simple epilogue (bias + relu)
 template <int KH, int KW, bool FS_>
 void launch_ws_fused_rowmajor(const ConvArgs& a, dim3 grid, hipStream_t st, bool padded) {
-    const bool fast = epi_is_pool_relu(a);
+    const bool fast = epi_is_pool_relu_any(a);
 #define ISS_WS_LAUNCH2(P_, E_) hipLaunchKernelGGL((conv_x3_ws_kernel<KH, KW, P_, false, true, 1, E_, FS_>), grid, dim3(512), 0, st, a)
     if (padded) { if (fast) ISS_WS_LAUNCH2(true, 1); else ISS_WS_LAUNCH2(true, 0); }
     else { if (fast) ISS_WS_LAUNCH2(false, 1); else ISS_WS_LAUNCH2(false, 0); }
