@@ -1569,7 +1569,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             iss_prof_begin(c, 0, 2.0 * K * (double)R[ISS_C_COUT] * (double)bc);
             iss_prof_tag(c, ISS_PROF_PW);
             iss_prof_row(c, r);
-            iss_prof_inst(c, "conv_dhl_kernel<%s>", f16 ? "true" : "false");
+            iss_prof_inst(c, "conv_dhl_kernel<%s,%d>", f16 ? "true" : "false", ISS_DHL_NW);       // <F16,NW>
             issk::iss_dhl_launch(d, c->stream, f16);
             iss_prof_end(c);
             return ISS_OK;

@@ -1,5 +1,5 @@
-// Instantiation unit of conv_dhl_kernel (conv_dhl.h): the first dense layer of the segmenter nets on the CHL tensor conv4 writes for
-// it, both operands by LDS-DMA; bf16 and fp16 operand halves.
+// Instantiation unit of conv_dhl_kernel (conv_dhl.h): the first dense layer of the segmenter nets on the pre-split (PHL) tensor conv4
+// writes for it; bf16 and fp16 operand halves.
 #include "conv_dhl.h"
 
 namespace issk {
@@ -24,7 +24,7 @@ void iss_dhl_pack(const uint16_t* wh, const uint16_t* wl, uint16_t* out, int Cou
 }
 void iss_dhl_launch(const DhlArgs& a, hipStream_t st, bool f16) {
     const dim3 grid((unsigned)((a.M + DHL_BM - 1) / DHL_BM));
-    if (f16) hipLaunchKernelGGL(conv_dhl_kernel<true>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(conv_dhl_kernel<false>, grid, dim3(256), 0, st, a);
+    if (f16) hipLaunchKernelGGL((conv_dhl_kernel<true>), grid, dim3(ISS_DHL_NW * 64), 0, st, a);
+    else hipLaunchKernelGGL((conv_dhl_kernel<false>), grid, dim3(ISS_DHL_NW * 64), 0, st, a);
 }
 }  // namespace issk

@@ -40,7 +40,7 @@ def _rand_dense(rng, i, o, act='linear'):
 
 # the fp16-operand instantiations of the segmenter nets' kernels, as iss_prof_get_instance spells them (template arguments)
 _F16_KERNELS = {'conv_x3_wq_kernel<5,3,true,true>', 'conv_x3_wq3h_kernel<0,true,true>', 'conv_x3_wq3h_kernel<1,true,true>',
-                'conv_dhl_kernel<true>'}
+                'conv_dhl_kernel<true,8>'}
 
 
 def _mspec(rng, T):
@@ -391,7 +391,7 @@ def test_one_wave_per_simd_kernels_edge_sizes(ctx, nmel, nout):
         if T >= 141:
             assert 'conv_x3_wq_kernel<5,3,true,false>' in used, (T, used)                          # <KH,KW,OUT_HL,F16>: conv2 writes CHL
             # conv3 (CHL out), conv4 (CHL of the flattened features out), the first dense layer on it
-            assert {'conv_x3_wq3h_kernel<0,true,false>', 'conv_x3_wq3h_kernel<1,true,false>', 'conv_dhl_kernel<false>'} <= used, (T, used)
+            assert {'conv_x3_wq3h_kernel<0,true,false>', 'conv_x3_wq3h_kernel<1,true,false>', 'conv_dhl_kernel<false,8>'} <= used, (T, used)
             assert sum(k.startswith('conv_x3_wq3_kernel') for k in used_f32) == 2 and 'conv_x3_wq_kernel<5,3,false,false>' in used_f32 \
                 and not any('wq3h' in k or 'dhl' in k for k in used_f32) and 'conv_x3_pw_kernel<false>' in used_f32, (T, used_f32)
     # irregular window lists (what the VAD-gated gender pass hands over): gaps, runs, repeats -- a footprint then spans two
