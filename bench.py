@@ -1086,6 +1086,15 @@ def main():
                 "flops_per_launch": kd["flops_per_launch"], "avg_launch_ms": kd["avg_launch_ms"],
                 "launches_per_step": kd["launches"], "kernel_ms_per_step": kd["ms_per_step"],
                 "mfma_executed_tflops": kd["achieved"] * (3 if x3 else 1),
+                # what the matrix pipe SUSTAINS under the chip's power cap on register-resident operands with every CU busy
+                # (tools/microbench/mfma_power_cap.hip, profiles/r06_mfma_power_cap.txt; static: measured once per round, on one box)
+                "sustained_mfma_ceiling": ({"f16_relu_data_tflops": 1620.0, "bf16_relu_data_tflops": 1715.0, "zeros_tflops": 2440.0,
+                                            "frac_of_ceiling": kd["achieved"] * 3 / (1620.0 if args.precision == 'f16x3' else 1715.0),
+                                            "what": "v_mfma_f32_32x32x16 with nothing else in the loop, 0.4-1.3 s per case: random-normal "
+                                                    "operands with relu'd A 1.62 PF (f16) / 1.72 PF (bf16) of the 2.5 PF dense peak, zeros "
+                                                    "2.44 PF -- the clock follows the power the operands' bit activity costs; frac_of_ceiling = "
+                                                    "this kernel's EXECUTED MFMA rate over that figure (profiles/r06_mfma_power_cap.txt)"}
+                                           if x3 else None),
                 "what": ("the kernel INSTANTIATION with the most HIP-event time in one dense step (template arguments spelled out: "
                          "<KH,KW,PADDED,TR,FUSED,NH,EPI>); achieved = its algorithmic flops per launch / its average launch duration. "
                          "split modes (f16x3 / bf16x3): three v_mfma_f32_32x32x16_{f16,bf16} per k-step on 16-bit hi/lo operand halves -- the "
