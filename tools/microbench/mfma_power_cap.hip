@@ -50,15 +50,23 @@ int main(int argc, char** argv) {
     uint4* d; float* o;
     hipMalloc(&d, N * 2); hipMalloc(&o, 1 << 24);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const char* names[] = {"random normal", "zeros", "relu(normal): half of A's values are zero", "lo parts (2^-11 of a normal)"};
+    const char* names[] = {"random normal", "zeros", "relu(normal): half of A's values are zero", "lo parts (2^-11 of a normal)",
+                           "relu'd A x B whose mantissas keep 5 bits (a short lo part)", "relu'd A x B whose mantissas keep 2 bits",
+                           "A and B mantissas keep 5 bits"};
     for (int f16 = 1; f16 >= 0; --f16)
-        for (int data = 0; data < 4; ++data)
+        for (int data = 0; data < 7; ++data)
             for (int waves = 4; waves <= 8; waves += 4) {
                 for (int i = 0; i < N; ++i) {
                     float x = data == 1 ? 0.f : gauss();
                     if (data == 2 && (i / 8) % 5 < 2) x = x > 0 ? x : 0.f;       // the A registers
                     if (data == 3) x *= 4.8828125e-4f;
+                    if (data >= 4 && (i / 8) % 5 < 2 && data != 6) x = x > 0 ? x : 0.f;
                     h[i] = f16 ? f16bits(x) : bf16bits(x);
+                    // B registers (and A for case 6): clear the low mantissa bits (f16: 10 stored bits, bf16: 7)
+                    if (data >= 4 && ((i / 8) % 5 >= 2 || data == 6)) {
+                        const int keep = data == 5 ? 2 : 5, stored = f16 ? 10 : 7;
+                        if (stored > keep) h[i] &= (uint16_t)~((1u << (stored - keep)) - 1u);
+                    }
                 }
                 hipMemcpy(d, h.data(), N * 2, hipMemcpyHostToDevice);
                 const int iters = 60000 * (argc > 1 ? atoi(argv[1]) : 1);
