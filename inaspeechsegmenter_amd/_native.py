@@ -15,7 +15,7 @@ PROG_COLS = 32
 OP_CONV, OP_POOL, OP_SOFTMAX, OP_STATPOOL, OP_ACT, OP_ELT = 1, 2, 3, 4, 5, 6
 (ELT_COPY, ELT_ADD, ELT_SUB, ELT_MUL, ELT_MAX, ELT_MIN, ELT_AVG, ELT_ZERO, ELT_PERMUTE) = range(9)     # ISS_OP_ELT kinds (ISS_C_ACT)
 (C_OP, C_IN, C_OUT, C_RES, C_H, C_W, C_CIN, C_HO, C_WO, C_COUT, C_KH, C_KW, C_SH, C_SW, C_PT, C_PL,
- C_ACT, C_WOFF, C_BOFF, C_PSOFF, C_PTOFF, C_INMODE, C_POOLKIND, C_ORDER, C_FPOOLH, C_FPOOLW, C_DUALW, C_DUALB, C_ACTPARAM) = range(29)
+ C_ACT, C_WOFF, C_BOFF, C_PSOFF, C_PTOFF, C_INMODE, C_POOLKIND, C_ORDER, C_FPOOLH, C_FPOOLW, C_DUALW, C_DUALB, C_ACTPARAM, C_ACTPARAM2, C_ACTPARAM3) = range(31)
 PREC_BF16X3, PREC_F32, PREC_F16X3 = 0, 1, 2
 K_ALIGN = 32          # conv weight rows are padded to a multiple of this many k
 BUF_INPUT = -2

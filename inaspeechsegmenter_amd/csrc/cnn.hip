@@ -928,8 +928,9 @@ __global__ void pool_kernel(const float* __restrict__ in, float* __restrict__ ou
 // Elementwise activations that are not fused into a producer's epilogue (ISS_OP_ACT): elu, leaky relu, selu, softplus, clipped relu.
 // One thread per 4 elements (the tail scalar), grid-stride; in place when in == out -- the op program's rows are, so the pointers are
 // NOT __restrict__ (iss_cnn_load refuses an ISS_OP_ACT row that reads the network input).
-__global__ __launch_bounds__(256) void act_kernel(const float* in, float* out, long long total, int act, float alpha) {
+__global__ __launch_bounds__(256) void act_kernel(const float* in, float* out, long long total, int act, float alpha, float p2, float p3) {
     auto f = [&](float v) {
+        if (act == 9) return v > p3 ? fminf(v, p2) : alpha * (v - p3);                   // keras.layers.ReLU(max_value = p2, negative_slope = alpha, threshold = p3)
         if (act == 8) return fminf(fmaxf(v, 0.f), alpha);                                // keras.layers.ReLU(max_value = alpha)
         if (act == 4) return v > 0.f ? v : alpha * (expf(v) - 1.f);                       // keras.activations.elu
         if (act == 5) return v > 0.f ? v : alpha * v;                                    // keras.layers.LeakyReLU
@@ -1125,7 +1126,7 @@ extern "C" int iss_cnn_load(iss_ctx* c, int id, const int32_t* prog, int32_t nro
                                "or the concatenated parameters lie outside the blob (include/iss.h)");
             }
         } else if (R[ISS_C_OP] == ISS_OP_ACT) {
-            if (R[ISS_C_ACT] < 4 || R[ISS_C_ACT] > 8) return bad("ISS_OP_ACT: activation code must be 4 (elu), 5 (leaky relu), 6 (selu), 7 (softplus) or 8 (relu with max_value)");
+            if (R[ISS_C_ACT] < 4 || R[ISS_C_ACT] > 9) return bad("ISS_OP_ACT: activation code must be 4 (elu), 5 (leaky relu), 6 (selu), 7 (softplus), 8 (relu with max_value) or 9 (keras ReLU in full)");
             if (R[ISS_C_IN] == ISS_BUF_INPUT) return bad("ISS_OP_ACT: an elementwise activation cannot read the network input (it works in place)");
         } else if (R[ISS_C_OP] == ISS_OP_ELT) {
             const int k = R[ISS_C_ACT];
@@ -2147,11 +2148,13 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             iss_prof_end(c);
         } else if (op == ISS_OP_ACT) {
             const long long total = (long long)bc * R[ISS_C_H] * R[ISS_C_W] * R[ISS_C_CIN];
-            float alpha;
+            float alpha, p2, p3;
             { const int32_t bits = R[ISS_C_ACTPARAM]; memcpy(&alpha, &bits, sizeof(float)); }
+            { const int32_t bits = R[ISS_C_ACTPARAM2]; memcpy(&p2, &bits, sizeof(float)); }
+            { const int32_t bits = R[ISS_C_ACTPARAM3]; memcpy(&p3, &bits, sizeof(float)); }
             iss_prof_begin(c, 2, 0);
             hipLaunchKernelGGL(act_kernel, dim3((unsigned)std::min<long long>((total + 1023) / 1024, 1 << 20)), dim3(256), 0, c->stream, in, out, total,
-                               R[ISS_C_ACT], alpha);
+                               R[ISS_C_ACT], alpha, p2, p3);
             iss_prof_end(c);
         } else if (op == ISS_OP_ELT) {
             const int k = R[ISS_C_ACT];

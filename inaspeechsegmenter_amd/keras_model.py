@@ -25,7 +25,7 @@ import numpy as np
 from . import _native as N
 
 _ACT_CODE = {None: 0, 'linear': 0, 'relu': 1, 'sigmoid': 2, 'tanh': 3}                 # fused into a conv / dense epilogue
-_ACT_OP_CODE = {'elu': 4, 'leaky_relu': 5, 'selu': 6, 'softplus': 7, 'relu_max': 8}    # their own elementwise op (ISS_OP_ACT)
+_ACT_OP_CODE = {'elu': 4, 'leaky_relu': 5, 'selu': 6, 'softplus': 7, 'relu_max': 8, 'relu_general': 9}    # their own elementwise op (ISS_OP_ACT)
 _ACT_DEFAULT_ALPHA = {'elu': 1.0, 'leaky_relu': 0.3}      # keras.activations.elu / keras.layers.LeakyReLU defaults
 
 
@@ -139,9 +139,12 @@ def layers_from_keras_config(model_config, weights):
             layers.append(dict(type='activation', name=name, fn=c['activation'], **_string_act_alpha(c['activation'])))
         elif cn == 'ReLU':
             slope = float(c.get('negative_slope', 0.0) or 0.0)
-            if float(c.get('threshold', 0.0) or 0.0) != 0.0 or (c.get('max_value') is not None and slope != 0.0):
-                raise NotImplementedError('ReLU with a threshold, or with max_value and negative_slope together')
-            if c.get('max_value') is not None:             # min(max(x, 0), max_value): its own elementwise op
+            thr = float(c.get('threshold', 0.0) or 0.0)
+            if thr != 0.0 or (c.get('max_value') is not None and slope != 0.0):
+                # keras.layers.ReLU in full: x > threshold ? min(x, max_value) : negative_slope * (x - threshold)
+                mv = float(c['max_value']) if c.get('max_value') is not None else float('inf')
+                layers.append(dict(type='activation', name=name, fn='relu_general', alpha=(slope, mv, thr)))
+            elif c.get('max_value') is not None:           # min(max(x, 0), max_value): its own elementwise op
                 layers.append(dict(type='activation', name=name, fn='relu_max', alpha=float(c['max_value'])))
             else:
                 layers.append(dict(type='activation', name=name, fn='relu') if slope == 0.0 else
@@ -431,7 +434,9 @@ class _Builder:
         r[N.C_H], r[N.C_W], r[N.C_CIN] = h, w, c
         r[N.C_HO], r[N.C_WO], r[N.C_COUT] = h, w, c
         r[N.C_ACT] = code
-        r[N.C_ACTPARAM] = int(np.array([alpha], np.float32).view(np.int32)[0])
+        prm = tuple(alpha) if isinstance(alpha, tuple) else (alpha, 0.0, 0.0)      # code 9: (negative_slope, max_value, threshold)
+        bits = np.array(prm, np.float32).view(np.int32)
+        r[N.C_ACTPARAM], r[N.C_ACTPARAM2], r[N.C_ACTPARAM3] = int(bits[0]), int(bits[1]), int(bits[2])
         for col in (N.C_WOFF, N.C_BOFF, N.C_PSOFF, N.C_PTOFF):
             r[col] = -1
         self.rows.append(r)
@@ -717,7 +722,7 @@ def _compile_chain(B, bufs, layers, cur, shape, pmap, first, padded_end, opts):
             # activation
             act_alpha = L.get('alpha') if ty in ('conv2d', 'dense') else None
             if act_name in (None, 'linear') and not softmax_after and j < n and layers[j]['type'] == 'activation' \
-                    and layers[j]['fn'] in ('relu', 'sigmoid', 'tanh', 'elu', 'leaky_relu', 'selu', 'softplus', 'relu_max'):
+                    and layers[j]['fn'] in ('relu', 'sigmoid', 'tanh', 'elu', 'leaky_relu', 'selu', 'softplus', 'relu_max', 'relu_general'):
                 act_name = layers[j]['fn']
                 act_alpha = layers[j].get('alpha')
                 j = peek(j + 1)
@@ -726,7 +731,10 @@ def _compile_chain(B, bufs, layers, cur, shape, pmap, first, padded_end, opts):
             # and an elementwise ISS_OP_ACT row follows; a BatchNorm behind such an activation is lowered on its own afterwards
             act_op = None
             if act_name in _ACT_OP_CODE:
-                alpha = float(act_alpha if act_alpha is not None else _ACT_DEFAULT_ALPHA.get(act_name, 0.0))
+                if act_name == 'relu_general':           # (negative_slope, max_value, threshold)
+                    alpha = tuple(float(v) for v in act_alpha)
+                else:
+                    alpha = float(act_alpha if act_alpha is not None else _ACT_DEFAULT_ALPHA.get(act_name, 0.0))
                 act_op = (_ACT_OP_CODE[act_name], alpha)
                 act_name = 'linear'
             if act_name not in _ACT_CODE:
@@ -743,7 +751,7 @@ def _compile_chain(B, bufs, layers, cur, shape, pmap, first, padded_end, opts):
             # non-overlapping 'valid' pool of 2 or 4 outputs right after -> epilogue
             fpool = None
             if fuse_pool and not softmax_after and j < n and layers[j]['type'] in ('maxpool', 'avgpool') and \
-                    (act_op is None or (layers[j]['type'] == 'maxpool' and act_op[1] >= 0.0)):
+                    (act_op is None or (layers[j]['type'] == 'maxpool' and (act_op[1][0] if isinstance(act_op[1], tuple) else act_op[1]) >= 0.0)):
                 PL = layers[j]
                 pph, ppw = PL['pool']
                 pst = tuple(PL.get('strides') or PL['pool'])

@@ -106,7 +106,9 @@ enum {
     ISS_OP_STATPOOL = 4,  /* mean || std over the time axis (resnet.py:123-127)          */
     ISS_OP_ACT      = 5,  /* elementwise activation beyond the fused ones: ISS_C_ACT 4 elu(alpha), 5 leaky relu(alpha),
                              6 selu, 7 softplus, 8 relu clipped at alpha (ReLU(max_value)); alpha = the float whose bits are in
-                             ISS_C_ACTPARAM; IN may equal OUT, and is never ISS_BUF_INPUT */
+                             ISS_C_ACTPARAM; 9 keras.layers.ReLU in full: x > threshold ? min(x, max_value) : negative_slope *
+                             (x - threshold), (negative_slope, max_value (+inf: none), threshold) in ISS_C_ACTPARAM, ..2, ..3;
+                             IN may equal OUT, and is never ISS_BUF_INPUT */
     ISS_OP_ELT      = 6,  /* merge / data-movement rows of graph-shaped models (keras.layers.Add, Concatenate, Permute ...; what
                              `keras.models.load_model`, segmenter.py:129-131, accepts beyond a chain).  Plain one-thread-per-element
                              kernels: correct, not fast.  ISS_C_ACT = kind (ISS_ELT_*); IN is never ISS_BUF_INPUT.
@@ -125,7 +127,7 @@ enum {
     ISS_C_OP = 0, ISS_C_IN, ISS_C_OUT, ISS_C_RES,      /* buffer ids; RES = residual add   */
     ISS_C_H, ISS_C_W, ISS_C_CIN, ISS_C_HO, ISS_C_WO, ISS_C_COUT,
     ISS_C_KH, ISS_C_KW, ISS_C_SH, ISS_C_SW, ISS_C_PT, ISS_C_PL,
-    ISS_C_ACT,                                          /* CONV: 0 none 1 relu 2 sigmoid 3 tanh (fused); ISS_OP_ACT rows: 4..8 */
+    ISS_C_ACT,                                          /* CONV: 0 none 1 relu 2 sigmoid 3 tanh (fused); ISS_OP_ACT rows: 4..9 */
     ISS_C_WOFF, ISS_C_BOFF,                             /* blob offsets: W [Cout][roundup32(kh*kw*Cin)] (WOFF % 8 == 0), bias */
     ISS_C_PSOFF, ISS_C_PTOFF,                           /* post-activation scale / shift   */
     ISS_C_INMODE,                                       /* 0 NHWC buffer, 1 z-normed mspec patch,
@@ -146,6 +148,7 @@ enum {
                                                            inputs (row r - 1's output is never materialised); it falls back
                                                            to the two rows whenever it cannot.  Both CIN % 32 == 0. */
     ISS_C_ACTPARAM,                                     /* ISS_OP_ACT: the bits of the activation's float parameter (alpha of elu / leaky relu) */
+    ISS_C_ACTPARAM2, ISS_C_ACTPARAM3,                   /* ISS_OP_ACT code 9: max_value, threshold */
 };
 #define ISS_BUF_INPUT  (-2)   /* IN: the network input (patch source or iss_cnn_forward input) */
 

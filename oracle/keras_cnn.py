@@ -42,6 +42,9 @@ def _act_np(x, fn, alpha=None):
         return x
     if fn == 'relu':
         return np.maximum(x, 0)
+    if fn == 'relu_general':                       # keras.layers.ReLU(max_value, negative_slope, threshold); alpha = (slope, max, thr)
+        sl, mv, th = (np.float32(v) for v in alpha)
+        return np.where(x > th, np.minimum(x, mv), sl * (x - th)).astype(np.float32)
     if fn == 'relu_max':                           # keras.layers.ReLU(max_value=alpha): min(max(x, 0), alpha)
         return np.minimum(np.maximum(x, 0), np.float32(alpha))
     if fn == 'elu':                                # keras.activations.elu: x if x > 0 else alpha * (exp(x) - 1)
@@ -75,6 +78,9 @@ def forward(layers, x, batch_size=1024, threads=None):
             return t
         if fn == 'relu':
             return torch.relu(t)
+        if fn == 'relu_general':
+            sl, mv, th = (float(v) for v in alpha)
+            return torch.where(t > th, torch.clamp(t, max=mv), sl * (t - th))
         if fn == 'relu_max':
             return torch.clamp(t, 0.0, float(alpha))
         if fn == 'elu':

@@ -61,7 +61,10 @@ def run(comp, x):
         elif op == N.OP_ACT:                         # elementwise elu / leaky relu / selu / softplus (in place in the program)
             alpha = float(np.array([int(R[N.C_ACTPARAM])], np.int32).view(np.float32)[0])
             out = {4: lambda: F.elu(src, alpha=alpha), 5: lambda: F.leaky_relu(src, negative_slope=alpha), 6: lambda: F.selu(src),
-                   7: lambda: F.softplus(src), 8: lambda: torch.clamp(src, 0.0, alpha)}[int(R[N.C_ACT])]()
+                   7: lambda: F.softplus(src), 8: lambda: torch.clamp(src, 0.0, alpha),
+                   9: lambda: (lambda mv, th: torch.where(src > th, torch.clamp(src, max=mv), alpha * (src - th)))(
+                       float(np.array([int(R[N.C_ACTPARAM2])], np.int32).view(np.float32)[0]),
+                       float(np.array([int(R[N.C_ACTPARAM3])], np.int32).view(np.float32)[0]))}[int(R[N.C_ACT])]()
         elif op == N.OP_ELT:                         # merge / data-movement rows of graph-shaped models
             kind = int(R[N.C_ACT])
             if N.ELT_ADD <= kind <= N.ELT_AVG:

@@ -103,6 +103,7 @@ TOPOLOGIES = {
         dict(type='maxpool', pool=(2, 2), strides=(2, 2), padding='valid'),
         dict(type='depthwise', W=r.normal(0, 0.4, (3, 3, 32, 1)).astype(np.float32), b=None, strides=(1, 1), padding='same',
              activation='linear', dilation=(1, 2)),
+        dict(type='activation', fn='relu_general', alpha=(0.1, 1.2, 0.15)),                  # keras.layers.ReLU in full (ISS_OP_ACT code 9)
         _rand_conv(r, 1, 1, 32, 32, act='relu'), dict(type='globalavgpool'), _rand_dense(r, 32, 3, 'softmax')],
     'standalone_bn_first': lambda r, h: [_rand_bn(r, 1), _rand_conv(r, 3, 3, 1, 4, act='relu'), dict(type='dropout'),
                                          dict(type='flatten'), _rand_dense(r, 66 * (h - 2) * 4, 64, 'relu'), _rand_bn(r, 64),

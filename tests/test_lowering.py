@@ -133,24 +133,25 @@ def test_more_activations_parse_lower_and_run():
         {'class_name': 'GlobalMaxPooling2D', 'config': {'name': 'g'}},
         {'class_name': 'Dense', 'config': {'name': 'd1', 'activation': 'softplus'}},
         {'class_name': 'ReLU', 'config': {'name': 'r1', 'negative_slope': 0.05}},
+        {'class_name': 'ReLU', 'config': {'name': 'r2', 'negative_slope': 0.1, 'max_value': 0.9, 'threshold': 0.2}},
         {'class_name': 'Dense', 'config': {'name': 'd2', 'activation': 'softmax'}}]}}
     weights = {'c1': {'kernel': k1, 'bias': rng.normal(0, 0.1, 8).astype(np.float32)}, 'c2': {'kernel': k2, 'bias': np.zeros(16, np.float32)},
                'd1': {'kernel': d1, 'bias': np.zeros(12, np.float32)}, 'd2': {'kernel': d2, 'bias': np.zeros(3, np.float32)}}
     layers, shp = KM.layers_from_keras_config(cfg, weights)
     fns = [(L['fn'], L.get('alpha')) for L in layers if L['type'] == 'activation']
-    assert fns == [('leaky_relu', 0.15), ('elu', 0.5), ('leaky_relu', 0.05)]
+    assert fns == [('leaky_relu', 0.15), ('elu', 0.5), ('leaky_relu', 0.05), ('relu_general', (0.1, 0.9, 0.2))]
     comp = KM.compile_layers(layers, shp)
     acts = [(int(R[N.C_ACT]), float(np.array([int(R[N.C_ACTPARAM])], np.int32).view(np.float32)[0])) for R in comp.prog if R[N.C_OP] == N.OP_ACT]
-    assert [a for a, _ in acts] == [5, 6, 4, 7, 5] and abs(acts[0][1] - 0.15) < 1e-7 and abs(acts[2][1] - 0.5) < 1e-7 and acts[1][1] == 0.0
+    assert [a for a, _ in acts] == [5, 6, 4, 7, 5, 9] and abs(acts[0][1] - 0.15) < 1e-7 and abs(acts[2][1] - 0.5) < 1e-7 and acts[1][1] == 0.0
     assert all(int(R[N.C_ACT]) == 0 for R in comp.prog if R[N.C_OP] == N.OP_CONV)           # the producers run linear
     first = [R for R in comp.prog if R[N.C_OP] == N.OP_CONV][0]
     assert int(first[N.C_FPOOLH]) == 2 and int(first[N.C_FPOOLW]) == 2                        # max pool fused IN FRONT of the leaky relu
     x = rng.normal(0, 1, (3,) + shp).astype(np.float32)
     want = ocnn.forward(layers, x)
     assert np.abs(prog_interp.run(comp, x) - want).max() < 2e-5 and np.abs(ocnn.forward_naive(layers, x[:1]) - want[:1]).max() < 2e-5
-    with pytest.raises(NotImplementedError):
-        KM.layers_from_keras_config({'class_name': 'Sequential', 'config': {'layers': [
-            {'class_name': 'ReLU', 'config': {'name': 'r', 'threshold': 0.5, 'batch_input_shape': [None, 68, 21, 1]}}]}}, {})
+    thr, _ = KM.layers_from_keras_config({'class_name': 'Sequential', 'config': {'layers': [
+        {'class_name': 'ReLU', 'config': {'name': 'r', 'threshold': 0.5, 'batch_input_shape': [None, 68, 21, 1]}}]}}, {})
+    assert thr[0]['fn'] == 'relu_general' and thr[0]['alpha'] == (0.0, float('inf'), 0.5)
 
 
 def test_layers_without_a_kernel_of_their_own_are_lowered_through_ordinary_convolutions():
