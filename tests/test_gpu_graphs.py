@@ -3,6 +3,8 @@ inception-style concatenations (incl. along H / W), permutes, reshapes, several 
 lowered onto chains (the usual kernels and fusions) joined by ISS_OP_ELT rows, against the Keras-semantics oracle: 1e-4 on
 probabilities on the segmenter's overlapping windows and on scattered windows, in the split-operand and in the exact-f32 arithmetic.
 `keras.models.load_model` (segmenter.py:129-131) accepts any of them; none may end in "no output"."""
+import os
+
 import numpy as np
 import pytest
 
@@ -54,7 +56,9 @@ def test_graph_model_parity(ctx, name):
         print(f'{name} nmel {nmel}: max |dp| {err:.2e}')
 
 
-@pytest.mark.parametrize('seed', range(16))
+# `ISS_GRAPH_FUZZ_N` / `ISS_GRAPH_FUZZ_BASE` widen the draw for a one-off soak run (profiles/r06_scripts/r06_graph_soak.sh)
+@pytest.mark.parametrize('seed', range(int(os.environ.get('ISS_GRAPH_FUZZ_BASE', '0')),
+                                       int(os.environ.get('ISS_GRAPH_FUZZ_BASE', '0')) + int(os.environ.get('ISS_GRAPH_FUZZ_N', '16'))))
 def test_random_graph_parity(ctx, seed):
     rng = np.random.default_rng(1000 + seed)
     T = 600
