@@ -951,11 +951,21 @@ __global__ __launch_bounds__(256) void act_kernel(const float* in, float* out, l
 __global__ __launch_bounds__(256) void elt_kernel(const float* in, const float* res, float* out, long long total, int kind,
                                                   int cin, int cout, int nch, int soff, int doff, int d0, int d1, int d2,
                                                   int s0, int s1, int s2) {
+    auto bin = [&](float a, float b) {
+        return kind == ISS_ELT_ADD ? a + b : kind == ISS_ELT_SUB ? a - b : kind == ISS_ELT_MUL ? a * b :
+               kind == ISS_ELT_MAX ? fmaxf(a, b) : kind == ISS_ELT_MIN ? fminf(a, b) : (a + b) * 0.5f;
+    };
+    if (kind >= ISS_ELT_ADD && kind <= ISS_ELT_AVG && (total & 3) == 0) {      // float4 at a time (buffers are 256-byte aligned)
+        const long long n4 = total >> 2;
+        for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const float4 a = reinterpret_cast<const float4*>(in)[i], b = reinterpret_cast<const float4*>(res)[i];
+            reinterpret_cast<float4*>(out)[i] = make_float4(bin(a.x, b.x), bin(a.y, b.y), bin(a.z, b.z), bin(a.w, b.w));
+        }
+        return;
+    }
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         if (kind >= ISS_ELT_ADD && kind <= ISS_ELT_AVG) {
-            const float a = in[i], b = res[i];
-            out[i] = kind == ISS_ELT_ADD ? a + b : kind == ISS_ELT_SUB ? a - b : kind == ISS_ELT_MUL ? a * b :
-                     kind == ISS_ELT_MAX ? fmaxf(a, b) : kind == ISS_ELT_MIN ? fminf(a, b) : (a + b) * 0.5f;
+            out[i] = bin(in[i], res[i]);
         } else if (kind == ISS_ELT_COPY || kind == ISS_ELT_ZERO) {       // total = pixels * nch
             const long long p = i / nch;
             const int ch = (int)(i - p * nch);
