@@ -88,3 +88,28 @@ def test_merge_rows_are_refused_when_malformed(ctx):
     bad.prog[k, _native.C_KW] = bad.prog[k, _native.C_KH]
     with pytest.raises(_native.NativeError, match='permutation'):
         ctx.cnn_load(6, bad)
+
+
+def test_precision_guard_probes_a_graph_model(ctx):
+    """The library's first-call probe (iss_set_precision_guard) runs a graph-shaped network in its split mode and in exact f32 like any
+    other program -- merge rows included -- and records the figure; fp16 halves (the product's default) pass on the residual stand-in."""
+    rng = np.random.default_rng(77)
+    T = 900
+    mspec = _mspec(rng, T)
+    ctx.set_mspec(mspec)
+    layers, shp = GN.NETS['standin_residual'](21, 3, 5)
+    rows = S._window_rows(T)
+    ctx.set_precision(_native.PREC_F16X3)
+    ctx.set_precision_guard(5e-4)
+    try:
+        ctx.cnn_load(5, KM.compile_layers(layers, shp))
+        assert ctx.cnn_precision_info(5)['state'] == 'pending'
+        probs, fin = ctx.cnn_probs(5, rows)
+        info = ctx.cnn_precision_info(5)
+        print('graph model:', info)
+        assert info['state'] == 'passed' and info['mode'] == 'f16x3' and 0 <= info['max_dlogp'] < 5e-4 and info['slots'] > 100, info
+        ref, rfin = _oracle_probs(layers, mspec, 21, rows)
+        assert np.array_equal(fin, rfin) and np.abs(probs - ref).max() < 1e-4
+    finally:
+        ctx.set_precision_guard(0)
+        ctx.set_precision(_native.PREC_BF16X3)
