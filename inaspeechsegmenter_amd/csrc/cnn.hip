@@ -950,10 +950,11 @@ __global__ __launch_bounds__(256) void act_kernel(const float* in, float* out, l
 // `res` and `out` may alias for the binary kinds (each element is read before it is written, by the same thread).
 __global__ __launch_bounds__(256) void elt_kernel(const float* in, const float* res, float* out, long long total, int kind,
                                                   int cin, int cout, int nch, int soff, int doff, int d0, int d1, int d2,
-                                                  int s0, int s1, int s2) {
+                                                  int s0, int s1, int s2, int relu) {
     auto bin = [&](float a, float b) {
-        return kind == ISS_ELT_ADD ? a + b : kind == ISS_ELT_SUB ? a - b : kind == ISS_ELT_MUL ? a * b :
-               kind == ISS_ELT_MAX ? fmaxf(a, b) : kind == ISS_ELT_MIN ? fminf(a, b) : (a + b) * 0.5f;
+        const float v = kind == ISS_ELT_ADD ? a + b : kind == ISS_ELT_SUB ? a - b : kind == ISS_ELT_MUL ? a * b :
+                        kind == ISS_ELT_MAX ? fmaxf(a, b) : kind == ISS_ELT_MIN ? fminf(a, b) : (a + b) * 0.5f;
+        return relu ? fmaxf(v, 0.f) : v;
     };
     if (kind >= ISS_ELT_ADD && kind <= ISS_ELT_AVG && (total & 3) == 0) {      // float4 at a time (buffers are 256-byte aligned)
         const long long n4 = total >> 2;
@@ -2181,7 +2182,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             iss_prof_begin(c, 2, 0);
             hipLaunchKernelGGL(elt_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 1 << 20)), dim3(256), 0, c->stream, in, res, out,
                                total, k, R[ISS_C_CIN], R[ISS_C_COUT], R[ISS_C_KH], R[ISS_C_PT], R[ISS_C_PL],
-                               R[ISS_C_HO], R[ISS_C_WO], R[ISS_C_COUT], st[0], st[1], st[2]);
+                               R[ISS_C_HO], R[ISS_C_WO], R[ISS_C_COUT], st[0], st[1], st[2], R[ISS_C_ORDER] == 1 ? 1 : 0);
             iss_prof_end(c);
         } else if (op == ISS_OP_STATPOOL) {
             const long long total = (long long)bc * R[ISS_C_H] * R[ISS_C_CIN];

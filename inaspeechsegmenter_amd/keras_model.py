@@ -442,7 +442,7 @@ class _Builder:
         self.rows.append(r)
         return shape_in
 
-    def elt(self, kind, src, dst, shape_in, shape_out, res=-1, nch=0, soff=0, doff=0, perm=(0, 0, 0)):
+    def elt(self, kind, src, dst, shape_in, shape_out, res=-1, nch=0, soff=0, doff=0, perm=(0, 0, 0), relu=False):
         """Merge / data-movement row (ISS_OP_ELT, include/iss.h): binary kinds on (src, res) -> dst; COPY / ZERO of `nch` channels
         from channel soff of src to channel doff of dst; PERMUTE of the (H, W, C) axes."""
         h, w, c = shape_in
@@ -453,6 +453,7 @@ class _Builder:
         r[N.C_H], r[N.C_W], r[N.C_CIN] = h, w, c
         r[N.C_HO], r[N.C_WO], r[N.C_COUT] = ho, wo, co
         r[N.C_ACT] = kind
+        r[N.C_ORDER] = 1 if relu else 0
         if kind in (N.ELT_COPY, N.ELT_ZERO):
             r[N.C_KH], r[N.C_PT], r[N.C_PL] = nch, soff, doff
         elif kind == N.ELT_PERMUTE:
@@ -984,10 +985,18 @@ def _compile_graph(B, layers, in_shape, opts):
                     raise ValueError("Subtract takes exactly two inputs")
                 kind = _MERGE_KIND[L['type']]
                 many_avg = L['type'] == 'average' and len(ts) > 2
+                # a ReLU that is the merge's only reader (the Add + ReLU of a residual block) rides in the last merge row
+                rd = readers[out_nm]
+                fuse = (not many_avg and len(rd) == 1 and layers[rd[0]]['type'] == 'activation' and layers[rd[0]]['fn'] == 'relu'
+                        and ins[rd[0]] == [out_nm])
                 dst = bufs.alloc(-1)
-                B.elt(N.ELT_ADD if many_avg else kind, ts[0][0], dst, base, base, res=ts[1][0])
-                for t in ts[2:]:
-                    B.elt(N.ELT_ADD if many_avg else kind, dst, dst, base, base, res=t[0])
+                B.elt(N.ELT_ADD if many_avg else kind, ts[0][0], dst, base, base, res=ts[1][0], relu=fuse and len(ts) == 2)
+                for q, t in enumerate(ts[2:]):
+                    B.elt(N.ELT_ADD if many_avg else kind, dst, dst, base, base, res=t[0], relu=fuse and q == len(ts) - 3)
+                if fuse:                              # the activation layer is done: its readers read the merge's buffer
+                    done.add(rd[0])
+                    out_nm = names[rd[0]]
+                    nrd = len(readers[out_nm])
                 if many_avg:                          # mean of n > 2 tensors: the sum through an identity 1x1 conv scaled by 1 / n
                     bufs.pin(dst, 1)
                     d2 = bufs.alloc(dst)

@@ -113,7 +113,7 @@ enum {
                              `keras.models.load_model`, segmenter.py:129-131, accepts beyond a chain).  Plain one-thread-per-element
                              kernels: correct, not fast.  ISS_C_ACT = kind (ISS_ELT_*); IN is never ISS_BUF_INPUT.
                              kinds ADD .. AVG: OUT[i] = IN[i] (op) RES[i] over H * W * CIN floats per sample (HO, WO, COUT = H, W, CIN;
-                                               OUT may be IN or RES);
+                                               OUT may be IN or RES); ISS_C_ORDER = 1: followed by relu (Add + ReLU of a residual block);
                              COPY:    OUT[p][PL + c] = IN[p][PT + c] for c < KH, p over the H * W pixels; IN holds CIN and OUT COUT
                                       channels per pixel (HO, WO = H, W); OUT != IN.  Concatenate = one COPY per input;
                              ZERO:    OUT[p][PL + c] = 0 for c < KH (channel padding behind a COPY);

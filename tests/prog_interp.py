@@ -72,6 +72,8 @@ def run(comp, x):
                 out = {N.ELT_ADD: lambda: src + b, N.ELT_SUB: lambda: src - b, N.ELT_MUL: lambda: src * b,
                        N.ELT_MAX: lambda: torch.maximum(src, b), N.ELT_MIN: lambda: torch.minimum(src, b),
                        N.ELT_AVG: lambda: (src + b) * 0.5}[kind]()
+                if int(R[N.C_ORDER]) == 1:
+                    out = torch.relu(out)
             elif kind in (N.ELT_COPY, N.ELT_ZERO):
                 nch, soff, doff = int(R[N.C_KH]), int(R[N.C_PT]), int(R[N.C_PL])
                 old = bufs.get(int(R[N.C_OUT]))
