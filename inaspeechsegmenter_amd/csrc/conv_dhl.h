@@ -133,20 +133,26 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_dhl_kernel(const DhlArgs p) {
     __syncthreads();
     int kt = 0;
     unsigned cur = 0;
+    // timing-only experiment bits (-DISS_DHL_EXP=.., with -DISS_DHL_NW=4 what profiles/r06_dhl_experiments.txt was measured on; wrong
+    // results, never in a release build): 4 no staging stores, 8 fragments read once, 16 no global loads, 32 no barrier
+#ifndef ISS_DHL_EXP
+#define ISS_DHL_EXP 0
+#endif
+    Frag f0, f1;
+    if (ISS_DHL_EXP & 8) { read_frags(f0, s0, 0); read_frags(f1, s0, 1); }
     auto step = [&](Regs& rload, Regs& rstage) {
         const unsigned st = s0 + cur * (unsigned)DHL_STAGE;
-        Frag f0, f1;
-        read_frags(f0, st, 0);
-        gather(rload, kt + 2 < nk ? kt + 2 : nk - 1);
-        read_frags(f1, st, 1);
+        if (!(ISS_DHL_EXP & 8)) read_frags(f0, st, 0);
+        if (!(ISS_DHL_EXP & 16)) gather(rload, kt + 2 < nk ? kt + 2 : nk - 1);
+        if (!(ISS_DHL_EXP & 8)) read_frags(f1, st, 1);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(f0);
         __builtin_amdgcn_sched_barrier(0);
-        stage(rstage, cur ^ 1u);
+        if (!(ISS_DHL_EXP & 4)) stage(rstage, cur ^ 1u);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(f1);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        if (!(ISS_DHL_EXP & 32)) __syncthreads();
         ++kt;
         cur ^= 1u;
     };
