@@ -123,7 +123,11 @@ __global__ __launch_bounds__(512, 2) void conv_x3_ws_kernel(const ConvArgs p) {
     constexpr int TG = RING ? ws_tg(NT) : NV;        // steps per tap group
     constexpr int NG = RING ? (NV + TG - 1) / TG : 1;
     constexpr int NRES = ws_resident(NT, NH);        // resident 4 KB weight tiles
-    constexpr int G = (NH == 2 || RING || FS) ? 1 : WS_G;  // tiles per group (FS: one -- its 64 fewer accumulator registers are what the S-table arithmetic needs)
+#ifdef ISS_WS_FS_G2                                  // comparison build only (profiles/r06_scripts/r06_fs_g_ab.sh): the FS form with two tiles per group, as in round 5
+    constexpr int G = (NH == 2 || RING) ? 1 : WS_G;
+#else
+    constexpr int G = (NH == 2 || RING || FS) ? 1 : WS_G;
+#endif  // tiles per group (FS: one -- its 64 fewer accumulator registers are what the S-table arithmetic needs)
     constexpr int PIX = ws_pix(NH, NT);
     constexpr int WS_ZERO = PIX * F2_ROW;            // byte offset of the all-zero pixel behind the footprint
     constexpr int WS_NFV = PIX / 128;                // 128-pixel slices per footprint: 512 threads x 4 channels each
