@@ -297,3 +297,24 @@ def test_functional_model_config_with_branches_parses_and_lowers(fmt):
     bad['config']['layers'][1]['inbound_nodes'] = bad['config']['layers'][1]['inbound_nodes'] * 2
     with pytest.raises(NotImplementedError, match='called 2 times'):
         KM.layers_from_keras_config(bad, w)
+
+
+def test_functional_graph_model_file_round_trip(tmp_path):
+    """A branched functional model through the file path `Segmenter` takes (keras_model.load_model_file, .npz form written by
+    tools/convert_keras_hdf5.py: 'model_config' JSON + '<layer>/<weight>' arrays): parsed, lowered and executed like the oracle."""
+    import json
+    rng = np.random.default_rng(4)
+    r = lambda *s: rng.normal(0, 0.3, s).astype(np.float32)
+    w = {'c1': {'kernel': r(3, 3, 1, 8), 'bias': r(8)}, 'c2': {'kernel': r(3, 3, 8, 8), 'bias': r(8)},
+         'bn': {'gamma': 1 + r(8), 'beta': r(8), 'moving_mean': r(8), 'moving_variance': 1 + np.abs(r(8))},
+         'sep': {'depthwise_kernel': r(3, 3, 8, 1), 'pointwise_kernel': r(1, 1, 8, 8), 'bias': r(8)},
+         'out': {'kernel': r(17 * 5 * 16, 3), 'bias': r(3)}}
+    arrays = {f'{ln}/{ln}/{wn}:0': a for ln, ws in w.items() for wn, a in ws.items()}
+    path = str(tmp_path / 'graph_model.npz')
+    np.savez(path, model_config=json.dumps(_keras_functional_config(3)), **arrays)
+    layers, shp = KM.load_model_file(path)
+    assert shp == (68, 21, 1) and any(L['type'] == 'add' for L in layers) and any(L['type'] == 'concatenate' for L in layers)
+    x = rng.normal(0, 1, (2,) + shp).astype(np.float32)
+    ref_layers, _ = KM.layers_from_keras_config(_keras_functional_config(3), w)
+    got = prog_interp.run(KM.compile_layers(layers, shp), x)
+    assert np.abs(got - ocnn.forward(ref_layers, x)).max() < 2e-5
