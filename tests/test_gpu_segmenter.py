@@ -355,3 +355,34 @@ def test_segmenter_loads_keras_hdf5_files_from_the_model_dir(tmp_path, monkeypat
     with pytest.raises(FileNotFoundError):                                     # the sm engine's file is not there: the reference's message
         Segmenter(vad_engine='sm', detect_gender=False, ffmpeg=None)
     s2.close()
+
+
+def test_graph_shaped_models_through_the_file_pipeline(tmp_path):
+    """A Segmenter whose two nets are functional models with branches (tests/graph_nets.py: a residual block in the stand-in's trunk,
+    an inception-style concatenation) -- lowered as chains joined by ISS_OP_ELT rows -- through single calls and batch_process, against
+    the oracle pipeline on the same layers: the product path computes whatever `keras.models.load_model` (segmenter.py:129-131) would
+    have handed the reference."""
+    import graph_nets as GN
+    from oracle import sidekit as osk, segment as oseg, keras_cnn as ocnn
+    vad, gender = GN.NETS['standin_residual'](21, 3, 3), GN.NETS['inception'](24, 2, 4)
+    models = {'keras_speech_music_noise_cnn.hdf5': vad, 'keras_male_female_cnn.hdf5': gender}
+    s2 = Segmenter(vad_engine='smn', detect_gender=True, ffmpeg=None, models=models)
+    lin = []
+    for i in range(3):
+        _wav(tmp_path / f'g{i}.wav', synth_pcm(170 + i, 16000 * (14 + 6 * i) + 7 * i))
+        lin.append(str(tmp_path / f'g{i}.wav'))
+    single = [s2(p) for p in lin]
+    lout = [str(tmp_path / f'go_{i}.csv') for i in range(3)]
+    t, nb, avg, lmsg = s2.batch_process(lin, lout, batch_files=2, workers=2)
+    assert nb == 3, lmsg
+    for seg_i, dst in zip(single, lout):
+        ref = str(tmp_path / 'gref.csv')
+        seg2csv(seg_i, ref)
+        assert filecmp.cmp(dst, ref, shallow=False), dst
+    from inaspeechsegmenter_amd.io import decode_pcm
+    pcm = decode_pcm(lin[1], None, None, None)
+    mspec, loge, difflen = osk.media2feats((pcm / 32768.0).astype(np.float32))
+    want = oseg.segment_feats(mspec, loge, difflen, 0, 'smn', lambda b: ocnn.forward(vad[0], b), lambda b: ocnn.forward(gender[0], b))
+    got = single[1]
+    assert [g[0] for g in got] == [w[0] for w in want] and [g[1:] for g in got] == [w[1:] for w in want], (got, want)
+    s2.close()
