@@ -1572,7 +1572,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const int K = R[ISS_C_CIN];
             uint16_t*& wp = n.dhl_wp[{r, f16 ? 1 : 0}];
             if (!wp) {
-                ISS_HIP(c, hipMalloc((void**)&wp, issk::dhl_packed_elems(K) * 2));
+                ISS_HIP(c, hipMalloc((void**)&wp, issk::dhl_packed_elems(K, R[ISS_C_COUT]) * 2));
                 issk::iss_dhl_pack((f16 ? n.d_wh16 : n.d_wh) + R[ISS_C_WOFF], (f16 ? n.d_wl16 : n.d_wl) + R[ISS_C_WOFF], wp, R[ISS_C_COUT], n.kpad[r], K, c->stream);
             }
             issk::DhlArgs d;

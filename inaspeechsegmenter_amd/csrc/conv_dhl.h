@@ -28,7 +28,7 @@ constexpr int DHL_STAGE = DHL_A + DHL_B;           // 40 KB
 
 struct DhlArgs {
     const uint16_t* a;       // PHL tensor: [window][K / 8 groups][hi 8 | lo 8] x 16 bit (K * 4 bytes per window)
-    const uint16_t* wp;      // packed weights: [K / 32][4 k-groups][2 parts][192 columns][8]
+    const uint16_t* wp;      // packed weights: [column tile of 192][K / 32][4 k-groups][2 parts][192 columns][8]
     const float* bias;       // [Cout] or null
     float* out;              // [M][Cout] f32
     unsigned np;             // windows the tensor has room for (a multiple of 128 >= M: rows beyond M are read, never stored)
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_dhl_kernel(const DhlArgs p) {
     const int li = lane & 31, lh = lane >> 5;
     const int wr = wv >> 1, wc = wv & 1;                                // row group of 32 RB rows, 96-column half
     const int m0 = (int)blockIdx.x * DHL_BM;
+    const int n0 = (int)blockIdx.y * DHL_BN;                            // column tile (layers wider than 192: the activation is re-read per tile)
     const int nk = p.K / DHL_BK;
     const unsigned rowbytes = (unsigned)p.K * 4u;                       // bytes per window
 
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_dhl_kernel(const DhlArgs p) {
     struct Regs { u32x4 a[NA], b[NB]; };
     auto gather = [&](Regs& r, int kt) {
         const unsigned char* ab = reinterpret_cast<const unsigned char*>(p.a) + (size_t)kt * 128;               // 128 B per window and k-tile
-        const unsigned char* bb = reinterpret_cast<const unsigned char*>(p.wp) + (size_t)kt * DHL_B;
+        const unsigned char* bb = reinterpret_cast<const unsigned char*>(p.wp) + ((size_t)blockIdx.y * nk + kt) * DHL_B;
 #pragma unroll
         for (int j = 0; j < NA; ++j) r.a[j] = *reinterpret_cast<const u32x4*>(ab + a_src[j]);
 #pragma unroll
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_dhl_kernel(const DhlArgs p) {
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = wc * 96 + c * 32 + 8 * g + 4 * lh;
+                const int n = n0 + wc * 96 + c * 32 + 8 * g + 4 * lh;
                 if (n >= p.Cout) continue;
                 float4 v = make_float4(acc[r][c][4 * g], acc[r][c][4 * g + 1], acc[r][c][4 * g + 2], acc[r][c][4 * g + 3]);
                 if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
@@ -185,10 +186,11 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_dhl_kernel(const DhlArgs p) {
 
 // host: the dense row the kernel takes (after a conv_x3_wq3h_kernel<1, ..> launch whose pooled output it reads)
 inline bool dhl_supported(int K, int Cout, int act, bool has_ps, bool has_res) {
-    return K % DHL_BK == 0 && K >= 2 * DHL_BK && Cout % 4 == 0 && Cout <= DHL_BN && act <= 1 && !has_ps && !has_res;
+    return K % DHL_BK == 0 && K >= 2 * DHL_BK && Cout % 4 == 0 && Cout >= 32 && Cout <= 16 * DHL_BN && act <= 1 && !has_ps && !has_res;
 }
+__host__ __device__ inline int dhl_col_tiles(int Cout) { return (Cout + DHL_BN - 1) / DHL_BN; }
 inline unsigned dhl_npad(long long windows) { return (unsigned)((windows + DHL_BM - 1) / DHL_BM * DHL_BM); }
-inline size_t dhl_packed_elems(int K) { return (size_t)(K / 8) * 2 * DHL_BN * 8; }
+inline size_t dhl_packed_elems(int K, int Cout = DHL_BN) { return (size_t)dhl_col_tiles(Cout) * (K / 8) * 2 * DHL_BN * 8; }   // [column tile][K / 32][4][2][192][8]
 void iss_dhl_pack(const uint16_t* wh, const uint16_t* wl, uint16_t* out, int Cout, int Kpad, int K, hipStream_t st);
 void iss_dhl_launch(const DhlArgs& a, hipStream_t st, bool f16);
 

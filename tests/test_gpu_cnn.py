@@ -570,3 +570,43 @@ def test_f16x3_mode(ctx, net, nmel, ncls):
     assert any(k.startswith('conv_igemm_kernel') for k in used), used        # the small trailing layers: exact f32
     assert np.abs(p_h - ref).max() < 1e-4 and np.array_equal(p_h.argmax(1)[rfin], ref.argmax(1)[rfin])
     assert dlogp(p_h) < 1e-4 and dlogp(p_h) < 0.5 * dlogp(p_b)
+
+
+@pytest.mark.parametrize('width', [36, 196, 320, 512, 772])
+def test_first_dense_layer_wider_than_one_column_tile(ctx, prec, width):
+    """conv_dhl_kernel holds a 128 x 192 tile; a wider first dense layer runs as column tiles (blockIdx.y, its packed weights one
+    [K / 32][4][2][192][8] block per tile, zero columns behind Cout).  Widths below, at a ragged multiple of and far above 192:
+    within 1e-4 of the oracle, and bit-identical to conv_x3_pw_kernel on the f32 hand-over (ISS_DIAG 'no_hl': the same operand
+    split, the same products in the same k order)."""
+    import topologies as TP
+    rng = np.random.default_rng(500 + width)
+    spec = TP.SPECS['standin'][:10] + [('flatten',), ('dense', width, 'linear'), ('bn_relu',), ('drop',), ('dense', 128)]
+    layers, shp = TP.build(spec, 21, 3, seed=width)
+    ctx.cnn_load(3, KM.compile_layers(layers, shp))
+    for T in (141, 700, 2400):
+        mspec = _mspec(rng, T)
+        ctx.set_mspec(mspec)
+        rows = np.arange(0, T - 68 + 1, 2, dtype=np.int32)
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        p_new, f_new = ctx.cnn_probs(3, rows)
+        used = {e['kernel'] for e in ctx.prof_instances()}
+        ctx.prof_enable(False)
+        ctx.set_diag('no_hl')
+        try:
+            ctx.prof_enable(True)
+            ctx.prof_reset()
+            p_f32, f_f32 = ctx.cnn_probs(3, rows)
+            used_f32 = {e['kernel'] for e in ctx.prof_instances()}
+            ctx.prof_enable(False)
+        finally:
+            ctx.set_diag(0)
+        ref, rfin = _oracle_probs(layers, mspec, 21, rows)
+        assert np.array_equal(f_new, rfin) and np.array_equal(f_new, f_f32)
+        assert np.abs(p_new - ref).max() < 1e-4, (width, T, np.abs(p_new - ref).max())
+        if prec != 'f32':
+            assert any(k.startswith('conv_dhl_kernel') for k in used), (width, T, sorted(used))
+            # (with fp16 halves the f32 hand-over runs conv2 .. conv4 on bf16 halves -- the fp16 forms exist on the CHL path only: nothing to equal)
+            if prec == 'bf16x3':
+                assert any(k.startswith('conv_x3_pw_kernel') for k in used_f32), (width, T, sorted(used_f32))
+                assert np.array_equal(p_new, p_f32), (width, T, np.abs(p_new - p_f32).max())

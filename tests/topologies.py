@@ -105,6 +105,10 @@ SPECS = {
     'dense512x4': [('conv', 4, 5, 64), ('bn_relu',), ('conv', 5, 3, 64), ('bn_relu',), ('maxpool', 2, 2),
                    ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 2),
                    ('flatten',), ('dense', 512), ('drop',), ('dense', 512), ('drop',), ('dense', 512), ('drop',), ('dense', 512)],
+    # the first dense layer wider than conv_dhl_kernel's 192-column tile (column tiles in blockIdx.y), behind a (2, 1) pool
+    'dense512_first': [('conv', 4, 5, 64), ('bn_relu',), ('conv', 5, 3, 64), ('bn_relu',), ('maxpool', 2, 2),
+                       ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 1),
+                       ('flatten',), ('dense', 512, 'linear'), ('bn_relu',), ('drop',), ('dense', 128)],
     'conv1_same': [('conv', 4, 5, 64, 'same'), ('bn_relu',), ('conv', 5, 3, 64), ('bn_relu',), ('maxpool', 2, 2),
                    ('conv', 3, 3, 128), ('bn_relu',), ('conv', 3, 3, 128), ('bn_relu',), ('maxpool', 2, 1)] + HEAD,
     'conv1_pool': [('conv', 4, 5, 64), ('bn_relu',), ('maxpool', 2, 2), ('conv', 5, 3, 64), ('bn_relu',),
