@@ -1560,8 +1560,15 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
         const bool patch = R[ISS_C_INMODE] == 1;
         // (fp16 mode) a small layer -- under 0.5 % of the network's arithmetic -- that no fp16 kernel takes: exact f32
         const double row_flops = 2.0 * R[ISS_C_KH] * R[ISS_C_KW] * R[ISS_C_CIN] * (double)R[ISS_C_COUT] * R[ISS_C_HO] * R[ISS_C_WO];
-        const bool small_row = f16mode && pend < 0 && row_flops < 0.005 * net_flops && row_flops < 2e6 &&      // (and small in absolute terms: a
-                               R[ISS_C_INMODE] == 0 && !can_defer(r);                                         //  ResNet-101 has 105 layers under 1 %)
+        const bool small_cand = f16mode && pend < 0 && row_flops < 0.005 * net_flops && row_flops < 2e6 &&     // (and small in absolute terms: a
+                                R[ISS_C_INMODE] == 0 && !can_defer(r);                                        //  ResNet-101 has 105 layers under 1 %)
+        // ... unless it is a dense layer of some width (a 512 -> 512 head: 0.5 MFLOP per window, 66 TFLOP/s on conv_igemm_kernel, 5 % of
+        // such a net's step): conv_x3_pw_kernel has an fp16 form for any K, so it takes the layer instead of the streaming kernels
+        const bool f16_dense_pw = small_cand && row_flops >= 2.5e5 && a.H_k == 1 && a.kw == 1 && a.H == 1 && a.W == 1 && R[ISS_C_HO] == 1 &&
+                                  R[ISS_C_WO] == 1 && a.pp == 1 && a.sh == 1 && a.sw == 1 && a.pt_ == 0 && a.pl_ == 0 && a.Cout % 4 == 0 && a.Cin % XBK == 0 &&
+                                  a.Kpad == a.Cin && !a.res &&
+                                  (c->diag & ISS_DIAG_NO_PW) == 0;
+        const bool small_row = small_cand && !f16_dense_pw;
         const bool x3 = x3mode && !small_row;
         bool row_f16 = f16mode;                                  // cleared below where the launch has no fp16 form
         const bool in_is_hl = R[ISS_C_IN] != ISS_BUF_INPUT && hl_np.count(R[ISS_C_IN]) != 0;     // (only conv_x3_wq3h_kernel reads that layout)
@@ -2063,7 +2070,7 @@ int run_program(iss_ctx* c, IssNet& n, int bc, const int32_t* d_winrow, const fl
             const bool no_pws = (c->diag & ISS_DIAG_NO_PWS) != 0;                // diagnostic: the round-2 pointwise kernel everywhere
 #endif
             const bool no_pws2 = (c->diag & ISS_DIAG_NO_PWS2) != 0;              // diagnostic: 64-column tiles everywhere
-            const bool pws_ok = !no_pws && a.Kpad <= 2048;
+            const bool pws_ok = !no_pws && a.Kpad <= 2048 && !f16_dense_pw;        // (fp16 mode: a dense layer that would otherwise run in exact f32)
             // strided 1x1 (the shortcut projections): the 128-column kernel on a strided pixel list
             const bool pw_strided = pws_ok && !no_pws2 && a.mode == 0 && tr && a.H_k == 1 && a.kw == 1 && (a.sh > 1 || a.sw > 1) && a.pt_ == 0 &&
                                     a.pl_ == 0 && a.Kpad == a.Cin && issk::pws2_strided_supported(a, R[ISS_C_HO], R[ISS_C_WO]);
