@@ -142,7 +142,11 @@ def main():
     # one BLAS / OpenMP thread for the conda interpreter: the reference's own mfcc (a float32 matmul in its mel step) is not
     # bit-reproducible across thread counts there, which made short_padded_mspec / patches_short_* differ by ~2e-6 between two
     # runs of this script (round-3 review); the oracle is checked against whatever this run recorded either way
-    env1 = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1')
+    # ... nor across HOSTS: that interpreter's numpy 1.26 carries a DYNAMIC_ARCH OpenBLAS 0.3.23 which picks its sgemm kernel by the CPU
+    # model it recognises (an AVX-512 Xeon it knows: SkylakeX; a newer Xeon it does not know: Prescott, SSE3 only -- seen on two
+    # build containers of round 6, 1-ulp differences in 45 values of short_padded_mspec).  Pinned to the AVX2 kernels every x86
+    # server of the last decade runs, so that this fixture regenerates byte-identically wherever the script is run
+    env1 = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', OPENBLAS_CORETYPE='Haswell')
     subprocess.run(['/opt/conda/bin/python3.9', f'{HERE}/ref_segmenter_pin.py', f'{HERE}/sidekit_feats.npz', pin], check=True, env=env1)
     check_segmenter_pin(np.load(pin), np.load(f'{HERE}/sidekit_feats.npz'))
 
