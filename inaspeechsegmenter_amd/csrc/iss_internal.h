@@ -74,7 +74,7 @@ struct iss_ctx {
 
     // CNN engine
     IssNet nets[ISS_MAX_NETS];
-    uint64_t ws_limit = 12ull << 30;
+    uint64_t ws_limit = 24ull << 30;                // of 288 GB: the x-vector net then runs the 1 816 windows per pass its 2^31-element buffers allow (12 GiB: 1 072, -2 %)
     int precision = ISS_PREC_F16X3;
     float guard_threshold = 5e-4f;        // precision guard: escalate a patch network to exact f32 above this max |d log p| (<= 0: guard off)
     bool in_guard = false;

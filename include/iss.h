@@ -43,7 +43,7 @@ void        iss_destroy(iss_ctx* ctx);
 const char* iss_last_error(const iss_ctx* ctx);
 const char* iss_version(void);
 /* Cap (bytes) on the activation workspace of the CNN engine; decides how many
- * 20 ms slots are pushed through the layer stack per pass.  Default 12 GiB.    */
+ * 20 ms slots are pushed through the layer stack per pass.  Default 24 GiB.    */
 int         iss_set_workspace_limit(iss_ctx* ctx, uint64_t bytes);
 int         iss_synchronize(iss_ctx* ctx);
 

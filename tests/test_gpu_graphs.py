@@ -39,7 +39,7 @@ def test_graph_model_parity(ctx, name):
         scattered = np.sort(rng.choice(T - 68, 97, replace=False)).astype(np.int32)
         _check(ctx, layers, shp, mspec, scattered, (name, nmel, 'scattered'))
         # several passes instead of one: buffers are sized per pass, the merge rows work on whatever the pass holds
-        prev = getattr(ctx, 'workspace_limit', None) or (12 << 30)
+        prev = getattr(ctx, 'workspace_limit', None) or (24 << 30)
         per_slot = 4 * int(np.sum(KM.compile_layers(layers, shp).buf_elems))
         ctx.set_workspace_limit(max(per_slot * (len(rows) // 8 + 1), 64 << 20))       # (64 MiB is the floor: >= 2 passes for every net here)
         try:

@@ -77,7 +77,7 @@ def test_topology_parity(ctx, name):
             assert np.array_equal(f_off, fin) and d_off < 5e-5, (name, net, d_off)
             # ... and in ~10 passes instead of one (per-pass first-layer rows, per-window edge rows and window scalars are
             # indexed relative to the pass): the same probabilities up to where the tile boundaries fall
-            prev_limit = getattr(ctx, 'workspace_limit', None) or (12 << 30)
+            prev_limit = getattr(ctx, 'workspace_limit', None) or (24 << 30)
             ctx.set_workspace_limit(64 << 20)
             try:
                 p_ch, f_ch = ctx.cnn_probs(5, rows)
